@@ -1,0 +1,82 @@
+"""ctypes binding of the C-ABI library (include/bayeformers_amd.h -> lib/libbayeformers_amd.so).
+
+The product path has no fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbayeformers_amd.so")
+
+BF_DT_F32, BF_DT_BF16, BF_DT_F16 = 0, 1, 2
+BF_PRIOR_MIXTURE, BF_PRIOR_GAUSSIAN, BF_PRIOR_NONE = 0, 1, 2
+
+
+class bf_prior_t(ctypes.Structure):
+    _fields_ = [
+        ("kind", ctypes.c_int32),
+        ("pi", ctypes.c_float),
+        ("sigma1", ctypes.c_float),
+        ("sigma2", ctypes.c_float),
+        ("d_mu", ctypes.c_void_p),
+        ("d_rho", ctypes.c_void_p),
+    ]
+
+
+class bf_tensor_t(ctypes.Structure):
+    _fields_ = [
+        ("d_mu", ctypes.c_void_p),
+        ("d_rho", ctypes.c_void_p),
+        ("n", ctypes.c_uint64),
+        ("prior", bf_prior_t),
+        ("stream_id", ctypes.c_uint32),
+        ("out_dtype", ctypes.c_int32),
+        ("d_sample_out", ctypes.c_void_p),
+    ]
+
+
+# every symbol include/bayeformers_amd.h declares: name -> (restype, argtypes)
+_vp, _i, _u32, _u64, _i64, _sz = (ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int64,
+                                  ctypes.c_size_t)
+_tp = ctypes.POINTER(bf_tensor_t)
+SYMBOLS = {
+    "bf_version": (_i, []),
+    "bf_last_error": (ctypes.c_char_p, []),
+    "bf_device_info": (_i, [ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "bf_philox_normal_host": (_i, [_vp, _u64, _u64, _u32, _u32, _u64]),
+    "bf_philox_normal": (_i, [_vp, _u64, _i, _u64, _u32, _u32, _vp]),
+    "bf_sample_logprob_workspace_bytes": (_sz, [_tp, _i, _i]),
+    "bf_sample_logprob": (_i, [_tp, _i, _i, _u64, _u32, _vp, _vp, _sz, _vp]),
+    "bf_gemm_nt": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "bf_linear_fwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "bf_linear_fwd": (_i, [_vp, _i, _i64, _tp, _tp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u32, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+class BayeFormersAMDError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BayeFormersAMDError(
+                f"{LIB_PATH} is missing: build it with `python -m bayeformers_amd.build` "
+                "(there is no CPU or PyTorch fallback for the Monte-Carlo forward path)")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError here = header/library drift
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().bf_last_error()
+        raise BayeFormersAMDError(f"{what} failed: {msg.decode() if msg else 'unknown error'}")

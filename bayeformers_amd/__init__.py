@@ -1,0 +1,44 @@
+# -*- coding: utf-8 -*-
+"""bayeformers_amd — MI355X-native Monte-Carlo variational forward path with the BayeFormers API.
+
+    from bayeformers_amd import to_bayesian
+    import bayeformers_amd.nn as bnn
+
+`to_bayesian` mirrors /root/reference/bayeformers/__init__.py:19-63.
+"""
+from copy import deepcopy
+from typing import Optional
+
+import torch.nn
+
+from . import nn  # noqa: F401  (bayeformers_amd.nn)
+from .nn import TORCH2BAYE
+from .nn.model import Model
+from .nn.parameters.base import Parameter
+from .nn.parameters.gaussian import DEFAULT_SCALED_GAUSSIAN_MIXTURE
+from .nn.parameters.initializations import DEFAULT_UNIFORM, Initialization
+from .random import get_compute_dtype, manual_seed, set_compute_dtype  # noqa: F401
+
+__all__ = ["to_bayesian", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype"]
+
+
+def to_bayesian(model: torch.nn.Module, initialization: Optional[Initialization] = DEFAULT_UNIFORM,
+                prior: Optional[Parameter] = DEFAULT_SCALED_GAUSSIAN_MIXTURE, delta: float = None,
+                freeze: bool = False) -> Model:
+    """Deep-copy `model`, swap every layer whose exact class is in TORCH2BAYE for its Bayesian equivalent
+    (`from_frequentist(layer, initialization, prior, delta, freeze)`, children visited in `named_children` order,
+    depth first) and wrap the result in `bnn.Model`.
+
+    Arguments / keyword arguments are the reference's: `delta` not None selects MOPED initialisation from the
+    pretrained weights (Krishnan et al., arXiv:1906.05323), `freeze` freezes the posterior means."""
+
+    def swap(module):
+        for name, child in module.named_children():
+            bayesian_cls = TORCH2BAYE.get(child.__class__)
+            if bayesian_cls is not None:
+                setattr(module, name, bayesian_cls.from_frequentist(child, initialization, prior, delta, freeze))
+            swap(child)
+
+    new_model = deepcopy(model)
+    swap(new_model)
+    return Model(model=new_model)

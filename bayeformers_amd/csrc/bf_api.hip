@@ -1,0 +1,134 @@
+// bf_api.hip — the extern "C" surface declared in include/bayeformers_amd.h.
+#include <string.h>
+
+#include "bf_common.h"
+#include "bf_philox.h"
+
+static thread_local char g_err[512] = "";
+
+void bf_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int bf_version(void) { return BF_VERSION_MAJOR * 1000 + BF_VERSION_MINOR; }
+
+const char* bf_last_error(void) { return g_err; }
+
+int bf_device_info(char* name, size_t name_len, int* n_cu, int* wave_size) {
+    int dev = 0;
+    BF_HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    BF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    if (name && name_len) {
+        strncpy(name, prop.gcnArchName, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (wave_size) *wave_size = prop.warpSize;
+    return 0;
+}
+
+int bf_philox_normal_host(float* out, uint64_t n, uint64_t seed, uint32_t sample, uint32_t stream_id,
+                          uint64_t offset) {
+    if (!out && n) BF_FAIL("bf_philox_normal_host: out is NULL");
+    uint64_t i = 0;
+    while (i < n) {
+        const uint64_t e = offset + i;
+        float z[4];
+        bf_normal4_host(e >> 2, sample, stream_id, seed, z);
+        for (uint64_t j = e & 3; j < 4 && i < n; ++j, ++i) out[i] = z[j];
+    }
+    return 0;
+}
+
+int bf_philox_normal(float* d_out, uint64_t n, int S, uint64_t seed, uint32_t sample_base, uint32_t stream_id,
+                     void* stream) {
+    if (!d_out && n) BF_FAIL("bf_philox_normal: d_out is NULL");
+    return bf_launch_philox_normal(d_out, n, S, seed, sample_base, stream_id, (hipStream_t)stream);
+}
+
+size_t bf_sample_logprob_workspace_bytes(const bf_tensor_t* tensors, int n_tensors, int S) {
+    if (!tensors || n_tensors < 1 || S < 1) return 0;
+    return bf_sample_partials_bytes(tensors, n_tensors, S);
+}
+
+int bf_sample_logprob(const bf_tensor_t* tensors, int n_tensors, int S, uint64_t seed, uint32_t sample_base,
+                      double* d_logprob_out, void* d_workspace, size_t workspace_bytes, void* stream) {
+    if (!tensors) BF_FAIL("bf_sample_logprob: tensors is NULL");
+    return bf_launch_sample_logprob(tensors, n_tensors, S, seed, sample_base, d_logprob_out, d_workspace,
+                                    workspace_bytes, (hipStream_t)stream);
+}
+
+int bf_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
+               const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, void* stream) {
+    return bf_launch_gemm_nt(d_x, x_dtype, x_sample_stride, d_w, w_dtype, d_bias, d_y, y_dtype, S, M, N, K,
+                             (hipStream_t)stream);
+}
+
+// workspace layout of bf_linear_fwd: [W_s : S*N*K compute_dtype][b_s : S*N fp32][log-prob partials]
+static void linear_ws_layout(int S, int N, int K, int has_bias, int compute_dtype, size_t* off_w, size_t* off_b,
+                             size_t* off_p, size_t* total) {
+    const size_t wbytes = bf_align_up((size_t)S * N * K * bf_dtype_size(compute_dtype), 256);
+    const size_t bbytes = has_bias ? bf_align_up((size_t)S * N * sizeof(float), 256) : 0;
+    bf_tensor_t t[2];
+    memset(t, 0, sizeof(t));
+    t[0].n = (uint64_t)N * K;
+    t[1].n = (uint64_t)N;
+    const size_t pbytes = bf_sample_partials_bytes(t, has_bias ? 2 : 1, S);
+    *off_w = 0;
+    *off_b = wbytes;
+    *off_p = wbytes + bbytes;
+    *total = wbytes + bbytes + pbytes;
+}
+
+size_t bf_linear_fwd_workspace_bytes(int S, int M, int N, int K, int has_bias, int compute_dtype, int x_dtype) {
+    (void)M;
+    (void)x_dtype;
+    if (S < 1 || N < 1 || K < 1) return 0;
+    size_t ow, ob, op, total;
+    linear_ws_layout(S, N, K, has_bias, compute_dtype, &ow, &ob, &op, &total);
+    return total;
+}
+
+int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const bf_tensor_t* weight,
+                  const bf_tensor_t* bias, void* d_y, int y_dtype, int compute_dtype, int S, int M, int N, int K,
+                  uint64_t seed, uint32_t sample_base, double* d_logprob_out, void* d_workspace,
+                  size_t workspace_bytes, void* stream) {
+    if (!weight) BF_FAIL("bf_linear_fwd: weight is NULL");
+    if (S < 1 || M < 1 || N < 1 || K < 1) BF_FAIL("bf_linear_fwd: bad shape S=%d M=%d N=%d K=%d", S, M, N, K);
+    if (weight->n != (uint64_t)N * (uint64_t)K)
+        BF_FAIL("bf_linear_fwd: weight.n=%llu != N*K=%llu", (unsigned long long)weight->n,
+                (unsigned long long)N * (unsigned long long)K);
+    if (bias && bias->n != (uint64_t)N) BF_FAIL("bf_linear_fwd: bias.n=%llu != N=%d", (unsigned long long)bias->n, N);
+    if (compute_dtype < BF_DT_F32 || compute_dtype > BF_DT_F16) BF_FAIL("bf_linear_fwd: bad compute dtype %d", compute_dtype);
+    size_t ow, ob, op, total;
+    linear_ws_layout(S, N, K, bias != nullptr, compute_dtype, &ow, &ob, &op, &total);
+    if (!d_workspace || workspace_bytes < total)
+        BF_FAIL("bf_linear_fwd: workspace too small (%zu < %zu bytes)", workspace_bytes, total);
+    char* ws = reinterpret_cast<char*>(d_workspace);
+
+    bf_tensor_t t[2];
+    t[0] = *weight;
+    t[0].d_sample_out = ws + ow;
+    t[0].out_dtype = compute_dtype;
+    int nt = 1;
+    if (bias) {
+        t[1] = *bias;
+        t[1].d_sample_out = ws + ob;
+        t[1].out_dtype = BF_DT_F32;
+        nt = 2;
+    }
+    int rc = bf_launch_sample_logprob(t, nt, S, seed, sample_base, d_logprob_out, ws + op, total - op,
+                                      (hipStream_t)stream);
+    if (rc) return rc;
+    return bf_launch_gemm_nt(d_x, x_dtype, x_sample_stride, ws + ow, compute_dtype,
+                             bias ? reinterpret_cast<const float*>(ws + ob) : nullptr, d_y, y_dtype, S, M, N, K,
+                             (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// bf_common.h — internal helpers shared by the HIP translation units (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/bayeformers_amd.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+// thread-local error string behind bf_last_error()
+void bf_set_error(const char* fmt, ...);
+
+#define BF_FAIL(...)               \
+    do {                           \
+        bf_set_error(__VA_ARGS__); \
+        return 1;                  \
+    } while (0)
+
+#define BF_HIP_CHECK(expr)                                                                      \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) BF_FAIL("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+static inline size_t bf_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline size_t bf_dtype_size(int dt) { return dt == BF_DT_F32 ? 4 : 2; }
+
+// internal launchers (defined in bf_sample.hip / bf_gemm.hip), all asynchronous on `stream`
+int bf_launch_philox_normal(float* d_out, uint64_t n, int S, uint64_t seed, uint32_t sample_base, uint32_t stream_id,
+                            hipStream_t stream);
+size_t bf_sample_partials_bytes(const bf_tensor_t* tensors, int n_tensors, int S);
+int bf_launch_sample_logprob(const bf_tensor_t* tensors, int n_tensors, int S, uint64_t seed, uint32_t sample_base,
+                             double* d_logprob_out, void* d_workspace, size_t workspace_bytes, hipStream_t stream);
+int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
+                      const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, hipStream_t stream);

@@ -1,0 +1,95 @@
+// bf_philox.h — the epsilon contract of bayeformers_amd, shared by host and gfx950 device code.
+//
+// The reference draws eps with torch.distributions.Normal(0,1).sample(size) from the global generator
+// (/root/reference/bayeformers/nn/parameters/gaussian.py:100).  A stateful stream cannot be regenerated
+// inside a tiled kernel, sharded over GPUs or replayed in backward, so this build defines eps as a pure
+// function of (seed, sample index, stream id, element index):
+//
+//   group g = e >> 2, component j = e & 3
+//   (x0,x1,x2,x3) = Philox4x32-10(counter = {lo32(g), sample, stream, hi32(g)}, key = {lo32(seed), hi32(seed)})
+//   u(x)  = fmaf((float)x, 2^-32, 2^-33)                      in (0, 1], fp32, identical on host and device
+//   (z0,z1) = BoxMuller(u(x0), u(x1)), (z2,z3) = BoxMuller(u(x2), u(x3)),  eps_e = z_j
+//   BoxMuller(u1,u2) = (r cos(2 pi u2), r sin(2 pi u2)),  r = sqrt(-2 ln u1)
+//
+// stream = 2*layer_id + tensor_id (0 = weight, 1 = bias).  The host twin evaluates Box-Muller in fp64 and
+// rounds once; the device uses the gfx950 transcendental units (v_log_f32, v_sqrt_f32, v_sin_f32/v_cos_f32,
+// whose argument is already in revolutions) — the two agree to a few 1e-7 absolute (tests/test_gpu_philox.py).
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define BF_HD __host__ __device__ __forceinline__
+#define BF_D __device__ __forceinline__
+#else
+#define BF_HD static inline
+#endif
+
+#define BF_PHILOX_M0 0xD2511F53u
+#define BF_PHILOX_M1 0xCD9E8D57u
+#define BF_PHILOX_W0 0x9E3779B9u
+#define BF_PHILOX_W1 0xBB67AE85u
+
+struct bf_u32x4 {
+    uint32_t x, y, z, w;
+};
+
+// Philox4x32 with 10 rounds (Salmon et al., SC'11).  Round r uses key + r*W; the key is bumped between rounds.
+BF_HD bf_u32x4 bf_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)BF_PHILOX_M0 * c0;
+        const uint64_t p1 = (uint64_t)BF_PHILOX_M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += BF_PHILOX_W0;
+        k1 += BF_PHILOX_W1;
+    }
+    bf_u32x4 o = {c0, c1, c2, c3};
+    return o;
+}
+
+BF_HD float bf_u32_to_unit(uint32_t x) {
+    // exact in both worlds: cvt u32->f32 (RNE) followed by one fused multiply-add
+    return fmaf((float)x, 2.3283064365386963e-10f /* 2^-32 */, 1.1641532182693481e-10f /* 2^-33 */);
+}
+
+// Host twin: fp64 Box-Muller on the fp32 uniforms, rounded once to fp32.
+static inline void bf_box_muller_host(uint32_t a, uint32_t b, float* z0, float* z1) {
+    const double u1 = (double)bf_u32_to_unit(a);
+    const double u2 = (double)bf_u32_to_unit(b);
+    const double r = sqrt(-2.0 * log(u1));
+    const double t = 6.283185307179586476925286766559 * u2;
+    *z0 = (float)(r * cos(t));
+    *z1 = (float)(r * sin(t));
+}
+
+static inline void bf_normal4_host(uint64_t group, uint32_t sample, uint32_t stream, uint64_t seed, float z[4]) {
+    const bf_u32x4 x = bf_philox4x32_10((uint32_t)group, sample, stream, (uint32_t)(group >> 32), (uint32_t)seed,
+                                        (uint32_t)(seed >> 32));
+    bf_box_muller_host(x.x, x.y, &z[0], &z[1]);
+    bf_box_muller_host(x.z, x.w, &z[2], &z[3]);
+}
+
+#if defined(__HIPCC__) || defined(__HIP__)
+// Device Box-Muller on the hardware transcendental units.
+//   v_log_f32 is log2; v_sin_f32 / v_cos_f32 take their argument in revolutions (valid for |x| <= 256).
+BF_D void bf_box_muller_dev(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float u1 = bf_u32_to_unit(a);
+    const float u2 = bf_u32_to_unit(b);
+    // -2 ln(u1) = (-2 ln 2) * log2(u1)
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    z0 = r * __builtin_amdgcn_cosf(u2);
+    z1 = r * __builtin_amdgcn_sinf(u2);
+}
+
+BF_D void bf_normal4_dev(uint32_t group_lo, uint32_t group_hi, uint32_t sample, uint32_t stream, uint32_t k0,
+                         uint32_t k1, float z[4]) {
+    const bf_u32x4 x = bf_philox4x32_10(group_lo, sample, stream, group_hi, k0, k1);
+    bf_box_muller_dev(x.x, x.y, z[0], z[1]);
+    bf_box_muller_dev(x.z, x.w, z[2], z[3]);
+}
+#endif

@@ -1,0 +1,151 @@
+# -*- coding: utf-8 -*-
+"""bayeformers_amd.nn.layers.linear
+
+Bayesian equivalent of torch.nn.Linear — same constructor, attributes, state-dict keys and `from_frequentist`
+as /root/reference/bayeformers/nn/layers/linear.py (Linear :25-81, forward :83-104, from_frequentist :106-165).
+
+forward() is ONE call into the C-ABI (bf_linear_fwd): the fused HIP kernel draws eps from the Philox counter,
+forms W_s = mu + softplus(rho) * eps for all S Monte-Carlo samples, accumulates log_prior and
+log_variational_posterior exactly once per scalar, and the MFMA GEMM computes y[s] = x[s] W_s^T + b_s.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch import Size, Tensor
+from torch.nn import Module
+
+from ... import ops
+from ... import random as bfr
+from ..parameters.base import NoneParameter, Parameter
+from ..parameters.gaussian import DEFAULT_SCALED_GAUSSIAN_MIXTURE, Gaussian
+from ..parameters.initializations import DEFAULT_UNIFORM, Initialization
+
+_LOGPROB_NAMES = ("log_prior", "log_variational_posterior")
+
+
+class _LinearFn(torch.autograd.Function):
+    """Autograd node of the fused forward.  Backward (dL/dmu = dL/dW, dL/drho = dL/dW * eps * sigmoid(rho) with eps
+    regenerated from the Philox counter) is the next milestone."""
+
+    @staticmethod
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, layer, S, seed, base, lp_out):
+        return ops.linear_forward(layer, x, S, seed, base, lp_out)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise NotImplementedError(
+            "bayeformers_amd: backward of the fused Monte-Carlo forward is not implemented yet; "
+            "run the forward + ELBO value under torch.no_grad()")
+
+
+class Linear(Module):
+    """Bayesian Linear layer with Gaussian weight/bias posteriors and a prior per parameter.
+
+    Attributes (as the reference): in_features, out_features, initialization, weight, weight_prior, bias,
+    bias_prior, log_prior, log_variational_posterior.  Additional: layer_id (Philox stream), compute_dtype
+    (None = bayeformers_amd.get_compute_dtype()), log_prob_samples ([S, 2] float64 of the last forward).
+    """
+
+    def __init__(self, in_features: int, out_features: int, bias: Optional[bool] = True,
+                 initialization: Optional[Initialization] = DEFAULT_UNIFORM,
+                 prior: Optional[Parameter] = DEFAULT_SCALED_GAUSSIAN_MIXTURE) -> None:
+        super(Linear, self).__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.initialization = initialization
+
+        size = Size((self.out_features, self.in_features))
+        self.weight = Gaussian(size, self.initialization)
+        self.weight_prior = prior
+
+        if bias:
+            size = Size((self.out_features,))
+            self.bias = Gaussian(size, self.initialization)
+            self.bias_prior = prior
+        else:
+            self.bias = NoneParameter()
+            self.bias_prior = NoneParameter()
+
+        self.register_parameter("log_prior", nn.Parameter(torch.tensor(0.), requires_grad=False))
+        self.register_parameter("log_variational_posterior", nn.Parameter(torch.tensor(0.), requires_grad=False))
+
+        self.layer_id = bfr.new_layer_id()
+        self.compute_dtype = None
+        self._plan = ops.LinearPlan()
+        self._lp_own = None    # [S, 2] float64 buffer when the layer is used outside a bnn.Model
+        self._lp_view = None   # where the last forward wrote {log_prior, log_q} per sample
+        self._lp_dirty = False
+
+    # --- log_prior / log_variational_posterior are refreshed lazily from the kernel's [S, 2] output ---------------
+    def __getattr__(self, name):
+        if name in _LOGPROB_NAMES and self.__dict__.get("_lp_dirty", False):
+            self._sync_logprobs()
+        return super(Linear, self).__getattr__(name)
+
+    def _sync_logprobs(self) -> None:
+        self.__dict__["_lp_dirty"] = False
+        v = self._lp_view.mean(0).to(torch.float32)
+        self._parameters["log_prior"].data = v[0]
+        self._parameters["log_variational_posterior"].data = v[1]
+
+    @property
+    def log_prob_samples(self) -> Optional[Tensor]:
+        """[S, 2] float64 {log_prior, log_variational_posterior} of each sample of the last forward."""
+        return self._lp_view
+
+    def forward(self, input: Tensor) -> Tensor:
+        """y = x W^T + b with W ~ N(mu_w, softplus(rho_w)), b ~ N(mu_b, softplus(rho_b))  (linear.py:83-104).
+
+        Inside `bnn.Model` with S Monte-Carlo samples in flight the input is [S*B, ..., in_features]
+        (sample-major) and slab s is multiplied by W_s; otherwise S = 1 and one fresh sample index is used."""
+        ctx = bfr.STATE.ctx
+        if ctx is not None:
+            base, S, slot = ctx.sample_base, ctx.S, ctx.slot(self)
+        else:
+            base, S, slot = bfr.reserve_samples(1), 1, None
+        if slot is None:
+            if self._lp_own is None or self._lp_own.shape[0] != S or self._lp_own.device != input.device:
+                self._lp_own = torch.zeros((S, 2), dtype=torch.float64, device=input.device)
+            slot = self._lp_own
+        x2 = input.reshape(-1, self.in_features)
+        mu_b = self.bias.mu if isinstance(self.bias, Gaussian) else None
+        rho_b = self.bias.rho if isinstance(self.bias, Gaussian) else None
+        y = _LinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, self, S, bfr.STATE.seed, base, slot)
+        self._lp_view = slot
+        self._lp_dirty = True
+        return y.view(*input.shape[:-1], self.out_features)
+
+    @classmethod
+    def from_frequentist(cls, linear: Module, initialization: Optional[Initialization] = DEFAULT_UNIFORM,
+                         prior: Optional[Parameter] = DEFAULT_SCALED_GAUSSIAN_MIXTURE, delta: float = None,
+                         freeze: bool = False) -> "Linear":
+        """Bayesian layer from a frequentist nn.Linear (linear.py:106-165).
+
+        With `delta` (MOPED, Krishnan et al. 2020): mu <- w (shares storage), rho <- log(exp(delta |w|) - 1) with
+        -inf -> 0.0, mu frozen if `freeze`, prior <- Gaussian(mu = w, rho = 1), same for the bias.  The fp32
+        expressions are the reference's, so the resulting rho is bit-identical.  As in the reference
+        (linear.py:137) `initialization` is not forwarded to the constructor."""
+        baye = cls(linear.in_features, linear.out_features, linear.bias is not None, prior=prior)
+        if delta is not None:
+            baye.weight_prior = _moped(baye.weight, linear.weight, delta, freeze)
+            if linear.bias is not None:
+                baye.bias_prior = _moped(baye.bias, linear.bias, delta, freeze)
+        return baye
+
+
+def _moped(posterior: Gaussian, source: Tensor, delta: float, freeze: bool) -> Gaussian:
+    """MOPED initialisation of one parameter from its pretrained value, returning its empirical-Bayes prior
+    (linear.py:139-150 for the weight, :152-163 for the bias): the posterior mean takes over the pretrained
+    tensor's storage, sigma = delta * |w| is stored as rho = log(exp(delta |w|) - 1) (fp32; where that expression
+    gives -inf, i.e. delta |w| < ~6e-8, rho is set to 0), and the prior is N(w, softplus(1))."""
+    pretrained = source.data
+    rho = torch.log(torch.exp(delta * torch.abs(pretrained)) - 1.0)
+    rho[rho == float("-inf")] = 0.0
+    posterior.mu.data = pretrained
+    posterior.rho.data = rho
+    posterior.mu.requires_grad = not freeze
+
+    prior = Gaussian(posterior.mu.size())  # draws its Uniform init like the reference, then is overwritten
+    prior.mu.data = pretrained
+    prior.rho.data = torch.ones_like(source)
+    return prior

@@ -1,0 +1,153 @@
+# -*- coding: utf-8 -*-
+"""bayeformers_amd.nn.model
+
+Wrapper that turns any module containing Bayesian children into a Bayesian model — same surface as
+/root/reference/bayeformers/nn/model.py (is_module_bayesian :16-28, Model :31-89).
+
+Additions for the MI355X path (all optional; with S = 1 the behaviour is the reference's):
+  * `with model.monte_carlo(S): out = model(**inputs_repeated_S_times)` runs S Monte-Carlo samples in ONE forward:
+    every bnn.Linear sees [S*B, ...] (sample-major), multiplies slab s by W_s and leaves per-sample log-probs;
+  * the per-layer {log_prior, log_q} land in one [L, S, 2] float64 buffer, so `log_prior()` is one reduction
+    instead of 74 scalar adds; `log_prior_samples()` / `log_variational_posterior_samples()` return the [S] values;
+  * all layers of one forward share the same reserved Monte-Carlo sample indices (bayeformers_amd.random).
+"""
+import contextlib
+import warnings
+from typing import Any, Iterator, List, Optional
+
+import torch
+from torch import Tensor
+from torch.nn import Module
+
+from .. import random as bfr
+from .layers.linear import Linear
+
+
+def is_module_bayesian(module: Module) -> bool:
+    """A module is Bayesian if it exposes log_prior and log_variational_posterior (model.py:16-28)."""
+    log_prior = hasattr(module, "log_prior")
+    log_variational_posterior = hasattr(module, "log_variational_posterior")
+    return log_prior and log_variational_posterior
+
+
+class _ForwardContext:
+    """What the Bayesian layers of one Model.forward share: the reserved sample indices and their log-prob slots."""
+
+    def __init__(self, sample_base: int, S: int, slots: dict):
+        self.sample_base, self.S, self._slots = sample_base, S, slots
+
+    def slot(self, layer) -> Optional[Tensor]:
+        return self._slots.get(id(layer))
+
+
+class Model(Module):
+    """Wrapper gathering log_prior and log_variational_posterior from Bayesian children.
+
+    Attributes:
+        model (Optional[nn.Module]): wrapped module (None when subclassed with its own forward)
+    """
+
+    def __init__(self, model: Optional[Module] = None) -> None:
+        super(Model, self).__init__()
+        self.model = model
+        self._mc_samples = 1
+        self._mc_shard = (0, 1)
+        self._fused: Optional[List[Linear]] = None
+        self._lp_buf: Optional[Tensor] = None
+        self._last_base = None
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, *args, **kwargs) -> Any:
+        """Forward of the wrapped module (model.py:53-57)."""
+        if self.model is not None:
+            return self.model.forward(*args, **kwargs)
+        raise NotImplementedError("Forward pass not implemented yet")
+
+    def __call__(self, *args, **kwargs):
+        if bfr.STATE.ctx is not None:  # nested bnn.Model: the outer forward owns the sample indices
+            return super(Model, self).__call__(*args, **kwargs)
+        S = self._mc_samples
+        layers = self.fused_children()
+        slots = {}
+        if layers:
+            dev = layers[0].weight.mu.device
+            buf = self._lp_buf
+            if buf is None or buf.shape[0] != len(layers) or buf.shape[1] != S or buf.device != dev:
+                buf = self._lp_buf = torch.zeros((len(layers), S, 2), dtype=torch.float64, device=dev)
+            slots = {id(l): buf[i] for i, l in enumerate(layers)}
+        rank, world = self._mc_shard
+        # every rank reserves the GLOBAL S*world indices and runs its own contiguous slice of them
+        base = bfr.reserve_samples(S * world) + rank * S
+        self._last_base = base
+        bfr.STATE.ctx = _ForwardContext(base, S, slots)
+        try:
+            return super(Model, self).__call__(*args, **kwargs)
+        finally:
+            bfr.STATE.ctx = None
+
+    @contextlib.contextmanager
+    def monte_carlo(self, samples: int, shard=(0, 1)):
+        """Run forwards with `samples` Monte-Carlo samples folded into the batch axis (inputs repeated S times,
+        sample-major: `x.repeat(S, 1, ...)`).  shard = (rank, world): this process runs `samples` of the
+        `samples * world` global sample indices of each step (S-sharding over GPUs, sampling.sample_bayesian)."""
+        prev = (self._mc_samples, self._mc_shard)
+        self._mc_samples, self._mc_shard = int(samples), (int(shard[0]), int(shard[1]))
+        try:
+            yield self
+        finally:
+            self._mc_samples, self._mc_shard = prev
+
+    def fused_children(self) -> List[Linear]:
+        """The bnn.Linear children in registration order; their layer_id (Philox stream) is that order."""
+        if self._fused is None:
+            self._fused = [m for m in self.modules() if isinstance(m, Linear)]
+            for i, l in enumerate(self._fused):
+                l.layer_id = i
+        return self._fused
+
+    def refresh(self) -> None:
+        """Re-scan the children after the module tree was edited."""
+        self._fused, self._lp_buf = None, None
+
+    # ------------------------------------------------------------------------------------------ log-probs
+    @property
+    def bayesian_children(self) -> Iterator[Module]:
+        """All Bayesian children (duck-typed, model.py:59-68)."""
+        children = filter(is_module_bayesian, self.modules())
+        children = [c for c in children if c != self]
+        return children
+
+    def _only_fused(self) -> bool:
+        return all(isinstance(c, Linear) for c in self.bayesian_children)
+
+    def _sum(self, index: int, name: str):
+        children = list(self.bayesian_children)
+        if not len(children):
+            warnings.warn("No Bayesian Child is present in this model")
+        if len(children) and self._lp_buf is not None and self._only_fused():
+            # one reduction over the [L, S, 2] buffer the kernels wrote: sum over layers, mean over samples
+            return self._lp_buf[:, :, index].sum(0).mean().to(torch.float32)
+        value = 0.0
+        for child in children:
+            value += getattr(child, name)
+        return value
+
+    def log_prior(self) -> Tensor:
+        """Sum of the children's log_prior (model.py:70-78); mean over the S samples of the last forward."""
+        return self._sum(0, "log_prior")
+
+    def log_variational_posterior(self) -> Tensor:
+        """Sum of the children's log_variational_posterior (model.py:81-89); mean over the S samples."""
+        return self._sum(1, "log_variational_posterior")
+
+    def log_prob_samples(self) -> Tensor:
+        """[S, 2] float64: per-sample {log_prior, log_variational_posterior} summed over the fused layers."""
+        if self._lp_buf is None:
+            raise RuntimeError("no forward has run yet")
+        return self._lp_buf.sum(0)
+
+    def log_prior_samples(self) -> Tensor:
+        return self.log_prob_samples()[:, 0]
+
+    def log_variational_posterior_samples(self) -> Tensor:
+        return self.log_prob_samples()[:, 1]

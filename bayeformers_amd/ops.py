@@ -1,0 +1,193 @@
+"""Host-side plumbing between torch tensors and the C-ABI (include/bayeformers_amd.h).
+
+torch is used here for device memory, the current HIP stream and autograd bookkeeping only; every arithmetic
+step of the Monte-Carlo forward path runs in the HIP kernels of csrc/.  There is no CPU fallback: tensors that
+are not on a ROCm device raise.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _C
+from . import random as bfr
+
+_TORCH2BF = {torch.float32: _C.BF_DT_F32, torch.bfloat16: _C.BF_DT_BF16, torch.float16: _C.BF_DT_F16}
+
+_WORKSPACES = {}
+
+
+def _require_device(t: Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise _C.BayeFormersAMDError(
+            f"{what} lives on '{t.device}': the bayeformers_amd forward path runs only on a ROCm device "
+            "(HIP kernels, no CPU fallback) — move the module and its inputs to 'cuda'")
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(device: torch.device, nbytes: int) -> Tensor:
+    """Per-(device, stream) scratch buffer, grown on demand (stream-ordered reuse is safe on one stream)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream_ptr())
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def philox_normal_host(n: int, seed: int, sample: int, stream_id: int, offset: int = 0) -> Tensor:
+    """Host twin of the device epsilon (bf_philox_normal_host): fp32 CPU tensor of n normals."""
+    out = torch.empty(int(n), dtype=torch.float32)
+    _C.check(_C.lib().bf_philox_normal_host(out.data_ptr(), int(n), int(seed), int(sample) & 0xFFFFFFFF,
+                                            int(stream_id), int(offset)), "bf_philox_normal_host")
+    return out
+
+
+def philox_normal(n: int, S: int, seed: int, sample_base: int, stream_id: int, device="cuda") -> Tensor:
+    """Device epsilon: [S, n] fp32 (test hook for the RNG contract)."""
+    out = torch.empty((int(S), int(n)), dtype=torch.float32, device=device)
+    _C.check(_C.lib().bf_philox_normal(out.data_ptr(), int(n), int(S), int(seed), int(sample_base) & 0xFFFFFFFF,
+                                       int(stream_id), _stream_ptr()), "bf_philox_normal")
+    return out
+
+
+def fill_prior(dst: "_C.bf_prior_t", prior) -> bool:
+    """Describe a prior module to the kernels.  Returns False for a user-defined Parameter (generic path)."""
+    from .nn.parameters.base import NoneParameter
+    from .nn.parameters.gaussian import Gaussian, ScaledGaussianMixture
+
+    if isinstance(prior, ScaledGaussianMixture):
+        pi, s1, s2 = prior.constants()
+        dst.kind, dst.pi, dst.sigma1, dst.sigma2 = _C.BF_PRIOR_MIXTURE, pi, s1, s2
+        dst.d_mu = dst.d_rho = None
+        return True
+    if isinstance(prior, Gaussian):
+        _require_device(prior.mu, "prior.mu")
+        dst.kind = _C.BF_PRIOR_GAUSSIAN
+        dst.d_mu, dst.d_rho = prior.mu.data_ptr(), prior.rho.data_ptr()
+        return True
+    if prior is None or isinstance(prior, NoneParameter):
+        dst.kind = _C.BF_PRIOR_NONE
+        dst.d_mu = dst.d_rho = None
+        return True
+    return False
+
+
+def fill_tensor(dst: "_C.bf_tensor_t", gaussian, prior, stream_id: int) -> bool:
+    mu, rho = gaussian.mu, gaussian.rho
+    _require_device(mu, "mu")
+    if not (mu.is_contiguous() and rho.is_contiguous() and mu.dtype == torch.float32 and rho.dtype == torch.float32):
+        raise _C.BayeFormersAMDError("mu/rho must be contiguous fp32 tensors")
+    dst.d_mu, dst.d_rho, dst.n = mu.data_ptr(), rho.data_ptr(), mu.numel()
+    dst.stream_id = stream_id
+    dst.d_sample_out = None
+    dst.out_dtype = _C.BF_DT_F32
+    known = fill_prior(dst.prior, prior)
+    if isinstance(prior, type(gaussian)) and prior.mu.numel() != mu.numel():
+        raise _C.BayeFormersAMDError("Gaussian prior must have the shape of the parameter it is a prior of")
+    return known
+
+
+def sample_logprob(gaussians, priors, stream_ids, S: int, seed: int, sample_base: int, out_dtype=None):
+    """Fused sampling + log-probs of 1 or 2 Gaussian parameters (bf_sample_logprob).
+
+    Returns (samples, logprob) where samples is a list of [S, *shape] tensors (or None when out_dtype is None)
+    and logprob is a [S, 2] float64 tensor {log_prior, log_variational_posterior} summed over the parameters."""
+    n = len(gaussians)
+    arr = (_C.bf_tensor_t * n)()
+    dev = gaussians[0].mu.device
+    outs = []
+    for i, (g, pr, sid) in enumerate(zip(gaussians, priors, stream_ids)):
+        if not fill_tensor(arr[i], g, pr, sid):
+            raise _C.BayeFormersAMDError("sample_logprob: user-defined priors go through Linear's generic path")
+        if out_dtype is not None:
+            o = torch.empty((S,) + tuple(g.mu.shape), dtype=out_dtype, device=dev)
+            arr[i].d_sample_out, arr[i].out_dtype = o.data_ptr(), _TORCH2BF[out_dtype]
+            outs.append(o)
+    lib = _C.lib()
+    need = lib.bf_sample_logprob_workspace_bytes(arr, n, S)
+    ws = workspace(dev, need)
+    lp = torch.empty((S, 2), dtype=torch.float64, device=dev)
+    _C.check(lib.bf_sample_logprob(arr, n, S, seed, sample_base & 0xFFFFFFFF, lp.data_ptr(), ws.data_ptr(),
+                                   ws.numel(), _stream_ptr()), "bf_sample_logprob")
+    return (outs if out_dtype is not None else None), lp
+
+
+def gemm_nt(x: Tensor, w: Tensor, bias: Optional[Tensor], S: int, M: int, N: int, K: int, x_sample_stride: int,
+            y_dtype: torch.dtype) -> Tensor:
+    """y[s] = x[s] w[s]^T + bias[s] on the matrix cores (bf_gemm_nt).  w: [S,N,K]; returns [S,M,N]."""
+    y = torch.empty((S, M, N), dtype=y_dtype, device=x.device)
+    _C.check(_C.lib().bf_gemm_nt(x.data_ptr(), _TORCH2BF[x.dtype], x_sample_stride, w.data_ptr(), _TORCH2BF[w.dtype],
+                                 bias.data_ptr() if bias is not None else None, y.data_ptr(), _TORCH2BF[y_dtype],
+                                 S, M, N, K, _stream_ptr()), "bf_gemm_nt")
+    return y
+
+
+class LinearPlan:
+    """Cached ctypes descriptors of one bnn.Linear (pointers are refreshed per call; structs are reused)."""
+
+    def __init__(self):
+        self.w = _C.bf_tensor_t()
+        self.b = _C.bf_tensor_t()
+
+
+def linear_forward(layer, x: Tensor, S: int, seed: int, sample_base: int, lp_out: Tensor) -> Tensor:
+    """Linear.forward for S samples: y[s] = x[s] W_s^T + b_s and lp_out[s] = {log_prior, log_q}.
+
+    x: [S*M, K] (sample-major) or [M, K] with S == 1.  lp_out: [S, 2] float64 on x's device."""
+    from .nn.parameters.base import NoneParameter
+
+    _require_device(x, "input")
+    K, N = layer.in_features, layer.out_features
+    if x.dtype not in _TORCH2BF:
+        raise _C.BayeFormersAMDError(f"unsupported input dtype {x.dtype}")
+    if not x.is_contiguous():
+        x = x.contiguous()
+    rows = x.numel() // K
+    if rows % S:
+        raise _C.BayeFormersAMDError(f"input rows ({rows}) are not a multiple of the sample count S={S}")
+    M = rows // S
+    cdt = layer.compute_dtype or bfr.get_compute_dtype()
+    if x.dtype != torch.float32 and x.dtype != cdt:
+        raise _C.BayeFormersAMDError(f"input dtype {x.dtype} does not match compute dtype {cdt} (fp32 inputs always do)")
+    if cdt == torch.float32 and x.dtype != torch.float32:
+        raise _C.BayeFormersAMDError("compute dtype fp32 needs fp32 inputs")
+    has_bias = not isinstance(layer.bias, NoneParameter)
+    plan = layer._plan
+    known = fill_tensor(plan.w, layer.weight, layer.weight_prior, 2 * layer.layer_id)
+    if has_bias:
+        known = fill_tensor(plan.b, layer.bias, layer.bias_prior, 2 * layer.layer_id + 1) and known
+    if not known:
+        return _linear_forward_generic(layer, x, S, M, N, K, seed, sample_base, lp_out, cdt, has_bias)
+    lib = _C.lib()
+    y = torch.empty((S * M, N), dtype=x.dtype, device=x.device)
+    need = lib.bf_linear_fwd_workspace_bytes(S, M, N, K, int(has_bias), _TORCH2BF[cdt], _TORCH2BF[x.dtype])
+    ws = workspace(x.device, need)
+    _C.check(lib.bf_linear_fwd(x.data_ptr(), _TORCH2BF[x.dtype], M * K, ctypes.byref(plan.w),
+                               ctypes.byref(plan.b) if has_bias else None, y.data_ptr(), _TORCH2BF[x.dtype],
+                               _TORCH2BF[cdt], S, M, N, K, seed, sample_base & 0xFFFFFFFF, lp_out.data_ptr(),
+                               ws.data_ptr(), ws.numel(), _stream_ptr()), "bf_linear_fwd")
+    return y
+
+
+def _linear_forward_generic(layer, x, S, M, N, K, seed, sample_base, lp_out, cdt, has_bias):
+    """User-defined prior (any Parameter with log_prob): the kernels sample W_s/b_s in fp32 and produce log q;
+    the prior's own log_prob is then called on each sample, as the reference does (layers/linear.py:99-100)."""
+    from .nn.parameters.base import NoneParameter
+
+    gs = [layer.weight] + ([layer.bias] if has_bias else [])
+    sids = [2 * layer.layer_id] + ([2 * layer.layer_id + 1] if has_bias else [])
+    outs, lp = sample_logprob(gs, [NoneParameter()] * len(gs), sids, S, seed, sample_base, out_dtype=torch.float32)
+    for s in range(S):
+        v = layer.weight_prior.log_prob(outs[0][s])
+        if has_bias:
+            v = v + layer.bias_prior.log_prob(outs[1][s])
+        lp[s, 0] = v
+    lp_out.copy_(lp)
+    w = outs[0] if cdt == torch.float32 else outs[0].to(cdt)
+    y = gemm_nt(x, w, outs[1] if has_bias else None, S, M, N, K, M * K, x.dtype)
+    return y.view(S * M, N)

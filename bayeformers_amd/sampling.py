@@ -1,0 +1,107 @@
+"""The S-sample Monte-Carlo loop and the ELBO — the user-side harness of the reference, as one batched call.
+
+Reference: `sample_bayesian` in /root/reference/examples/bert_glue.py:56-73 and examples/bert_squad.py:190-212,
+the inline loop of examples/mlp_mnist.py:97-107 and README.md:58-72 — S serial forwards, then the mean over S of
+the outputs and of the two log-prob scalars; the NLL is taken on the MEAN output and
+`loss = (lvp - log_prior) / n_batches + nll` (bert_glue.py:234-235).
+
+Here the S samples are folded into the batch axis of ONE forward (`Model.monte_carlo`), and optionally sharded
+over the ranks of a torch.distributed group: rank r runs the global sample indices
+[base + r*S/G, base + (r+1)*S/G), so per-sample results do not depend on the number of GPUs, and a single
+all-reduce (RCCL over xGMI on MI355X) of the packed [sum of outputs | sum log_prior | sum lvp] buffer finishes the
+step.  The message is KB-sized, i.e. latency-bound: one collective per step, on the compute stream.
+"""
+from typing import Any, Callable, Dict, Optional, Sequence, Tuple, Union
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from .nn.model import Model
+
+
+def repeat_inputs(inputs: Union[Tensor, Dict[str, Any], Sequence[Any]], samples: int):
+    """Repeat every tensor S times along dim 0, sample-major ([s0 batch | s1 batch | ...])."""
+    def rep(v):
+        if isinstance(v, Tensor) and v.dim() > 0:
+            return v.repeat(samples, *([1] * (v.dim() - 1)))
+        return v
+
+    if isinstance(inputs, Tensor):
+        return rep(inputs)
+    if isinstance(inputs, dict):
+        return {k: rep(v) for k, v in inputs.items()}
+    return type(inputs)(rep(v) for v in inputs)
+
+
+def _default_select(out):
+    if isinstance(out, Tensor):
+        return (out,)
+    if hasattr(out, "start_logits") and hasattr(out, "end_logits"):  # HF question answering
+        return (out.start_logits, out.end_logits)
+    if hasattr(out, "logits"):
+        return (out.logits,)
+    raise TypeError("sample_bayesian: pass select= to pick the output tensor(s) of the model")
+
+
+def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callable] = None,
+                    group: Optional["dist.ProcessGroup"] = None, gather_raw: bool = False
+                    ) -> Tuple[Tuple[Tensor, ...], Tuple[Tensor, ...], Tensor, Tensor]:
+    """Run `samples` Monte-Carlo forwards of `model` as one batched forward.
+
+    inputs: a tensor, a dict of tensors (HF style, called as model(**inputs)) or a sequence (model(*inputs)) for ONE
+        batch; they are repeated S_local times here.
+    select: maps the model output to a tuple of [S_local*B, ...] tensors to average (default: `.logits`,
+        `(start_logits, end_logits)`, or the output itself).
+    group: if torch.distributed is initialised (or a group is given) the samples are sharded over its ranks;
+        `samples` must be a multiple of the world size.
+
+    Returns (raw, mean, log_prior, log_variational_posterior):
+        raw   tuple of [S_local, B, ...] per-sample outputs of this rank (all S if gather_raw),
+        mean  tuple of [B, ...] means over ALL S samples,
+        log_prior, log_variational_posterior: 0-d float64 means over ALL S samples.
+    """
+    distributed = dist.is_available() and dist.is_initialized() and (group is not None or dist.get_world_size() > 1)
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    if samples % world:
+        raise ValueError(f"samples={samples} must be a multiple of the world size {world}")
+    s_local = samples // world
+    select = select or _default_select
+
+    rep = repeat_inputs(inputs, s_local)
+    with model.monte_carlo(s_local, shard=(rank, world)):
+        if isinstance(rep, dict):
+            out = model(**rep)
+        elif isinstance(rep, Tensor):
+            out = model(rep)
+        else:
+            out = model(*rep)
+    outs = select(out)
+    raw = tuple(o.reshape(s_local, o.shape[0] // s_local, *o.shape[1:]) for o in outs)
+    lp = model.log_prob_samples()  # [S_local, 2] float64
+
+    sums = [r.sum(0, dtype=torch.float64).reshape(-1) for r in raw]
+    packed = torch.cat(sums + [lp.sum(0)])
+    if distributed:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    packed = packed / samples
+    means, off = [], 0
+    for r in raw:
+        n = r[0].numel()
+        means.append(packed[off:off + n].reshape(r.shape[1:]).to(r.dtype))
+        off += n
+    log_prior, lvp = packed[off], packed[off + 1]
+    if distributed and gather_raw:
+        gathered = []
+        for r in raw:
+            parts = [torch.empty_like(r) for _ in range(world)]
+            dist.all_gather(parts, r.contiguous(), group=group)
+            gathered.append(torch.cat(parts, 0))
+        raw = tuple(gathered)
+    return raw, tuple(means), log_prior, lvp
+
+
+def elbo(log_prior: Tensor, log_variational_posterior: Tensor, nll: Tensor, n_batches: int) -> Tensor:
+    """loss = (lvp - log_prior) / n_batches + nll  (bert_glue.py:235, mlp_mnist.py:107, README.md:72)."""
+    return (log_variational_posterior - log_prior) / n_batches + nll

@@ -1,0 +1,111 @@
+/* bayeformers_amd.h — C-ABI of the MI355X (gfx950) Monte-Carlo variational forward path.
+ *
+ * The reference (yliess86/BayeFormers) has no FFI: its boundary is the Python class protocol.  Every entry
+ * point below replaces a specific stretch of reference Python on the hot path; the Python host layer in
+ * bayeformers_amd/ binds these with ctypes and keeps the reference's class/attribute surface.
+ *
+ * Conventions
+ *   - every pointer named d_* (or documented "device") is a device pointer valid on the current HIP device;
+ *   - nothing is allocated inside: outputs and workspaces are caller-provided (torch tensors on the host side);
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the legacy default stream) and
+ *     the call returns without synchronising;
+ *   - return value 0 = ok, non-zero = error; bf_last_error() returns a thread-local description.  No C++
+ *     exception crosses the boundary;
+ *   - no hidden RNG state: epsilon is a pure function of (seed, sample index, stream id, element index) —
+ *     see bayeformers_amd/csrc/bf_philox.h for the contract (Philox4x32-10 + Box-Muller).
+ */
+#ifndef BAYEFORMERS_AMD_H
+#define BAYEFORMERS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BF_VERSION_MAJOR 0
+#define BF_VERSION_MINOR 1
+
+/* element types of activations / sampled weights */
+enum { BF_DT_F32 = 0, BF_DT_BF16 = 1, BF_DT_F16 = 2 };
+
+/* prior kinds.
+ *   BF_PRIOR_MIXTURE  = ScaledGaussianMixture.log_prob   /root/reference/bayeformers/nn/parameters/gaussian.py:160-171
+ *   BF_PRIOR_GAUSSIAN = Gaussian.log_prob used as MOPED prior  .../gaussian.py:103-116, layers/linear.py:147-150
+ *   BF_PRIOR_NONE     = NoneParameter.log_prob -> 0.0     /root/reference/bayeformers/nn/parameters/base.py:68-69 */
+enum { BF_PRIOR_MIXTURE = 0, BF_PRIOR_GAUSSIAN = 1, BF_PRIOR_NONE = 2 };
+
+typedef struct bf_prior {
+    int32_t kind;        /* BF_PRIOR_* */
+    float pi;            /* mixture: weight of the first component */
+    float sigma1;        /* mixture: std of the first component */
+    float sigma2;        /* mixture: std of the second component */
+    const float* d_mu;   /* gaussian: device, prior mean, same shape as the tensor */
+    const float* d_rho;  /* gaussian: device, prior rho (sigma_p = softplus(rho)), same shape */
+} bf_prior_t;
+
+/* One Gaussian variational parameter (a weight or a bias): Gaussian(mu, rho) of
+ * /root/reference/bayeformers/nn/parameters/gaussian.py:22-116. */
+typedef struct bf_tensor {
+    const float* d_mu;   /* device, n floats */
+    const float* d_rho;  /* device, n floats */
+    uint64_t n;          /* number of scalars */
+    bf_prior_t prior;
+    uint32_t stream_id;  /* Philox stream: 2*layer_id + (0 weight | 1 bias) */
+    int32_t out_dtype;   /* BF_DT_* of d_sample_out */
+    void* d_sample_out;  /* device, [S][n] of out_dtype, or NULL when only the log-probs are wanted */
+} bf_tensor_t;
+
+int bf_version(void);
+const char* bf_last_error(void);
+
+/* Number of compute units / name of the current device (diagnostics for bench.py). */
+int bf_device_info(char* name, size_t name_len, int* n_cu, int* wave_size);
+
+/* Host twin of the device epsilon generator: out[i] = eps(seed, sample, stream_id, element offset+i).
+ * Replaces the reference's only RNG touch-point, Normal(0,1).sample(size) at gaussian.py:100. */
+int bf_philox_normal_host(float* out, uint64_t n, uint64_t seed, uint32_t sample, uint32_t stream_id, uint64_t offset);
+
+/* Device epsilon only (test hook for the RNG contract): d_out[s][i] for s in [0,S). */
+int bf_philox_normal(float* d_out, uint64_t n, int S, uint64_t seed, uint32_t sample_base, uint32_t stream_id,
+                     void* stream);
+
+/* Fused reparameterise + log-prob kernel.  For each tensor t and each sample s in [0,S):
+ *     eps  = philox_normal(seed, sample_base + s, t.stream_id, e)
+ *     W    = mu + softplus(rho) * eps                     Gaussian.sample      gaussian.py:90-101, :81-88
+ *     lq_s += sum_e log N(W; mu, softplus(rho))            Gaussian.log_prob    gaussian.py:103-116
+ *     lp_s += sum_e log prior(W)                           gaussian.py:160-171 | :103-116 | base.py:68-69
+ * and, when t.d_sample_out != NULL, W is written as out_dtype to d_sample_out[s][e].
+ * d_logprob_out is [S][2] doubles: {log_prior, log_variational_posterior} summed over all `tensors`
+ * — the two scalars Linear.forward leaves behind (layers/linear.py:99-102).  Deterministic (fixed-order) sums.
+ * Workspace: bf_sample_logprob_workspace_bytes(). */
+size_t bf_sample_logprob_workspace_bytes(const bf_tensor_t* tensors, int n_tensors, int S);
+int bf_sample_logprob(const bf_tensor_t* tensors, int n_tensors, int S, uint64_t seed, uint32_t sample_base,
+                      double* d_logprob_out, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Batched NT GEMM on the matrix cores:  y[s] = x[s] * w[s]^T + bias[s]   (F.linear, layers/linear.py:104)
+ *   x: [S or 1][M][K] of x_dtype, sample stride x_sample_stride elements (0 = one x shared by all samples)
+ *   w: [S][N][K] of w_dtype (what bf_sample_logprob wrote);  bias: [S][N] fp32 or NULL
+ *   y: [S][M][N] of y_dtype.
+ * compute: w_dtype BF16/F16 -> v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulate (x must be w_dtype or F32);
+ *          w_dtype F32 -> v_mfma_f32_16x16x4_f32 (exact fp32; x must be F32). */
+int bf_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
+               const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, void* stream);
+
+/* The whole of Linear.forward (layers/linear.py:83-104) for S Monte-Carlo samples in one call:
+ * sample W_s and b_s, accumulate both log-probs, y[s] = x[s] W_s^T + b_s.
+ *   weight.n must be N*K (row-major [N][K], as nn.Linear), bias may be NULL (NoneParameter, base.py:55-69);
+ *   weight->d_sample_out / bias->d_sample_out / out_dtype are ignored (scratch lives in the workspace);
+ *   compute_dtype: BF_DT_BF16 | BF_DT_F16 | BF_DT_F32.
+ * d_logprob_out: [S][2] doubles {log_prior, log_variational_posterior}. */
+size_t bf_linear_fwd_workspace_bytes(int S, int M, int N, int K, int has_bias, int compute_dtype, int x_dtype);
+int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const bf_tensor_t* weight,
+                  const bf_tensor_t* bias, void* d_y, int y_dtype, int compute_dtype, int S, int M, int N, int K,
+                  uint64_t seed, uint32_t sample_base, double* d_logprob_out, void* d_workspace,
+                  size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAYEFORMERS_AMD_H */

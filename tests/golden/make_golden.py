@@ -1,0 +1,244 @@
+"""Generate the golden fixtures from the REAL reference (yliess86/BayeFormers at /root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box):
+
+    PYTHONPATH=/root/repo python tests/golden/make_golden.py [--skip-bert]
+
+The reference is imported unmodified.  Its only RNG touch-point is `self.normal.sample(self.size)` in
+Gaussian.sample (/root/reference/bayeformers/nn/parameters/gaussian.py:100); each Gaussian's `normal` attribute
+is replaced by a stub that returns the oracle's Philox epsilon for (seed, sample, 2*layer_id + tensor_id), so the
+reference and the HIP path consume identical draws.  Everything written below is DATA: inputs (or the seeds that
+regenerate them, with checksums) and the reference's outputs.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+import bayeformers  # noqa: E402  (the reference)
+import bayeformers.nn as rbnn  # noqa: E402
+from bayeformers import to_bayesian as ref_to_bayesian  # noqa: E402
+
+from oracle import bayes_oracle as bo  # noqa: E402
+
+SEED = 0x5EED
+
+
+class PhiloxNormal:
+    """Stand-in for torch.distributions.Normal(0, 1) on one reference Gaussian."""
+
+    def __init__(self, clock, stream_id):
+        self.clock, self.stream_id = clock, stream_id
+
+    def sample(self, size):
+        n = int(np.prod(tuple(size)))
+        z = bo.normals(n, self.clock["seed"], self.clock["sample"], self.stream_id)
+        return torch.from_numpy(z).reshape(tuple(size))
+
+
+def inject(module, clock):
+    """Give every reference bnn.Linear a layer_id (registration order) and Philox epsilon."""
+    layers = [m for m in module.modules() if isinstance(m, rbnn.Linear)]
+    for i, l in enumerate(layers):
+        l.weight.normal = PhiloxNormal(clock, 2 * i)
+        if isinstance(l.bias, rbnn.Gaussian):
+            l.bias.normal = PhiloxNormal(clock, 2 * i + 1)
+    return layers
+
+
+def checksum(module):
+    return float(sum(p.detach().double().abs().sum() for p in module.parameters()))
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------- single layers
+def linear_cases():
+    cases = {}
+
+    def run(name, layer, x, S, base):
+        clock = {"seed": SEED, "sample": base}
+        inject(layer, clock)
+        ys, lps, lqs = [], [], []
+        with torch.no_grad():
+            for s in range(S):
+                clock["sample"] = base + s
+                ys.append(t2n(layer(x)))
+                lps.append(float(layer.log_prior))
+                lqs.append(float(layer.log_variational_posterior))
+        d = {"x": t2n(x), "w_mu": t2n(layer.weight.mu), "w_rho": t2n(layer.weight.rho), "S": S, "base": base,
+             "y": np.stack(ys), "log_prior": np.array(lps, np.float64), "lvp": np.array(lqs, np.float64)}
+        if isinstance(layer.bias, rbnn.Gaussian):
+            d["b_mu"], d["b_rho"] = t2n(layer.bias.mu), t2n(layer.bias.rho)
+        if isinstance(layer.weight_prior, rbnn.Gaussian):
+            d["wp_mu"], d["wp_rho"] = t2n(layer.weight_prior.mu), t2n(layer.weight_prior.rho)
+            if isinstance(layer.bias, rbnn.Gaussian):
+                d["bp_mu"], d["bp_rho"] = t2n(layer.bias_prior.mu), t2n(layer.bias_prior.rho)
+        else:
+            pr = layer.weight_prior
+            d["mixture"] = np.array([float(pr.pi), float(pr.sigma1), float(pr.sigma2)], np.float64)
+        for k, v in d.items():
+            cases[f"{name}/{k}"] = v
+
+    torch.manual_seed(1)
+    run("mix_bias", rbnn.Linear(40, 24), torch.randn(5, 40), 3, 0)
+    torch.manual_seed(2)
+    run("mix_nobias_oddK", rbnn.Linear(33, 7, bias=False), torch.randn(4, 33), 2, 7)
+    torch.manual_seed(3)
+    run("mix_custom_prior", rbnn.Linear(16, 10, prior=rbnn.ScaledGaussianMixture(0.25, 0.5, 0.05)),
+        torch.randn(3, 16), 2, 11)
+
+    torch.manual_seed(4)
+    freq = torch.nn.Linear(64, 48)
+    with torch.no_grad():
+        freq.weight.mul_(0.2)
+        freq.weight[0, :5] = 0.0          # MOPED: delta*|w| = 0 -> log(0) = -inf -> rho := 0
+        freq.weight[1, 0] = 1e-7          # below the fp32 resolution of exp(x) - 1
+        freq.bias[3] = 0.0
+    run("moped", rbnn.Linear.from_frequentist(freq, delta=0.05, freeze=True), torch.randn(6, 64), 3, 100)
+
+    torch.manual_seed(5)
+    edge = rbnn.Linear(24, 8)
+    with torch.no_grad():
+        edge.weight.rho[0, :4] = 25.0      # softplus threshold: sigma = rho
+        edge.weight.rho[1, :4] = 20.0
+        edge.weight.rho[2, :4] = -30.0     # tiny sigma
+        edge.weight.mu[3, :4] = torch.tensor([14.0, -14.2, 5.0, -9.0])  # deep mixture tail, still finite in fp32
+        edge.weight.rho[3, :4] = -12.0
+    run("edge", edge, torch.randn(2, 24), 2, 3)
+
+    torch.manual_seed(6)
+    inf_edge = rbnn.Linear(8, 4)
+    with torch.no_grad():
+        inf_edge.weight.mu[0, 0] = 15.0    # reference fp32: exp underflow -> log(0) = -inf
+        inf_edge.weight.rho[0, 0] = -12.0
+    run("edge_inf", inf_edge, torch.randn(2, 8), 1, 5)
+    return cases
+
+
+# ---------------------------------------------------------------------------------------------- C1: MLP
+class MLP(torch.nn.Module):
+    """The 784-512-512-10 MLP of /root/reference/examples/mlp_mnist.py:16-26 (architecture only)."""
+
+    def __init__(self, in_features, hidden, n_classes):
+        super().__init__()
+        self.mlp = torch.nn.Sequential(
+            torch.nn.Linear(in_features, hidden), torch.nn.ReLU(),
+            torch.nn.Linear(hidden, hidden), torch.nn.ReLU(),
+            torch.nn.Linear(hidden, n_classes), torch.nn.LogSoftmax(dim=1))
+
+    def forward(self, input):
+        return self.mlp(input)
+
+
+def mlp_case():
+    S, B, NB = 5, 128, 469
+    torch.manual_seed(0)
+    model = MLP(784, 512, 10)
+    bmodel = ref_to_bayesian(model, delta=0.05)
+    torch.manual_seed(123)
+    x = torch.rand(B, 784)
+    labels = torch.randint(0, 10, (B,))
+    clock = {"seed": SEED, "sample": 0}
+    inject(bmodel, clock)
+    pred = torch.zeros(S, B, 10)
+    lp = torch.zeros(S)
+    lq = torch.zeros(S)
+    with torch.no_grad():
+        for s in range(S):  # the sample loop of examples/mlp_mnist.py:97-100
+            clock["sample"] = s
+            pred[s] = bmodel(x)
+            lp[s] = bmodel.log_prior()
+            lq[s] = bmodel.log_variational_posterior()
+        nll = torch.nn.functional.nll_loss(pred.mean(0), labels, reduction="sum")  # mlp_mnist.py:103-107
+        loss = (lq.mean() - lp.mean()) / NB + nll
+    return {"S": S, "B": B, "n_batches": NB, "model_seed": 0, "input_seed": 123, "delta": 0.05,
+            "checksum": checksum(bmodel), "x_sum": float(x.double().sum()), "labels": t2n(labels),
+            "pred": t2n(pred), "log_prior": t2n(lp).astype(np.float64), "lvp": t2n(lq).astype(np.float64),
+            "nll": float(nll), "loss": float(loss)}
+
+
+# ---------------------------------------------------------------------------------------------- C3: BERT
+def bert_case(tiny):
+    from transformers import BertConfig, BertForSequenceClassification
+
+    if tiny:
+        cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                         vocab_size=1000, max_position_embeddings=64)
+        S, B, L = 3, 4, 16
+    else:
+        cfg = BertConfig()
+        S, B, L = 10, 32, 128
+    torch.manual_seed(0)
+    model = BertForSequenceClassification(cfg).eval()
+    bmodel = ref_to_bayesian(model, delta=0.05, freeze=True).eval()
+    torch.manual_seed(321)
+    ids = torch.randint(0, cfg.vocab_size, (B, L))
+    mask = torch.ones(B, L, dtype=torch.long)
+    labels = torch.randint(0, 2, (B,))
+    clock = {"seed": SEED, "sample": 0}
+    layers = inject(bmodel, clock)
+    logits = torch.zeros(S, B, 2)
+    lp = torch.zeros(S, dtype=torch.float64)
+    lq = torch.zeros(S, dtype=torch.float64)
+    t0 = time.time()
+    with torch.no_grad():
+        for s in range(S):  # sample_bayesian, examples/bert_glue.py:63-66
+            clock["sample"] = s
+            out = bmodel(input_ids=ids, attention_mask=mask, labels=labels)
+            logits[s] = out[1]
+            lp[s] = float(bmodel.log_prior())
+            lq[s] = float(bmodel.log_variational_posterior())
+        nll = torch.nn.functional.cross_entropy(logits.mean(0), labels)  # bert_glue.py:234
+    print(f"  bert tiny={tiny}: {len(layers)} layers, {time.time() - t0:.1f}s for {S} samples", flush=True)
+    return {"S": S, "B": B, "L": L, "model_seed": 0, "input_seed": 321, "delta": 0.05, "n_layers": len(layers),
+            "checksum": checksum(bmodel), "ids_sum": int(ids.sum()), "labels": t2n(labels), "logits": t2n(logits),
+            "log_prior": t2n(lp), "lvp": t2n(lq), "nll": float(nll)}
+
+
+def conversion_case():
+    """to_bayesian / from_frequentist numerics and state-dict layout (bayeformers/__init__.py:19-63)."""
+    torch.manual_seed(7)
+    net = torch.nn.Sequential(torch.nn.Linear(12, 9), torch.nn.Tanh(), torch.nn.Linear(9, 4, bias=False))
+    torch.manual_seed(8)
+    moped = ref_to_bayesian(net, delta=0.1, freeze=True)
+    torch.manual_seed(8)
+    plain = ref_to_bayesian(net)
+    d = {"moped_keys": np.array(sorted(moped.state_dict().keys())),
+         "plain_keys": np.array(sorted(plain.state_dict().keys())),
+         "moped_requires_grad": np.array(sorted(n for n, p in moped.named_parameters() if p.requires_grad)),
+         "plain_requires_grad": np.array(sorted(n for n, p in plain.named_parameters() if p.requires_grad))}
+    for k, v in moped.state_dict().items():
+        d["moped/" + k] = t2n(v)
+    for k, v in plain.state_dict().items():
+        d["plain/" + k] = t2n(v)
+    return d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-bert", action="store_true")
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    print("eps KAT"); np.savez_compressed(os.path.join(HERE, "eps_kat.npz"), seed=SEED,
+                                         z_s0_str0=bo.normals(64, SEED, 0, 0), z_s9_str5_off3=bo.normals(64, SEED, 9, 5, 3))
+    print("linear cases"); np.savez_compressed(os.path.join(HERE, "linear_cases.npz"), **linear_cases())
+    print("conversion"); np.savez_compressed(os.path.join(HERE, "conversion.npz"), **conversion_case())
+    print("mlp C1"); np.savez_compressed(os.path.join(HERE, "mlp_c1.npz"), **mlp_case())
+    print("bert tiny"); np.savez_compressed(os.path.join(HERE, "bert_tiny.npz"), **bert_case(True))
+    if not args.skip_bert:
+        print("bert base C3 (about a minute of CPU)"); np.savez_compressed(os.path.join(HERE, "bert_c3.npz"), **bert_case(False))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,54 @@
+"""The oracle's epsilon generator: Random123 known-answer vectors, C vs numpy, committed KAT, host twin."""
+import numpy as np
+
+from oracle import bayes_oracle as bo
+
+# Random123 kat_vectors, philox4x32 with 10 rounds: counter[4], key[2] -> output[4]
+KAT = [
+    ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+    ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+    ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0],
+     [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+]
+
+
+def test_philox_known_answers():
+    for ctr, key, exp in KAT:
+        assert list(bo.philox4x32_10(ctr, key)) == exp
+        assert list(bo.philox4x32_10_numpy(np.array(ctr), key)) == exp
+
+
+def test_c_and_numpy_normals_agree_bitwise():
+    for n, seed, sample, stream, off in [(1000, 0x5EED, 3, 7, 5), (17, 2**63 + 11, 2**32 - 1, 147, 0), (1, 1, 0, 0, 3)]:
+        a = bo.normals(n, seed, sample, stream, off)
+        b = bo.normals_numpy(n, seed, sample, stream, off)
+        assert np.array_equal(a, b)
+
+
+def test_offset_is_a_pure_index():
+    full = bo.normals(64, 9, 2, 4)
+    for off in (1, 2, 3, 4, 13):
+        assert np.array_equal(bo.normals(20, 9, 2, 4, off), full[off:off + 20])
+
+
+def test_committed_eps_vectors(golden_dir):
+    g = np.load(f"{golden_dir}/eps_kat.npz")
+    seed = int(g["seed"])
+    assert np.array_equal(bo.normals(64, seed, 0, 0), g["z_s0_str0"])
+    assert np.array_equal(bo.normals(64, seed, 9, 5, 3), g["z_s9_str5_off3"])
+
+
+def test_moments():
+    z = bo.normals(1 << 20, 123, 0, 0).astype(np.float64)
+    assert abs(z.mean()) < 4e-3 and abs(z.std() - 1) < 3e-3
+    assert abs((z ** 3).mean()) < 2e-2 and abs((z ** 4).mean() - 3) < 5e-2
+    assert np.abs(z).max() < 6.8  # sqrt(-2 ln 2^-33)
+
+
+def test_product_host_twin_matches_oracle():
+    """bf_philox_normal_host (product library, host code only) against the independent oracle."""
+    from bayeformers_amd import ops
+
+    for n, seed, sample, stream, off in [(4099, 0x5EED, 0, 0, 0), (257, 77, 12, 147, 6)]:
+        a = ops.philox_normal_host(n, seed, sample, stream, off).numpy()
+        assert np.array_equal(a, bo.normals(n, seed, sample, stream, off))
