@@ -13,7 +13,99 @@ void bf_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// ---------------------------------------------------------------------------------------------- profiling
+#include <mutex>
+#include <vector>
+namespace {
+struct ProfEntry {
+    int kind;
+    double work;
+    hipEvent_t start, stop;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfEntry> g_prof;            // recorded launches
+std::vector<hipEvent_t> g_prof_free;      // event pool
+
+hipEvent_t prof_event() {
+    if (!g_prof_free.empty()) {
+        hipEvent_t e = g_prof_free.back();
+        g_prof_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    bool on;
+    ProfEntry e;
+    hipStream_t stream;
+    ProfScope(int kind, double work, hipStream_t s) : on(g_prof_on), stream(s) {
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        e.kind = kind;
+        e.work = work;
+        e.start = prof_event();
+        e.stop = prof_event();
+        (void)hipEventRecord(e.start, stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(e.stop, stream);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(e);
+    }
+};
+
+double sample_work_bytes(const bf_tensor_t* t, int n, int S) {
+    double b = 0;
+    for (int i = 0; i < n; ++i) {
+        const double per = (t[i].prior.kind == BF_PRIOR_GAUSSIAN ? 16.0 : 8.0) +
+                           (t[i].d_sample_out ? (double)S * (double)bf_dtype_size(t[i].out_dtype) : 0.0);
+        b += per * (double)t[i].n;
+    }
+    return b;
+}
+}  // namespace
+
 extern "C" {
+
+int bf_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return 0;
+}
+
+int bf_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& e : g_prof) {
+        g_prof_free.push_back(e.start);
+        g_prof_free.push_back(e.stop);
+    }
+    g_prof.clear();
+    return 0;
+}
+
+int bf_profile_read(int kind, uint64_t* launches, double* total_ms, double* total_work) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    uint64_t n = 0;
+    double ms = 0, work = 0;
+    for (auto& e : g_prof) {
+        if (e.kind != kind) continue;
+        BF_HIP_CHECK(hipEventSynchronize(e.stop));
+        float t = 0.f;
+        BF_HIP_CHECK(hipEventElapsedTime(&t, e.start, e.stop));
+        ms += t;
+        work += e.work;
+        ++n;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    if (total_work) *total_work = work;
+    return 0;
+}
 
 int bf_version(void) { return BF_VERSION_MAJOR * 1000 + BF_VERSION_MINOR; }
 
@@ -60,12 +152,15 @@ size_t bf_sample_logprob_workspace_bytes(const bf_tensor_t* tensors, int n_tenso
 int bf_sample_logprob(const bf_tensor_t* tensors, int n_tensors, int S, uint64_t seed, uint32_t sample_base,
                       double* d_logprob_out, void* d_workspace, size_t workspace_bytes, void* stream) {
     if (!tensors) BF_FAIL("bf_sample_logprob: tensors is NULL");
+    ProfScope prof(BF_PROF_SAMPLE, n_tensors >= 1 && n_tensors <= 2 ? sample_work_bytes(tensors, n_tensors, S) : 0.0,
+                   (hipStream_t)stream);
     return bf_launch_sample_logprob(tensors, n_tensors, S, seed, sample_base, d_logprob_out, d_workspace,
                                     workspace_bytes, (hipStream_t)stream);
 }
 
 int bf_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
                const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, void* stream) {
+    ProfScope prof(BF_PROF_GEMM, 2.0 * S * M * (double)N * K, (hipStream_t)stream);
     return bf_launch_gemm_nt(d_x, x_dtype, x_sample_stride, d_w, w_dtype, d_bias, d_y, y_dtype, S, M, N, K,
                              (hipStream_t)stream);
 }
@@ -123,9 +218,14 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
         t[1].out_dtype = BF_DT_F32;
         nt = 2;
     }
-    int rc = bf_launch_sample_logprob(t, nt, S, seed, sample_base, d_logprob_out, ws + op, total - op,
+    int rc;
+    {
+        ProfScope prof(BF_PROF_SAMPLE, sample_work_bytes(t, nt, S), (hipStream_t)stream);
+        rc = bf_launch_sample_logprob(t, nt, S, seed, sample_base, d_logprob_out, ws + op, total - op,
                                       (hipStream_t)stream);
+    }
     if (rc) return rc;
+    ProfScope prof(BF_PROF_GEMM, 2.0 * S * M * (double)N * K, (hipStream_t)stream);
     return bf_launch_gemm_nt(d_x, x_dtype, x_sample_stride, ws + ow, compute_dtype,
                              bias ? reinterpret_cast<const float*>(ws + ob) : nullptr, d_y, y_dtype, S, M, N, K,
                              (hipStream_t)stream);

@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py — MC-samples/sec (fwd+ELBO) of the MI355X Monte-Carlo variational forward path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bert_base|linear768|linear768_m32|mlp]
+
+One step = one pass of the hot path over one synthetic batch: S Monte-Carlo samples of the converted model
+(sampling + log-probs + MFMA GEMMs for every Bayesian linear, everything else of the wrapped model in torch),
+the mean over samples, the NLL on the mean logits and the ELBO scalar read back to the host
+(the `sample_bayesian` + loss recipe of /root/reference/examples/bert_glue.py:56-73,:234-235).
+
+Default workload (the one BASELINE.json's metric is quoted on): to_bayesian(BERT-base seq-cls, delta=0.05,
+freeze=True), S=10 samples per GPU, B=32, L=128, bf16, random-init weights, synthetic token ids.
+N>1 (launched by torch.distributed.run): weak scaling over the sample axis — every rank runs S=10 samples of the
+same batch at distinct global sample indices, one RCCL all-reduce of the packed ELBO terms per step.
+
+Prints ONE JSON line on rank 0 with `roofline` (the MFMA GEMM, HIP events on the launch stream) and
+`cpu_baseline` (the oracle's CPU port of the reference op sequence, rank 0 at N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_TFLOPS = 2500.0   # MI355X dense bf16/fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0  # HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="bert_base", choices=["bert_base", "linear768", "linear768_m32", "mlp"])
+    ap.add_argument("--samples", type=int, default=None, help="MC samples per GPU per step (default: workload's)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+class Workload:
+    """name, S (per GPU), dtype, step() -> python float (the ELBO), config dict, cpu_baseline() -> dict."""
+
+
+def make_bert(device, S, dtype):
+    import bayeformers_amd as bf
+    from bayeformers_amd.sampling import elbo, sample_bayesian
+    from transformers import BertConfig, BertForSequenceClassification
+
+    B, L, n_batches = 32, 128, 2105  # SST-2: 67,349 train sentences / 32
+    torch.manual_seed(0)
+    cfg = BertConfig()
+    model = BertForSequenceClassification(cfg).eval()
+    bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().to(device)
+    if dtype != "fp32":
+        bmodel = bmodel.to(torch.bfloat16 if dtype == "bf16" else torch.float16)
+    g = torch.Generator().manual_seed(321)
+    ids = torch.randint(0, cfg.vocab_size, (B, L), generator=g)
+    labels = torch.randint(0, 2, (B,), generator=g)
+    inputs = {"input_ids": ids.to(device), "attention_mask": torch.ones(B, L, dtype=torch.long, device=device)}
+    labels_d = labels.to(device)
+
+    def step():
+        with torch.no_grad():
+            raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S)
+            nll = torch.nn.functional.cross_entropy(mean[0].float(), labels_d)
+            return float(elbo(lp, lq, nll.double(), n_batches))
+
+    def cpu_baseline():
+        from oracle.model_oracle import log_probs, to_oracle
+
+        omodel = to_oracle(model, delta=0.05).eval()
+        n = 2
+        with torch.no_grad():
+            omodel(input_ids=ids, attention_mask=torch.ones(B, L, dtype=torch.long))  # warm-up sample
+            t0 = time.perf_counter()
+            for _ in range(n):
+                out = omodel(input_ids=ids, attention_mask=torch.ones(B, L, dtype=torch.long))
+                log_probs(omodel)
+            dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "MC-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{n} serial MC samples (fwd + log-probs) of the same BERT-base B=32 L=128 batch, "
+                          f"torch-CPU fp32, {dt:.1f}s"}
+
+    cfgd = {"workload": "to_bayesian(BERT-base seq-cls, delta=0.05, freeze=True) fwd+ELBO", "samples_per_gpu": S,
+            "batch": B, "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "bayesian_scalars": 85609730}
+    return step, cpu_baseline, cfgd
+
+
+def make_linear(device, S, dtype, M):
+    import bayeformers_amd as bf
+    import bayeformers_amd.nn as bnn
+    from bayeformers_amd.sampling import elbo, sample_bayesian
+
+    torch.manual_seed(0)
+    layer = bnn.Linear(768, 768)
+    model = bnn.Model(layer).to(device)
+    x = torch.randn(M, 768)
+    xd = x.to(device)
+    if dtype != "fp32":
+        xd = xd.to(torch.bfloat16 if dtype == "bf16" else torch.float16)
+    tgt = torch.randint(0, 768, (M,), device=device)
+
+    def step():
+        with torch.no_grad():
+            raw, mean, lp, lq = sample_bayesian(model, xd, S)
+            nll = torch.nn.functional.cross_entropy(mean[0].float(), tgt)
+            return float(elbo(lp, lq, nll.double(), 100))
+
+    def cpu_baseline():
+        from oracle import bayes_oracle as bo
+
+        mu_w, rho_w = layer.weight.mu.detach().cpu(), layer.weight.rho.detach().cpu()
+        mu_b, rho_b = layer.bias.mu.detach().cpu(), layer.bias.rho.detach().cpu()
+        prior = ("mixture", 0.5, 1.0, float(torch.tensor(-6.0).exp()))
+        n = 3 if M <= 64 else 2
+        with torch.no_grad():
+            bo.cpu_reference_step(x, mu_w, rho_w, mu_b, rho_b, S, prior)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                bo.cpu_reference_step(x, mu_w, rho_w, mu_b, rho_b, S, prior)
+            dt = time.perf_counter() - t0
+        return {"value": n * S / dt, "unit": "MC-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{n} steps of S={S} serial samples, x=[{M},768], torch-CPU fp32, {dt:.1f}s"}
+
+    cfgd = {"workload": f"bnn.Linear(768,768) default init + mixture prior, x=[{M},768], fwd+ELBO",
+            "samples_per_gpu": S, "batch": M}
+    return step, cpu_baseline, cfgd
+
+
+def make_mlp(device, S, dtype):
+    import bayeformers_amd as bf
+    from bayeformers_amd.sampling import elbo, sample_bayesian
+
+    torch.manual_seed(0)
+    mlp = torch.nn.Sequential(torch.nn.Linear(784, 512), torch.nn.ReLU(), torch.nn.Linear(512, 512), torch.nn.ReLU(),
+                              torch.nn.Linear(512, 10), torch.nn.LogSoftmax(dim=1))
+    bmodel = bf.to_bayesian(mlp, delta=0.05).to(device)
+    x = torch.rand(128, 784)
+    xd, labels = x.to(device), torch.randint(0, 10, (128,), device=device)
+
+    def step():
+        with torch.no_grad():
+            raw, mean, lp, lq = sample_bayesian(bmodel, xd, S)
+            nll = torch.nn.functional.nll_loss(mean[0], labels, reduction="sum")
+            return float(elbo(lp, lq, nll.double(), 469))
+
+    def cpu_baseline():
+        from oracle.model_oracle import log_probs, to_oracle
+
+        om = to_oracle(mlp, delta=0.05)
+        n = 20
+        with torch.no_grad():
+            om(x)
+            t0 = time.perf_counter()
+            for _ in range(n * S):
+                om(x)
+                log_probs(om)
+            dt = time.perf_counter() - t0
+        return {"value": n * S / dt, "unit": "MC-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{n} steps of S={S} serial samples, MLP 784-512-512-10 B=128, torch-CPU fp32, {dt:.1f}s"}
+
+    return step, cpu_baseline, {"workload": "to_bayesian(MLP 784-512-512-10, delta=0.05) fwd+ELBO", "samples_per_gpu": S,
+                                "batch": 128}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    import bayeformers_amd as bf
+    from bayeformers_amd import _C
+
+    defaults = {"bert_base": (10, "bf16"), "linear768": (10, "bf16"), "linear768_m32": (10, "bf16"), "mlp": (5, "bf16")}
+    S = args.samples or defaults[args.workload][0]
+    dtype = args.dtype or defaults[args.workload][1]
+    bf.set_compute_dtype(dtype)
+    bf.manual_seed(0x5EED)
+    if args.workload == "bert_base":
+        step, cpu_baseline, cfgd = make_bert(device, S, dtype)
+    elif args.workload == "linear768":
+        step, cpu_baseline, cfgd = make_linear(device, S, dtype, 4096)
+    elif args.workload == "linear768_m32":
+        step, cpu_baseline, cfgd = make_linear(device, S, dtype, 32)
+    else:
+        step, cpu_baseline, cfgd = make_mlp(device, S, dtype)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+
+    # roofline leg: the same steps again with HIP events around every GEMM / sampling launch
+    lib = _C.lib()
+    lib.bf_profile_reset()
+    lib.bf_profile_enable(1)
+    prof_steps = max(1, min(args.steps, 5))
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    lib.bf_profile_enable(0)
+    prof = {}
+    for kind, name in ((_C.BF_PROF_GEMM, "gemm"), (_C.BF_PROF_SAMPLE, "sample")):
+        n, ms, work = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
+        _C.check(lib.bf_profile_read(kind, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work)), "bf_profile_read")
+        prof[name] = (n.value, ms.value, work.value)
+    lib.bf_profile_reset()
+
+    if rank == 0:
+        gn, gms, gflop = prof["gemm"]
+        sn, sms, sbytes = prof["sample"]
+        tflops = gflop / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (sampled-weight GEMM, all Bayesian linears)",
+                    "achieved": round(tflops, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tflops / PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": gn // prof_steps, "avg_launch_us": round(1e3 * gms / max(gn, 1), 2),
+                    "flop_per_step": gflop / prof_steps, "gemm_ms_per_step": round(gms / prof_steps, 3),
+                    "sample_kernel": {"bound": "hbm", "achieved": round(sbytes / (sms * 1e-3) / 1e9, 1) if sms > 0 else 0.0,
+                                      "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": round(sbytes / (sms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if sms > 0 else 0.0,
+                                      "launches_per_step": sn // prof_steps, "ms_per_step": round(sms / prof_steps, 3),
+                                      "bytes_per_step": sbytes / prof_steps}}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+        total_samples = S * world * args.steps
+        cfgd.update({"parallelism": f"mc-sample-shard x{world}", "last_elbo": last})
+        out = {"metric": "MC-samples/sec (fwd+ELBO)", "value": round(total_samples / dt, 3), "unit": "MC-samples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+               "config": cfgd, "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -105,6 +105,17 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
                   uint64_t seed, uint32_t sample_base, double* d_logprob_out, void* d_workspace,
                   size_t workspace_bytes, void* stream);
 
+/* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
+ * While enabled, every sampling launch (kind BF_PROF_SAMPLE) and every GEMM launch (BF_PROF_GEMM) made through
+ * this library is bracketed by two events; bf_profile_read() synchronises them and returns, per kind, the number
+ * of launches, the summed kernel time and the summed ALGORITHMIC work:
+ *   BF_PROF_GEMM   work = 2*S*M*N*K flop;
+ *   BF_PROF_SAMPLE work = bytes: (8 | 16 with a Gaussian prior) per scalar read + S * sizeof(out) per scalar written. */
+enum { BF_PROF_SAMPLE = 0, BF_PROF_GEMM = 1 };
+int bf_profile_enable(int on);
+int bf_profile_reset(void);
+int bf_profile_read(int kind, uint64_t* launches, double* total_ms, double* total_work);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,25 +136,57 @@ def mixture_log_prob(x, pi, sigma1, sigma2):
     return torch.log(pi_t * p1 + (1.0 - pi_t) * p2).sum()
 
 
-def gaussian_log_prob_f64(eps, mu, rho, x=None):
-    """Closed form in fp64.  As the posterior of its own sample (x is None) the quadratic term is eps^2/2."""
+def gaussian_log_prob_terms_f64(eps, mu, rho, x=None):
+    """Per-element closed form in fp64.  As the posterior of its own sample (x is None) the quadratic term is
+    eps^2/2."""
     s = F.softplus(rho.double())
     if x is None:
         q = 0.5 * eps.double() ** 2
     else:
         q = (x.double() - mu.double()) ** 2 / (2 * s ** 2)
-    return float((-LOG_SQRT_2PI - torch.log(s) - q).sum())
+    return -LOG_SQRT_2PI - torch.log(s) - q
 
 
-def mixture_log_prob_f64(x, pi, sigma1, sigma2):
-    """log(pi N(x;0,s1) + (1-pi) N(x;0,s2)) in fp64, log-sum-exp form (finite for all x)."""
+def gaussian_log_prob_f64(eps, mu, rho, x=None):
+    return float(gaussian_log_prob_terms_f64(eps, mu, rho, x).sum())
+
+
+def mixture_log_prob_terms_f64(x, pi, sigma1, sigma2):
+    """Per-element log(pi N(x;0,s1) + (1-pi) N(x;0,s2)) in fp64, log-sum-exp form (finite for all x)."""
     x = x.double()
     pi = float(np.float32(pi))
     s1 = float(np.float32(sigma1))
     s2 = float(np.float32(sigma2))
     t1 = -0.5 * (x / s1) ** 2 - math.log(s1) - LOG_SQRT_2PI + (math.log(pi) if pi > 0 else -math.inf)
     t2 = -0.5 * (x / s2) ** 2 - math.log(s2) - LOG_SQRT_2PI + (math.log1p(-pi) if pi < 1 else -math.inf)
-    return float(torch.logaddexp(t1, t2).sum())
+    return torch.logaddexp(t1, t2)
+
+
+def mixture_log_prob_f64(x, pi, sigma1, sigma2):
+    return float(mixture_log_prob_terms_f64(x, pi, sigma1, sigma2).sum())
+
+
+def linear_logprob_magnitudes(mu_w, rho_w, mu_b, rho_b, eps_w, eps_b, prior_w, prior_b=None):
+    """(sum |log-prior terms|, sum |log-q terms|): the scale a summation tolerance is relative to — the signed
+    sums can cancel to nearly zero (e.g. a narrow custom mixture) while every term is O(1)."""
+    if prior_b is None:
+        prior_b = prior_w
+
+    def lp_terms(prior, w):
+        if prior is None or w is None:
+            return torch.zeros(1, dtype=torch.float64)
+        if prior[0] == "mixture":
+            return mixture_log_prob_terms_f64(w, *prior[1:])
+        return gaussian_log_prob_terms_f64(None, prior[1], prior[2], x=w)
+
+    W = mu_w.double() + eps_w.double() * F.softplus(rho_w.double())
+    ap = float(lp_terms(prior_w, W).abs().sum())
+    aq = float(gaussian_log_prob_terms_f64(eps_w, mu_w, rho_w).abs().sum())
+    if mu_b is not None:
+        b = mu_b.double() + eps_b.double() * F.softplus(rho_b.double())
+        ap += float(lp_terms(prior_b, b).abs().sum())
+        aq += float(gaussian_log_prob_terms_f64(eps_b, mu_b, rho_b).abs().sum())
+    return ap, aq
 
 
 # ------------------------------------------------------------------------------------------------ a6

@@ -146,6 +146,7 @@ def mlp_case():
     torch.manual_seed(0)
     model = MLP(784, 512, 10)
     bmodel = ref_to_bayesian(model, delta=0.05)
+    csum = checksum(bmodel)  # before any forward: the log-prob Parameters are still 0
     torch.manual_seed(123)
     x = torch.rand(B, 784)
     labels = torch.randint(0, 10, (B,))
@@ -163,7 +164,7 @@ def mlp_case():
         nll = torch.nn.functional.nll_loss(pred.mean(0), labels, reduction="sum")  # mlp_mnist.py:103-107
         loss = (lq.mean() - lp.mean()) / NB + nll
     return {"S": S, "B": B, "n_batches": NB, "model_seed": 0, "input_seed": 123, "delta": 0.05,
-            "checksum": checksum(bmodel), "x_sum": float(x.double().sum()), "labels": t2n(labels),
+            "checksum": csum, "x_sum": float(x.double().sum()), "labels": t2n(labels),
             "pred": t2n(pred), "log_prior": t2n(lp).astype(np.float64), "lvp": t2n(lq).astype(np.float64),
             "nll": float(nll), "loss": float(loss)}
 
@@ -182,6 +183,7 @@ def bert_case(tiny):
     torch.manual_seed(0)
     model = BertForSequenceClassification(cfg).eval()
     bmodel = ref_to_bayesian(model, delta=0.05, freeze=True).eval()
+    csum = checksum(bmodel)  # before any forward
     torch.manual_seed(321)
     ids = torch.randint(0, cfg.vocab_size, (B, L))
     mask = torch.ones(B, L, dtype=torch.long)
@@ -202,7 +204,7 @@ def bert_case(tiny):
         nll = torch.nn.functional.cross_entropy(logits.mean(0), labels)  # bert_glue.py:234
     print(f"  bert tiny={tiny}: {len(layers)} layers, {time.time() - t0:.1f}s for {S} samples", flush=True)
     return {"S": S, "B": B, "L": L, "model_seed": 0, "input_seed": 321, "delta": 0.05, "n_layers": len(layers),
-            "checksum": checksum(bmodel), "ids_sum": int(ids.sum()), "labels": t2n(labels), "logits": t2n(logits),
+            "checksum": csum, "ids_sum": int(ids.sum()), "labels": t2n(labels), "logits": t2n(logits),
             "log_prior": t2n(lp), "lvp": t2n(lq), "nll": float(nll)}
 
 

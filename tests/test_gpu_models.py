@@ -1,0 +1,109 @@
+"""Whole-model parity: to_bayesian(model) on the HIP path against the real reference's outputs (golden fixtures,
+identical Philox epsilon): BASELINE config 1 (MLP, S=5, B=128), a tiny BERT, and config 3 (BERT-base, S=10, B=32)."""
+import numpy as np
+import pytest
+import torch
+
+import bayeformers_amd as bf
+import bayeformers_amd.nn as bnn
+from bayeformers_amd.sampling import elbo, sample_bayesian
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EED
+
+
+def checksum(module):
+    return float(sum(p.detach().double().abs().sum() for p in module.parameters()))
+
+
+class MLP(torch.nn.Module):
+    def __init__(self, in_features, hidden, n_classes):
+        super().__init__()
+        self.mlp = torch.nn.Sequential(
+            torch.nn.Linear(in_features, hidden), torch.nn.ReLU(),
+            torch.nn.Linear(hidden, hidden), torch.nn.ReLU(),
+            torch.nn.Linear(hidden, n_classes), torch.nn.LogSoftmax(dim=1))
+
+    def forward(self, input):
+        return self.mlp(input)
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 1e-4), ("bf16", 3e-2)])
+def test_mlp_c1(golden_dir, dtype, tol):
+    g = np.load(f"{golden_dir}/mlp_c1.npz")
+    S, B, NB = int(g["S"]), int(g["B"]), int(g["n_batches"])
+    torch.manual_seed(int(g["model_seed"]))
+    bmodel = bf.to_bayesian(MLP(784, 512, 10), delta=float(g["delta"]))
+    assert checksum(bmodel) == pytest.approx(float(g["checksum"]), rel=1e-6)  # init/MOPED differ by ulps across host CPUs
+    torch.manual_seed(int(g["input_seed"]))
+    x = torch.rand(B, 784)
+    labels = torch.randint(0, 10, (B,))
+    assert float(x.double().sum()) == pytest.approx(float(g["x_sum"]), rel=1e-12) and np.array_equal(labels.numpy(), g["labels"])
+    bmodel = bmodel.cuda()
+    bf.manual_seed(SEED)
+    bf.set_compute_dtype(dtype)
+    try:
+        with torch.no_grad():
+            raw, mean, lp, lq = sample_bayesian(bmodel, x.cuda(), S)
+            nll = torch.nn.functional.nll_loss(mean[0], labels.cuda(), reduction="sum")
+            loss = elbo(lp, lq, nll, NB)
+    finally:
+        bf.set_compute_dtype("bf16")
+    lps = bmodel.log_prob_samples().cpu().numpy()
+    np.testing.assert_allclose(lps[:, 0], g["log_prior"], rtol=2e-6)
+    np.testing.assert_allclose(lps[:, 1], g["lvp"], rtol=2e-6)
+    assert np.abs(raw[0].cpu().numpy() - g["pred"]).max() < tol * max(1.0, np.abs(g["pred"]).max())
+    assert float(nll) == pytest.approx(float(g["nll"]), rel=tol)
+    assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-3)  # north-star ELBO tolerance
+    # reference-style accessors: mean over samples, fp32 scalars
+    assert float(bmodel.log_prior()) == pytest.approx(g["log_prior"].mean(), rel=1e-6)
+    assert float(bmodel.log_variational_posterior()) == pytest.approx(g["lvp"].mean(), rel=1e-6)
+
+
+def _bert(tiny):
+    from transformers import BertConfig, BertForSequenceClassification
+
+    if tiny:
+        cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                         vocab_size=1000, max_position_embeddings=64)
+    else:
+        cfg = BertConfig()
+    torch.manual_seed(0)
+    return cfg, BertForSequenceClassification(cfg).eval()
+
+
+@pytest.mark.parametrize("fixture,tiny,dtype,tol", [("bert_tiny", True, "fp32", 2e-4), ("bert_tiny", True, "bf16", 5e-2),
+                                                    ("bert_c3", False, "bf16", 5e-2), ("bert_c3", False, "fp32", 5e-4)])
+def test_bert(golden_dir, fixture, tiny, dtype, tol):
+    g = np.load(f"{golden_dir}/{fixture}.npz")
+    S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
+    cfg, model = _bert(tiny)
+    bmodel = bf.to_bayesian(model, delta=float(g["delta"]), freeze=True).eval()
+    assert len(bmodel.fused_children()) == int(g["n_layers"])
+    assert checksum(bmodel) == pytest.approx(float(g["checksum"]), rel=1e-6)  # init/MOPED differ by ulps across host CPUs
+    torch.manual_seed(int(g["input_seed"]))
+    ids = torch.randint(0, cfg.vocab_size, (B, L))
+    mask = torch.ones(B, L, dtype=torch.long)
+    labels = torch.randint(0, 2, (B,))
+    assert int(ids.sum()) == int(g["ids_sum"]) and np.array_equal(labels.numpy(), g["labels"])
+    bmodel = bmodel.cuda()
+    if dtype != "fp32":
+        bmodel = bmodel.to(torch.bfloat16)   # activations bf16 end to end; mu/rho stay fp32 masters
+    bf.manual_seed(SEED)
+    bf.set_compute_dtype(dtype)
+    try:
+        with torch.no_grad():
+            inputs = {"input_ids": ids.cuda(), "attention_mask": mask.cuda()}
+            raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S)
+            nll = torch.nn.functional.cross_entropy(mean[0].float(), labels.cuda())
+    finally:
+        bf.set_compute_dtype("bf16")
+    lps = bmodel.log_prob_samples().cpu().numpy()
+    np.testing.assert_allclose(lps[:, 0], g["log_prior"], rtol=2e-6)
+    np.testing.assert_allclose(lps[:, 1], g["lvp"], rtol=2e-6)
+    logits = raw[0].float().cpu().numpy()
+    assert np.abs(logits - g["logits"]).max() < tol * max(1.0, np.abs(g["logits"]).max())
+    assert float(nll) == pytest.approx(float(g["nll"]), rel=max(tol, 1e-3), abs=tol)
+    n_batches = 2105  # SST-2 train set / batch 32
+    ref_loss = (g["lvp"].mean() - g["log_prior"].mean()) / n_batches + float(g["nll"])
+    assert float(elbo(lp, lq, nll.double(), n_batches)) == pytest.approx(ref_loss, rel=1e-3)

@@ -1,0 +1,68 @@
+"""Shared helpers of the GPU parity tests."""
+import numpy as np
+import torch
+
+import bayeformers_amd.nn as bnn
+from oracle import bayes_oracle as bo
+
+SEED = 0x5EED
+
+
+def load_case(g, name):
+    return {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(name + "/")}
+
+
+def layer_from_case(c, device="cuda"):
+    """bnn.Linear holding exactly the fixture's parameters."""
+    N, K = c["w_mu"].shape
+    has_bias = "b_mu" in c
+    if "mixture" in c:
+        pi, s1, s2 = (float(v) for v in c["mixture"])
+        default = (pi, s1, s2) == (0.5, 1.0, float(np.float32(np.exp(-6))))
+        prior = bnn.DEFAULT_SCALED_GAUSSIAN_MIXTURE if default else bnn.ScaledGaussianMixture(pi, s1, s2)
+        layer = bnn.Linear(K, N, bias=has_bias, prior=prior)
+    else:
+        layer = bnn.Linear(K, N, bias=has_bias)
+        wp = bnn.Gaussian(torch.Size((N, K)))
+        wp.mu.data, wp.rho.data = torch.from_numpy(c["wp_mu"]), torch.from_numpy(c["wp_rho"])
+        layer.weight_prior = wp
+        if has_bias:
+            bp = bnn.Gaussian(torch.Size((N,)))
+            bp.mu.data, bp.rho.data = torch.from_numpy(c["bp_mu"]), torch.from_numpy(c["bp_rho"])
+            layer.bias_prior = bp
+    layer.weight.mu.data, layer.weight.rho.data = torch.from_numpy(c["w_mu"]), torch.from_numpy(c["w_rho"])
+    if has_bias:
+        layer.bias.mu.data, layer.bias.rho.data = torch.from_numpy(c["b_mu"]), torch.from_numpy(c["b_rho"])
+    layer.layer_id = 0
+    return layer.to(device)
+
+
+def oracle_priors(c):
+    t = lambda k: torch.from_numpy(c[k])
+    if "mixture" in c:
+        pw = ("mixture",) + tuple(float(v) for v in c["mixture"])
+        return pw, pw
+    return ("gaussian", t("wp_mu"), t("wp_rho")), (("gaussian", t("bp_mu"), t("bp_rho")) if "bp_mu" in c else None)
+
+
+def oracle_layer(c, sample, layer_id=0, seed=SEED):
+    """fp32 reference-order (y, lp, lq) and fp64 analytic (lp, lq) of one sample of a fixture layer."""
+    t = lambda k: torch.from_numpy(c[k]) if k in c else None
+    pw, pb = oracle_priors(c)
+    eps_w = bo.eps_tensor(c["w_mu"].shape, seed, sample, layer_id, 0)
+    eps_b = bo.eps_tensor(c["b_mu"].shape, seed, sample, layer_id, 1) if "b_mu" in c else None
+    y, lp, lq = bo.linear_forward(t("x"), t("w_mu"), t("w_rho"), t("b_mu"), t("b_rho"), eps_w, eps_b, pw, pb)
+    lp64, lq64 = bo.linear_logprobs_f64(t("w_mu"), t("w_rho"), t("b_mu"), t("b_rho"), eps_w, eps_b, pw, pb)
+    mags = bo.linear_logprob_magnitudes(t("w_mu"), t("w_rho"), t("b_mu"), t("b_rho"), eps_w, eps_b, pw, pb)
+    return y, float(lp), float(lq), lp64, lq64, mags
+
+
+def run_layer(layer, x, S, base, seed=SEED):
+    """One batched forward of a bare layer through a bnn.Model: returns y [S, M, N] and lp [S, 2] float64."""
+    import bayeformers_amd as bf
+
+    model = bnn.Model(layer)
+    bf.manual_seed(seed, next_sample=base)
+    with torch.no_grad(), model.monte_carlo(S):
+        y = model(x.repeat(S, *([1] * (x.dim() - 1))))
+    return y.view(S, -1, layer.out_features), model.log_prob_samples().clone()
