@@ -12,19 +12,18 @@
 //   gemm_nt_kernel<T,XT,YT,ALIGNED> : bf16/fp16 MFMA (v_mfma_f32_16x16x32_*), 128x128x32 tile, 4 waves (2x2),
 //                                     register-prefetched, double-buffered LDS; any M,N,K (K%8 != 0 -> scalar loads)
 //   gemm_nt_f32_kernel              : exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), 64x64x16 tile — the parity path
+#include <stdlib.h>
+
 #include "bf_common.h"
+#include "bf_gemm_params.h"
 
 namespace {
 
-struct GemmParams {
-    const void* x;
-    const void* w;
-    const float* bias;
-    void* y;
-    long long x_sstride;  // elements between samples of x (0 = shared)
-    int S, M, N, K;
-    int tiles_m, tiles_n;
-};
+// developer knob: BF_GEMM_VARIANT=0 forces the generic kernel (read on every call; a getenv is ~50 ns)
+int gemm_variant() {
+    const char* v = getenv("BF_GEMM_VARIANT");
+    return v ? atoi(v) : 2;  // 2 = ping-pong (default), 3 = persistent ping-pong, 1 = lockstep, 0 = generic
+}
 
 template <typename T>
 struct Mfma16;
@@ -301,6 +300,11 @@ int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, con
         BF_HIP_CHECK(hipGetLastError());
         return 0;
     }
+    // large aligned problems: the 256x256x64 LDS-DMA kernel; everything else: the generic 128x128x32 kernel
+    const int variant = gemm_variant();
+    if (variant != 0 && (long long)M * N >= 128 * 128 &&
+        bf_gemm256_supported(x_dtype, w_dtype, y_dtype, S, M, N, K, d_x, d_w, x_sample_stride))
+        return bf_launch_gemm256(p, w_dtype, y_dtype, variant, stream);
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
     const size_t xs = bf_dtype_size(x_dtype);

@@ -108,7 +108,9 @@ def test_batched_equals_serial_and_is_deterministic(cases):
 
 
 GEMM_SHAPES = [(1, 1, 1, 8), (2, 5, 3, 8), (1, 128, 128, 32), (3, 130, 70, 72), (2, 33, 129, 40), (1, 257, 2, 768),
-               (2, 64, 10, 512), (1, 17, 9, 33), (2, 31, 65, 100), (1, 300, 256, 264)]
+               (2, 64, 10, 512), (1, 17, 9, 33), (2, 31, 65, 100), (1, 300, 256, 264),
+               # K % 64 == 0 and M*N >= 128*128: the 256x256x64 LDS-DMA kernel, with ragged M and N edges
+               (1, 256, 256, 64), (2, 300, 200, 128), (3, 513, 259, 192), (1, 1000, 130, 768), (2, 129, 1030, 64)]
 
 
 @pytest.mark.parametrize("S,M,N,K", GEMM_SHAPES)
