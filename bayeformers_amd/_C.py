@@ -47,6 +47,10 @@ SYMBOLS = {
     "bf_philox_normal": (_i, [_vp, _u64, _i, _u64, _u32, _u32, _vp]),
     "bf_sample_logprob_workspace_bytes": (_sz, [_tp, _i, _i]),
     "bf_sample_logprob": (_i, [_tp, _i, _i, _u64, _u32, _vp, _vp, _sz, _vp]),
+    "bf_sample_table_bytes": (_sz, [_tp, _i, ctypes.POINTER(ctypes.c_uint32)]),
+    "bf_sample_table_build": (_i, [_tp, _i, _vp, _sz, _vp]),
+    "bf_sample_logprob_table": (_i, [_vp, _i, _u32, _u32, _i, _u64, _u32, _vp, _vp]),
+    "bf_reduce_logprob": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "bf_gemm_nt": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "bf_linear_fwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "bf_linear_fwd": (_i, [_vp, _i, _i64, _tp, _tp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u32, _vp, _vp, _sz, _vp]),

@@ -158,6 +158,29 @@ int bf_sample_logprob(const bf_tensor_t* tensors, int n_tensors, int S, uint64_t
                                     workspace_bytes, (hipStream_t)stream);
 }
 
+size_t bf_sample_table_bytes(const bf_tensor_t* tensors, int n_tensors, uint32_t* total_blocks) {
+    if (!tensors || n_tensors < 1) return 0;
+    return bf_table_blob_bytes(tensors, n_tensors, total_blocks);
+}
+
+int bf_sample_table_build(const bf_tensor_t* tensors, int n_tensors, void* h_blob, size_t blob_bytes,
+                          uint32_t* h_block_begin) {
+    if (!tensors || n_tensors < 1) BF_FAIL("bf_sample_table_build: no tensors");
+    return bf_table_build(tensors, n_tensors, h_blob, blob_bytes, h_block_begin);
+}
+
+int bf_sample_logprob_table(const void* d_blob, int n_tensors, uint32_t block_begin, uint32_t block_end, int S,
+                            uint64_t seed, uint32_t sample_base, double* d_partials, void* stream) {
+    ProfScope prof(BF_PROF_SAMPLE, 0.0, (hipStream_t)stream);
+    return bf_launch_sample_table(d_blob, n_tensors, block_begin, block_end, S, seed, sample_base, d_partials,
+                                  (hipStream_t)stream);
+}
+
+int bf_reduce_logprob(const double* d_partials, const uint32_t* d_rows, int n_groups, int S, double* d_out,
+                      void* stream) {
+    return bf_launch_reduce_groups(d_partials, d_rows, n_groups, S, d_out, (hipStream_t)stream);
+}
+
 int bf_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
                const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, void* stream) {
     ProfScope prof(BF_PROF_GEMM, 2.0 * S * M * (double)N * K, (hipStream_t)stream);

@@ -72,6 +72,28 @@ __device__ __forceinline__ void store4(YT* y, long long m, int n, int M, int N, 
     }
 }
 
+
+// acc[nb][mb][j] starts at bias[n] (n = the lane's 4 consecutive features of fragment nb): the bias add costs no
+// epilogue work and its loads overlap the first DMA wait of the tile.
+__device__ __forceinline__ void init_acc(f32x4_t (&acc)[4][8], const float* bias, int n0, int N, int wn, int lane) {
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        f32x4_t b = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            const int n = n0 + wn * 64 + nb * 16 + (lane >> 4) * 4;
+            if (n + 3 < N) {
+                b = *reinterpret_cast<const f32x4_t*>(bias + n);  // [S][N] fp32 rows, N % 4 == 0 checked on the host
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n + j < N) b[j] = bias[n + j];
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = b;
+    }
+}
+
 // XCD-aware bijective remap of the flat block id (block b runs on XCD b % 8, observed; speed only).
 __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nwg) {
     const unsigned xcd = b & 7u, q = nwg >> 3, r = nwg & 7u;
@@ -113,16 +135,10 @@ __device__ __forceinline__ void epilogue_via_lds(char* smem, const f32x4_t (&acc
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
                 const int nl = wn * 64 + nb * 16 + (lane >> 4) * 4;
-                f32x4_t b = {0.f, 0.f, 0.f, 0.f};
-                if (bias) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (n0 + nl + j < N) b[j] = bias[n0 + nl + j];
-                }
 #pragma unroll
                 for (int mb = 0; mb < 8; ++mb) {
                     const int ml = (PASSES == 1 ? wm * 128 : 0) + mb * 16 + (lane & 15);
-                    const f32x4_t v = acc[nb][mb] + b;
+                    const f32x4_t v = acc[nb][mb];
                     char* dst = smem + ml * ROW + nl * (int)sizeof(YT);
                     if constexpr (sizeof(YT) == 4)
                         *reinterpret_cast<f32x4_t*>(dst) = v;
@@ -318,12 +334,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_pp_kernel(const GemmParams p) 
     const int xfrag_base = wm * 128 * ROW_BYTES;
     const int wfrag_base = X_BYTES + wn * 64 * ROW_BYTES;
 
+    const float* bias = p.bias ? p.bias + (long long)s * N : nullptr;
     f32x4_t acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    init_acc(acc, bias, n0, N, wn, lane);
 
+    // De-synchronise the CUs: every tile takes the same time, so without this all 256 CUs stream their operands,
+    // run their MFMAs and write their output tiles in lock-step, and the HBM write burst of the epilogues overlaps
+    // with nothing.  Workgroups of the first dispatch round start 0..3 quarter-periods late (spread evenly inside
+    // each XCD); later workgroups inherit the offsets because they start when an earlier one retires.
+    if (p.stagger > 0 && blockIdx.x < 256u) {
+        const unsigned phase = (blockIdx.x >> 3) & 3u;
+        if (phase) {
+            const unsigned long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < (unsigned long long)(phase * (unsigned)p.stagger)) __builtin_amdgcn_s_sleep(8);
+        }
+    }
     const int nk = K / TK;
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -389,8 +414,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_pp_kernel(const GemmParams p) 
 
     if (p.flags & 8) return;
     YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
-    const float* bias = p.bias ? p.bias + (long long)s * N : nullptr;
-    epilogue_via_lds<YT>(smem, acc, bias, y, m0, n0, M, N, wm, wn, wid, lane);
+    epilogue_via_lds<YT>(smem, acc, nullptr, y, m0, n0, M, N, wm, wn, wid, lane);
 }
 
 
@@ -429,17 +453,10 @@ __device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&ac
         if (wm == pass / PASSES_PER_GROUP) {
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
-                f32x4_t b = {0.f, 0.f, 0.f, 0.f};
-                if (bias) {
-                    const int nn = n0 + wn * 64 + nb * 16 + (lane >> 4) * 4;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (nn + j < N) b[j] = bias[nn + j];
-                }
 #pragma unroll
                 for (int k = 0; k < MB_PER_PASS; ++k) {
                     const int mb = (pass % PASSES_PER_GROUP) * MB_PER_PASS + k;
-                    const f32x4_t v = acc[nb][mb] + b;
+                    const f32x4_t v = acc[nb][mb];
                     char* dst = region + wr_off + k * 16 * ROW + nb * 16 * (int)sizeof(YT);
                     if constexpr (sizeof(YT) == 4)
                         *reinterpret_cast<f32x4_t*>(dst) = v;
@@ -581,17 +598,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
     for (;;) {
         const bool has_next = vb + gridDim.x < total;
         if (wm == 1) __builtin_amdgcn_s_barrier();  // G1 runs one slot behind G0
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        init_acc(acc, p.bias ? p.bias + (long long)s * N : nullptr, n0, N, wn, lane);
 
-        for (int kt = 0; kt + 1 < nk; ++kt) kstep([&] { stage(cur, kt + 1, (g & 1) ^ 1); });
+        for (int kt = 0; kt + 1 < nk; ++kt) kstep([&] { if (!(p.flags & 1)) stage(cur, kt + 1, (g & 1) ^ 1); });
         // last k-step: its DMA slot fetches k-step 0 of this workgroup's next tile
         unsigned vbn = vb + gridDim.x;
         asm volatile("" : "+s"(vbn));  // keep the next tile's address arithmetic out of the k-loop's live ranges
         kstep([&] {
-            if (has_next) {
+            if (has_next && !(p.flags & 1)) {
                 Src nxt;
                 int s2, m2, n2;
                 tile_setup(vbn, nxt, s2, m2, n2);
@@ -602,8 +616,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
 
         // the last consumed buffer is (g-1)&1; buffer g&1 already holds k-step 0 of the next tile
         YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
-        const float* bias = p.bias ? p.bias + (long long)s * N : nullptr;
-        epilogue_passes<YT>(smem + ((g - 1) & 1) * STAGE_BYTES, acc, bias, y, m0, n0, M, N, wm, wn, wid, lane);
+        if (!(p.flags & 8))
+            epilogue_passes<YT>(smem + ((g - 1) & 1) * STAGE_BYTES, acc, nullptr, y, m0, n0, (p.flags & 16) ? 0 : M, N, wm,
+                                wn, wid, lane);
         if (!has_next) break;
         vb = vbn;
         tile_setup(vb, cur, s, m0, n0);
@@ -653,6 +668,7 @@ bool bf_gemm256_supported(int x_dtype, int w_dtype, int y_dtype, int S, int M, i
     if (x_dtype != w_dtype) return false;
     if (y_dtype != w_dtype && y_dtype != BF_DT_F32) return false;
     if (K % TK != 0 || K < TK) return false;
+    if (N % 4 != 0) return false;  // 16-byte bias rows / output chunks
     if (((uintptr_t)d_x | (uintptr_t)d_w) & 15) return false;
     if (((size_t)x_sample_stride * 2) % 16 != 0) return false;
     if ((long long)M * K >= (1ll << 32) || (long long)N * K >= (1ll << 32) || (long long)M * N >= (1ll << 31)) return false;
@@ -666,6 +682,13 @@ int bf_launch_gemm256(const GemmParams& p0, int w_dtype, int y_dtype, int varian
     GemmParams p = p0;
     const char* ab = getenv("BF_GEMM_ABLATE");
     p.flags = ab ? atoi(ab) : 0;
+    // quarter of a tile period: ~1.15 us per 64-deep k-step + ~9 us of prologue/epilogue, in 10 ns ticks
+    const char* st = getenv("BF_GEMM_STAGGER");
+    const double period_us = 1.15 * (p.K / TK) + 9.0;
+    const long long ntiles = (long long)((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN) * p.S;
+    p.stagger = st ? atoi(st) : 0;  // measured: no gain on MI355X (the epilogue was latency-, not HBM-burst-bound)
+    (void)period_us;
+    (void)ntiles;
     p.tiles_m = (p.M + TM - 1) / TM;
     p.tiles_n = (p.N + TN - 1) / TN;
     if (w_dtype == BF_DT_BF16) return launch256<__bf16>(p, y_dtype, variant, stream);

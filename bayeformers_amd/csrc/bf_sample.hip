@@ -6,28 +6,34 @@
 //   Gaussian.log_prob    .../gaussian.py:103-116                                        (posterior, and MOPED prior)
 //   ScaledGaussianMixture.log_prob  .../gaussian.py:160-171
 //   the four accumulations in Linear.forward  /root/reference/bayeformers/nn/layers/linear.py:99-102
-// with ONE launch over all S samples: mu/rho (and the Gaussian prior's mu/rho) are read once from HBM
-// (8 or 16 B per scalar), softplus/log are evaluated once per scalar, epsilon is generated in registers from the
-// Philox counter (bf_philox.h), W_s is written once as bf16/fp16/fp32 (2-4 B per scalar-sample) and the two
-// log-probs are reduced wave -> block -> fixed-order partials (deterministic, fp64 at block level and above).
+// with ONE launch over all S samples: mu/rho (and the Gaussian prior's mu/rho) are read once from HBM with 16-byte
+// loads (8 or 16 B per scalar), softplus/log are evaluated once per scalar and reused for every sample, epsilon is
+// generated in registers from the Philox counter (bf_philox.h, one Philox4x32-10 block = the 4 scalars a thread
+// owns), W_s is written once as bf16/fp16/fp32 and the two log-probs are reduced lane -> wave (DPP) -> block (LDS)
+// -> fixed-order fp64 partials (deterministic).
 //
-// Roofline: HBM-bound at S<=2, VALU/transcendental-bound beyond (one Philox4x32-10 call per 4 normals, one
-// Box-Muller per 2, ~1 exp2 + 1 log2 per scalar-sample for the mixture prior).
+// Roofline: HBM-bound at S <= 2; beyond that VALU/transcendental-bound (per scalar-sample: 1/4 Philox block,
+// 1/2 Box-Muller, one fma, ~10 ops + 2 transcendentals for the mixture prior).
 //
 // Numerics (documented deviations from the reference's fp32 expression order):
 //   log q uses eps^2/2 instead of (W-mu)^2/(2 sigma^2)  — identical analytically, avoids the cancellation;
 //   the mixture uses max + log1p(exp(-|d|)) instead of log(pi*exp(lp1) + (1-pi)*exp(lp2)), which in the
-//   reference underflows to -inf for |w| >= 14.3 with sigma1 = 1; here it stays finite.
+//   reference underflows to -inf for |w| >= 14.3 with sigma1 = 1; here it stays finite;
+//   softplus/log run on the hardware exp2/log2 units with an fma-compensated argument (relative error ~2e-7).
+#include <string.h>
+
 #include "bf_common.h"
 #include "bf_philox.h"
 
 namespace {
 
-constexpr int kThreads = 256;        // 4 waves
-constexpr int kElemsPerThread = 8;   // two Philox groups -> one 16-byte bf16 store per sample
+constexpr int kThreads = 256;  // 4 waves
+constexpr int kEPT = 4;        // scalars per thread = one Philox block per sample
 constexpr int kMaxSChunk = 32;
 constexpr int kMaxSeg = 2;
 constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
+constexpr float kLn2 = 0.69314718055994531f;
+constexpr int OUT_NONE = -1;
 
 struct SegDesc {
     const float* mu;
@@ -36,52 +42,76 @@ struct SegDesc {
     const float* rho_p;
     void* out;
     unsigned long long n;
-    float a1, b1, a2, b2;  // mixture: t_i = a_i * w^2 + b_i  (natural log)
-    int prior_kind;
-    int out_dtype;
     uint32_t stream;
     uint32_t block_begin;
     int vec_in;   // mu/rho(/prior) 16B-aligned -> float4 loads on full chunks
-    int vec_out;  // out rows 16B-aligned (n % 8 == 0 and base aligned)
+    int vec_out;  // out rows aligned for one vector store per thread (n % 4 == 0 and base aligned)
 };
 
 struct SampleParams {
     SegDesc seg[kMaxSeg];
+    float a1, b1, a2, b2;  // mixture: t_i = a_i * w^2 + b_i  (natural log)
     int nseg;
     int S;
-    int s_chunk;
+    int ny;  // sample chunks (gridDim.y)
     uint32_t k0, k1;
     uint32_t sample_base;
     uint32_t nblk;
     double* partials;  // [nblk][S][2]
 };
 
-__device__ __forceinline__ float softplus_f(float r) {
-    // torch.nn.functional.softplus(beta=1, threshold=20)
-    return r > 20.0f ? r : log1pf(expf(r));
+// e^x with the argument reduction done in two pieces so the result is good to ~1e-7 relative for |x| <= 80.
+__device__ __forceinline__ float exp_fast(float x) {
+    const float y = x * 1.4426950408889634f;
+    const float yh = __builtin_rintf(y);
+    float r = fmaf(x, 1.4426950408889634f, -yh);   // exact residual of the rounded product
+    r = fmaf(x, 1.9259629911266175e-8f, r);         // low part of log2(e)
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(r), (int)yh);
 }
 
+// torch.nn.functional.softplus(beta=1, threshold=20): sigma = rho > 20 ? rho : log1p(exp(rho))
+__device__ __forceinline__ float softplus_fast(float rho) {
+    const float t = exp_fast(fminf(rho, 21.0f));
+    // small t: alternating series (t^7/7 < 2e-10 relative below 2^-5)
+    const float ser = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, fmaf(t, -1.0f / 6.0f, 0.2f), -0.25f), 1.0f / 3.0f), -0.5f), 1.0f);
+    // otherwise log(u) + (t - (u - 1)) / u with u = fl(1 + t): the second term restores the bits lost in u
+    const float u = 1.0f + t;
+    const float big = fmaf(kLn2, __builtin_amdgcn_logf(u), (t - (u - 1.0f)) * __builtin_amdgcn_rcpf(u));
+    const float sp = t < 0.03125f ? ser : big;
+    return rho > 20.0f ? rho : sp;
+}
+
+__device__ __forceinline__ float log_fast(float x) { return kLn2 * __builtin_amdgcn_logf(x); }
+
+// wave64 sum on the DPP network: row_shr 1,2,4,8 then row_bcast 15 / 31; the total lands in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true);
+    return v + __builtin_bit_cast(float, t);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row holds the row sum
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 template <int OUT_DT>
-__device__ __forceinline__ void store8(void* out, unsigned long long idx, const float w[8], bool vec, int nvalid) {
+__device__ __forceinline__ void store4(void* out, unsigned long long idx, const float (&w)[4], bool vec, int nvalid) {
     if constexpr (OUT_DT == BF_DT_BF16) {
         __bf16* o = reinterpret_cast<__bf16*>(out) + idx;
         if (vec) {
-            f32x8_t v = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]};
-            *reinterpret_cast<bf16x8_t*>(o) = __builtin_convertvector(v, bf16x8_t);
+            *reinterpret_cast<bf16x4_t*>(o) = __builtin_convertvector((f32x4_t{w[0], w[1], w[2], w[3]}), bf16x4_t);
         } else {
             for (int i = 0; i < nvalid; ++i) o[i] = (__bf16)w[i];
         }
     } else if constexpr (OUT_DT == BF_DT_F16) {
         _Float16* o = reinterpret_cast<_Float16*>(out) + idx;
         if (vec) {
-            f32x8_t v = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]};
-            *reinterpret_cast<f16x8_t*>(o) = __builtin_convertvector(v, f16x8_t);
+            *reinterpret_cast<f16x4_t*>(o) = __builtin_convertvector((f32x4_t{w[0], w[1], w[2], w[3]}), f16x4_t);
         } else {
             for (int i = 0; i < nvalid; ++i) o[i] = (_Float16)w[i];
         }
@@ -89,85 +119,98 @@ __device__ __forceinline__ void store8(void* out, unsigned long long idx, const 
         float* o = reinterpret_cast<float*>(out) + idx;
         if (vec) {
             *reinterpret_cast<f32x4_t*>(o) = f32x4_t{w[0], w[1], w[2], w[3]};
-            *reinterpret_cast<f32x4_t*>(o + 4) = f32x4_t{w[4], w[5], w[6], w[7]};
         } else {
             for (int i = 0; i < nvalid; ++i) o[i] = w[i];
         }
     }
 }
 
-__device__ __forceinline__ void load8(const float* p, unsigned long long e0, int nvalid, bool vec, float fill,
-                                      float v[8]) {
-    if (vec && nvalid == 8) {
+__device__ __forceinline__ void load4(const float* p, unsigned long long e0, int nvalid, bool vec, float (&v)[4]) {
+    if (vec && nvalid == 4) {
         const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p + e0);
-        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(p + e0 + 4);
         v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
-        v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = i < nvalid ? p[e0 + i] : fill;
+        for (int i = 0; i < 4; ++i) v[i] = i < nvalid ? p[e0 + i] : 0.f;
     }
 }
 
-// grid = (nblk, ceil(S / s_chunk)); block = 256 threads; thread = 8 consecutive scalars x s_chunk samples.
-template <int PRIOR, int OUT_DT, bool HAS_OUT>
-__device__ __forceinline__ void sample_logprob_body(const SampleParams& p, const SegDesc& sg, float (*red)[kMaxSChunk][2]) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
-    const unsigned long long e0 =
-        ((unsigned long long)(blockIdx.x - sg.block_begin) * kThreads + tid) * kElemsPerThread;
-    const int nvalid = e0 >= sg.n ? 0 : (sg.n - e0 >= 8 ? 8 : (int)(sg.n - e0));
-    const int s_begin = blockIdx.y * p.s_chunk;
-    const int s_count = min(p.s_chunk, p.S - s_begin);
+constexpr int OUT_RUNTIME = -2;
 
-    float mu[8], sigma[8];
-    float pmu[8], pinv[8];  // gaussian prior: mean and 1/(2 sigma_p^2)
+// what one block needs to know about the tensor it works on
+struct BodyArgs {
+    const float* mu;
+    const float* rho;
+    const float* mu_p;
+    const float* rho_p;
+    void* out;
+    unsigned long long n;
+    float a1, b1, a2, b2;
+    uint32_t stream;
+    uint32_t rel_block;  // block index within the tensor
+    int vec_in, vec_out;
+    int out_dt;          // used when OUT_DT == OUT_RUNTIME
+    int S, ny;
+    uint32_t k0, k1, sample_base;
+    double* partial_row;  // this block's [S][2] row of the partials
+};
+
+// block = 256 threads; thread = 4 consecutive scalars x the samples of chunk blockIdx.y.
+template <int PRIOR, int OUT_DT>
+__device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[kMaxSChunk][2], float (*cst)[2]) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long e0 = ((unsigned long long)a.rel_block * kThreads + tid) * kEPT;
+    const int nvalid = e0 >= a.n ? 0 : (a.n - e0 >= 4 ? 4 : (int)(a.n - e0));
+    // balanced sample chunks: chunk y covers [y*S/ny, (y+1)*S/ny)
+    const int s_begin = (int)(((long long)blockIdx.y * a.S) / a.ny);
+    const int s_end = (int)(((long long)(blockIdx.y + 1) * a.S) / a.ny);
+
+    float mu[4], sigma[4];
+    float pmu[4], pinv[4];  // gaussian prior: mean and 1/(2 sigma_p^2)
     float constq = 0.f, constp = 0.f;
     if (nvalid > 0) {
-        float rho[8];
-        load8(sg.mu, e0, nvalid, sg.vec_in, 0.f, mu);
-        load8(sg.rho, e0, nvalid, sg.vec_in, 0.f, rho);
+        float rho[4];
+        load4(a.mu, e0, nvalid, a.vec_in, mu);
+        load4(a.rho, e0, nvalid, a.vec_in, rho);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            sigma[i] = softplus_f(rho[i]);
-            if (i < nvalid) constq += -kLogSqrt2Pi - logf(sigma[i]);
+        for (int i = 0; i < 4; ++i) {
+            sigma[i] = softplus_fast(rho[i]);
+            if (i < nvalid) constq += -kLogSqrt2Pi - log_fast(sigma[i]);
         }
         if constexpr (PRIOR == BF_PRIOR_GAUSSIAN) {
-            float prho[8];
-            load8(sg.mu_p, e0, nvalid, sg.vec_in, 0.f, pmu);
-            load8(sg.rho_p, e0, nvalid, sg.vec_in, 0.f, prho);
+            float prho[4];
+            load4(a.mu_p, e0, nvalid, a.vec_in, pmu);
+            load4(a.rho_p, e0, nvalid, a.vec_in, prho);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float sp = softplus_f(prho[i]);
-                pinv[i] = 0.5f / (sp * sp);
-                if (i < nvalid) constp += -kLogSqrt2Pi - logf(sp);
+            for (int i = 0; i < 4; ++i) {
+                const float sp = softplus_fast(prho[i]);
+                pinv[i] = 0.5f * __builtin_amdgcn_rcpf(sp * sp);
+                if (i < nvalid) constp += -kLogSqrt2Pi - log_fast(sp);
             }
         }
     }
     const uint32_t g_lo = (uint32_t)(e0 >> 2), g_hi = (uint32_t)(e0 >> 34);
-    // (e0>>2)+1 cannot carry into the high word: e0 is a multiple of 8, so the low group index is even.
 
-    for (int si = 0; si < s_count; ++si) {
+    for (int s = s_begin; s < s_end; ++s) {
         float lq = 0.f, lp = 0.f;
         if (nvalid > 0) {
-            const uint32_t sample = p.sample_base + (uint32_t)(s_begin + si);
-            float z[8], w[8];
-            bf_normal4_dev(g_lo, g_hi, sample, sg.stream, p.k0, p.k1, z);
-            bf_normal4_dev(g_lo + 1u, g_hi, sample, sg.stream, p.k0, p.k1, z + 4);
+            float z[4], w[4];
+            bf_normal4_dev(g_lo, g_hi, a.sample_base + (uint32_t)s, a.stream, a.k0, a.k1, z);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 w[i] = fmaf(sigma[i], z[i], mu[i]);
-                float tq = -0.5f * z[i] * z[i];
+                const float tq = -0.5f * z[i] * z[i];
                 float tp = 0.f;
                 if constexpr (PRIOR == BF_PRIOR_MIXTURE) {
                     const float w2 = w[i] * w[i];
-                    const float t1 = fmaf(sg.a1, w2, sg.b1);
-                    const float t2 = fmaf(sg.a2, w2, sg.b2);
+                    const float t1 = fmaf(a.a1, w2, a.b1);
+                    const float t2 = fmaf(a.a2, w2, a.b2);
                     const float m = fmaxf(t1, t2);
                     const float d = fabsf(t1 - t2);
                     // log(e^t1 + e^t2) = m + ln2 * log2(1 + 2^(-d*log2e))
                     const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * d);
-                    tp = fmaf(0.69314718055994531f, __builtin_amdgcn_logf(1.0f + e), m);
+                    tp = fmaf(kLn2, __builtin_amdgcn_logf(1.0f + e), m);
                 } else if constexpr (PRIOR == BF_PRIOR_GAUSSIAN) {
                     const float dlt = w[i] - pmu[i];
                     tp = -(dlt * dlt) * pinv[i];
@@ -177,74 +220,115 @@ __device__ __forceinline__ void sample_logprob_body(const SampleParams& p, const
                     lp += tp;
                 }
             }
-            if constexpr (HAS_OUT) {
-                store8<OUT_DT>(sg.out, (unsigned long long)(s_begin + si) * sg.n + e0, w, sg.vec_out && nvalid == 8,
-                               nvalid);
+            if (a.out) {
+                const unsigned long long idx = (unsigned long long)s * a.n + e0;
+                const bool vec = a.vec_out && nvalid == 4;
+                if constexpr (OUT_DT == OUT_RUNTIME) {
+                    if (a.out_dt == BF_DT_BF16) store4<BF_DT_BF16>(a.out, idx, w, vec, nvalid);
+                    else if (a.out_dt == BF_DT_F16) store4<BF_DT_F16>(a.out, idx, w, vec, nvalid);
+                    else store4<BF_DT_F32>(a.out, idx, w, vec, nvalid);
+                } else if constexpr (OUT_DT != OUT_NONE) {
+                    store4<OUT_DT>(a.out, idx, w, vec, nvalid);
+                }
             }
         }
         lq = wave_sum(lq);
         lp = wave_sum(lp);
         if (lane == 0) {
-            red[wid][si][0] = lp;
-            red[wid][si][1] = lq;
+            red[wid][s - s_begin][0] = lp;
+            red[wid][s - s_begin][1] = lq;
         }
     }
     // sample-independent parts: sum_e(-c - log sigma_e) for q, sum_e(-c - log sigma_p,e) for a Gaussian prior
     constq = wave_sum(constq);
     constp = wave_sum(constp);
-    __shared__ float cst[4][2];
     if (lane == 0) {
         cst[wid][0] = constp;
         cst[wid][1] = constq;
     }
     __syncthreads();
-    if (tid < 2 * s_count) {
-        const int si = tid >> 1, j = tid & 1;
+    if (tid < 2 * (s_end - s_begin)) {
+        const int sl = tid >> 1, j = tid & 1;
         double acc = 0.0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) acc += (double)red[w][si][j];
-        double c = 0.0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) c += (double)cst[w][j];
-        p.partials[((size_t)blockIdx.x * p.S + (s_begin + si)) * 2 + j] = acc + c;
+        for (int w = 0; w < 4; ++w) acc += (double)red[w][sl][j] + (double)cst[w][j];
+        a.partial_row[(s_begin + sl) * 2 + j] = acc;
     }
 }
 
-template <int PRIOR, int OUT_DT, bool HAS_OUT>
-__device__ __forceinline__ void dispatch_body(const SampleParams& p, const SegDesc& sg, float (*red)[kMaxSChunk][2]) {
-    sample_logprob_body<PRIOR, OUT_DT, HAS_OUT>(p, sg, red);
-}
-
+// Per-layer launch: grid = (nblk, ny).  Segment 0 (the weight) is written as OUT_DT, segment 1 (the bias) as fp32.
+template <int PRIOR, int OUT_DT>
 __global__ __launch_bounds__(kThreads) void bf_sample_logprob_kernel(const SampleParams p) {
     __shared__ float red[4][kMaxSChunk][2];
+    __shared__ float cst[4][2];
     const int si = (p.nseg > 1 && blockIdx.x >= p.seg[1].block_begin) ? 1 : 0;
     const SegDesc& sg = p.seg[si];
-    const bool has_out = sg.out != nullptr;
-#define BF_CASE(PR, DT)                                                  \
-    if (sg.prior_kind == PR && (!has_out || sg.out_dtype == DT)) {       \
-        if (has_out)                                                     \
-            dispatch_body<PR, DT, true>(p, sg, red);                     \
-        else                                                             \
-            dispatch_body<PR, DT, false>(p, sg, red);                    \
-        return;                                                          \
+    BodyArgs a;
+    a.mu = sg.mu; a.rho = sg.rho; a.mu_p = sg.mu_p; a.rho_p = sg.rho_p; a.out = sg.out; a.n = sg.n;
+    a.a1 = p.a1; a.b1 = p.b1; a.a2 = p.a2; a.b2 = p.b2;
+    a.stream = sg.stream; a.rel_block = blockIdx.x - sg.block_begin;
+    a.vec_in = sg.vec_in; a.vec_out = sg.vec_out; a.out_dt = BF_DT_F32;
+    a.S = p.S; a.ny = p.ny; a.k0 = p.k0; a.k1 = p.k1; a.sample_base = p.sample_base;
+    a.partial_row = p.partials + (size_t)blockIdx.x * p.S * 2;
+    if (si == 0) sample_body<PRIOR, OUT_DT>(a, red, cst);
+    else sample_body<PRIOR, BF_DT_F32>(a, red, cst);
+}
+
+// Cross-layer launch: one grid over the blocks of MANY tensors described by a device-resident table.
+struct TableEntry {
+    const float* mu;
+    const float* rho;
+    const float* mu_p;
+    const float* rho_p;
+    void* out;
+    unsigned long long n;
+    float a1, b1, a2, b2;
+    uint32_t stream;
+    uint32_t block_begin;
+    int prior_kind;
+    int out_dt;
+    int vec_in, vec_out;
+};
+
+__global__ __launch_bounds__(kThreads) void bf_sample_table_kernel(const TableEntry* __restrict__ table,
+                                                                   const uint32_t* __restrict__ entry_of_block,
+                                                                   uint32_t block0, int S, int ny, uint32_t k0,
+                                                                   uint32_t k1, uint32_t sample_base,
+                                                                   double* __restrict__ partials) {
+    __shared__ float red[4][kMaxSChunk][2];
+    __shared__ float cst[4][2];
+    const uint32_t gb = block0 + blockIdx.x;
+    const TableEntry& e = table[entry_of_block[gb]];
+    BodyArgs a;
+    a.mu = e.mu; a.rho = e.rho; a.mu_p = e.mu_p; a.rho_p = e.rho_p; a.out = e.out; a.n = e.n;
+    a.a1 = e.a1; a.b1 = e.b1; a.a2 = e.a2; a.b2 = e.b2;
+    a.stream = e.stream; a.rel_block = gb - e.block_begin;
+    a.vec_in = e.vec_in; a.vec_out = e.vec_out; a.out_dt = e.out_dt;
+    a.S = S; a.ny = ny; a.k0 = k0; a.k1 = k1; a.sample_base = sample_base;
+    a.partial_row = partials + (size_t)gb * S * 2;
+    const int pk = __builtin_amdgcn_readfirstlane(e.prior_kind);
+    if (pk == BF_PRIOR_GAUSSIAN) sample_body<BF_PRIOR_GAUSSIAN, OUT_RUNTIME>(a, red, cst);
+    else if (pk == BF_PRIOR_MIXTURE) sample_body<BF_PRIOR_MIXTURE, OUT_RUNTIME>(a, red, cst);
+    else sample_body<BF_PRIOR_NONE, OUT_RUNTIME>(a, red, cst);
+}
+
+// out[g][s][j] = sum of partial rows [rows[g], rows[g+1]) in a fixed order.  grid = (2*S, G).
+__global__ __launch_bounds__(256) void bf_reduce_groups_kernel(const double* __restrict__ partials,
+                                                               const uint32_t* __restrict__ rows, int S,
+                                                               double* __restrict__ out) {
+    __shared__ double sh[256];
+    const int sj = blockIdx.x, g = blockIdx.y;
+    const uint32_t r0 = rows[g], r1 = rows[g + 1];
+    double acc = 0.0;
+    for (uint32_t b = r0 + threadIdx.x; b < r1; b += 256) acc += partials[(size_t)b * S * 2 + sj];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
     }
-    // without an output the dtype is irrelevant: route everything through the BF16 instantiation
-    if (!has_out) {
-        if (sg.prior_kind == BF_PRIOR_MIXTURE) dispatch_body<BF_PRIOR_MIXTURE, BF_DT_BF16, false>(p, sg, red);
-        else if (sg.prior_kind == BF_PRIOR_GAUSSIAN) dispatch_body<BF_PRIOR_GAUSSIAN, BF_DT_BF16, false>(p, sg, red);
-        else dispatch_body<BF_PRIOR_NONE, BF_DT_BF16, false>(p, sg, red);
-        return;
-    }
-    BF_CASE(BF_PRIOR_MIXTURE, BF_DT_BF16)
-    BF_CASE(BF_PRIOR_MIXTURE, BF_DT_F16)
-    BF_CASE(BF_PRIOR_MIXTURE, BF_DT_F32)
-    BF_CASE(BF_PRIOR_GAUSSIAN, BF_DT_BF16)
-    BF_CASE(BF_PRIOR_GAUSSIAN, BF_DT_F16)
-    BF_CASE(BF_PRIOR_GAUSSIAN, BF_DT_F32)
-    BF_CASE(BF_PRIOR_NONE, BF_DT_BF16)
-    BF_CASE(BF_PRIOR_NONE, BF_DT_F16)
-    BF_CASE(BF_PRIOR_NONE, BF_DT_F32)
-#undef BF_CASE
+    if (threadIdx.x == 0) out[(size_t)g * S * 2 + sj] = sh[0];
 }
 
 // out[s][j] = sum_b partials[b][s][j] in a fixed order (deterministic).  grid = 2*S blocks of 256 threads.
@@ -279,8 +363,18 @@ __global__ __launch_bounds__(256) void bf_philox_normal_kernel(float* __restrict
 }
 
 inline uint32_t blocks_for(uint64_t n) {
-    const uint64_t per_block = (uint64_t)kThreads * kElemsPerThread;
+    const uint64_t per_block = (uint64_t)kThreads * kEPT;
     return (uint32_t)((n + per_block - 1) / per_block);
+}
+
+template <int PRIOR>
+void launch_prior(int out_dt, dim3 grid, hipStream_t stream, const SampleParams& p) {
+    switch (out_dt) {
+        case BF_DT_BF16: hipLaunchKernelGGL((bf_sample_logprob_kernel<PRIOR, BF_DT_BF16>), grid, dim3(kThreads), 0, stream, p); break;
+        case BF_DT_F16: hipLaunchKernelGGL((bf_sample_logprob_kernel<PRIOR, BF_DT_F16>), grid, dim3(kThreads), 0, stream, p); break;
+        case BF_DT_F32: hipLaunchKernelGGL((bf_sample_logprob_kernel<PRIOR, BF_DT_F32>), grid, dim3(kThreads), 0, stream, p); break;
+        default: hipLaunchKernelGGL((bf_sample_logprob_kernel<PRIOR, OUT_NONE>), grid, dim3(kThreads), 0, stream, p); break;
+    }
 }
 
 }  // namespace
@@ -302,6 +396,172 @@ int bf_launch_philox_normal(float* d_out, uint64_t n, int S, uint64_t seed, uint
     return 0;
 }
 
+static int pick_ny(uint32_t blk, int S);
+
+// One launch covers tensors[first .. first+count) (count <= 2, same prior kind; the second is written as fp32).
+static int launch_group(const bf_tensor_t* tensors, int first, int count, uint32_t blk_offset, int S, uint64_t seed,
+                        uint32_t sample_base, double* partials, uint32_t nblk_total_for_layout, hipStream_t stream) {
+    SampleParams p{};
+    p.nseg = count;
+    p.S = S;
+    p.k0 = (uint32_t)seed;
+    p.k1 = (uint32_t)(seed >> 32);
+    p.sample_base = sample_base;
+    // this group's blocks write partial rows [blk_offset, blk_offset + blk)
+    p.partials = partials + (size_t)blk_offset * (size_t)S * 2;
+    uint32_t blk = 0;
+    const int prior_kind = tensors[first].prior.kind;
+    for (int t = 0; t < count; ++t) {
+        const bf_tensor_t& T = tensors[first + t];
+        SegDesc& sg = p.seg[t];
+        sg.mu = T.d_mu;
+        sg.rho = T.d_rho;
+        sg.n = T.n;
+        sg.out = T.d_sample_out;
+        sg.stream = T.stream_id;
+        sg.mu_p = T.prior.d_mu;
+        sg.rho_p = T.prior.d_rho;
+        uintptr_t align_bits = (uintptr_t)T.d_mu | (uintptr_t)T.d_rho;
+        if (prior_kind == BF_PRIOR_GAUSSIAN) align_bits |= (uintptr_t)T.prior.d_mu | (uintptr_t)T.prior.d_rho;
+        sg.vec_in = (align_bits & 15) == 0;
+        const size_t osz = t == 0 ? bf_dtype_size(T.out_dtype) : 4;
+        sg.vec_out = T.d_sample_out && ((uintptr_t)T.d_sample_out % (4 * osz)) == 0 && (T.n % 4) == 0;
+        sg.block_begin = blk;
+        blk += blocks_for(T.n);
+    }
+    if (prior_kind == BF_PRIOR_MIXTURE) {
+        const double pi = tensors[first].prior.pi, s1 = tensors[first].prior.sigma1, s2 = tensors[first].prior.sigma2;
+        p.a1 = (float)(-0.5 / (s1 * s1));
+        p.a2 = (float)(-0.5 / (s2 * s2));
+        p.b1 = (float)(log(pi) - log(s1) - 0.91893853320467274178);
+        p.b2 = (float)(log1p(-pi) - log(s2) - 0.91893853320467274178);
+    }
+    p.nblk = blk;
+    const int ny = pick_ny(blk, S);
+    p.ny = ny;
+    const dim3 grid(blk, (uint32_t)ny);
+    const int out_dt = tensors[first].d_sample_out ? tensors[first].out_dtype : OUT_NONE;
+    switch (prior_kind) {
+        case BF_PRIOR_MIXTURE: launch_prior<BF_PRIOR_MIXTURE>(out_dt, grid, stream, p); break;
+        case BF_PRIOR_GAUSSIAN: launch_prior<BF_PRIOR_GAUSSIAN>(out_dt, grid, stream, p); break;
+        default: launch_prior<BF_PRIOR_NONE>(out_dt, grid, stream, p); break;
+    }
+    BF_HIP_CHECK(hipGetLastError());
+    (void)nblk_total_for_layout;
+    return 0;
+}
+
+static int pick_ny(uint32_t blk, int S) {
+    // Sample chunks per element block.  The launch runs in rounds of kResident co-resident blocks (256 CUs x 8 blocks
+    // of 4 waves, <= 64 VGPRs); a block costs ~0.35 sample-equivalents for loads + softplus + log and 1 per sample.
+    // Pick the ny that minimises rounds x per-block cost (avoids a nearly empty last round).
+    constexpr double kResident = 2048.0, kSetup = 0.35;
+    int ny = 1;
+    double best = 1e300;
+    for (int c = 1; c <= S; ++c) {
+        const int chunk = (S + c - 1) / c;
+        if (chunk > kMaxSChunk) continue;
+        const double cost = ceil((double)blk * c / kResident) * (kSetup + chunk);
+        if (cost < best - 1e-9) {
+            best = cost;
+            ny = c;
+        }
+    }
+    return ny;
+}
+
+static int validate_tensor(const bf_tensor_t& T, int t) {
+    if (!T.d_mu || !T.d_rho) BF_FAIL("bf_sample_logprob: tensor %d has NULL mu/rho", t);
+    if (T.n == 0) BF_FAIL("bf_sample_logprob: tensor %d is empty", t);
+    switch (T.prior.kind) {
+        case BF_PRIOR_MIXTURE: {
+            const double pi = T.prior.pi, s1 = T.prior.sigma1, s2 = T.prior.sigma2;
+            if (!(s1 > 0.0) || !(s2 > 0.0) || !(pi >= 0.0) || !(pi <= 1.0))
+                BF_FAIL("bf_sample_logprob: bad mixture prior (pi=%g sigma1=%g sigma2=%g)", pi, s1, s2);
+            break;
+        }
+        case BF_PRIOR_GAUSSIAN:
+            if (!T.prior.d_mu || !T.prior.d_rho) BF_FAIL("bf_sample_logprob: gaussian prior needs d_mu/d_rho");
+            break;
+        case BF_PRIOR_NONE:
+            break;
+        default:
+            BF_FAIL("bf_sample_logprob: unknown prior kind %d", T.prior.kind);
+    }
+    if (T.d_sample_out && (T.out_dtype < BF_DT_F32 || T.out_dtype > BF_DT_F16))
+        BF_FAIL("bf_sample_logprob: bad out_dtype %d", T.out_dtype);
+    return 0;
+}
+
+size_t bf_table_blob_bytes(const bf_tensor_t* tensors, int n_tensors, uint32_t* total_blocks) {
+    uint64_t blk = 0;
+    for (int t = 0; t < n_tensors; ++t) blk += blocks_for(tensors[t].n);
+    if (total_blocks) *total_blocks = (uint32_t)blk;
+    return bf_align_up((size_t)n_tensors * sizeof(TableEntry), 256) + bf_align_up((size_t)blk * sizeof(uint32_t), 256);
+}
+
+int bf_table_build(const bf_tensor_t* tensors, int n_tensors, void* h_blob, size_t blob_bytes, uint32_t* h_block_begin) {
+    uint32_t total = 0;
+    const size_t need = bf_table_blob_bytes(tensors, n_tensors, &total);
+    if (!h_blob || blob_bytes < need) BF_FAIL("bf_sample_table_build: blob too small (%zu < %zu bytes)", blob_bytes, need);
+    TableEntry* ent = reinterpret_cast<TableEntry*>(h_blob);
+    uint32_t* map = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(h_blob) +
+                                                bf_align_up((size_t)n_tensors * sizeof(TableEntry), 256));
+    uint32_t blk = 0;
+    for (int t = 0; t < n_tensors; ++t) {
+        const bf_tensor_t& T = tensors[t];
+        if (int rc = validate_tensor(T, t)) return rc;
+        TableEntry& e = ent[t];
+        memset(&e, 0, sizeof(e));
+        e.mu = T.d_mu; e.rho = T.d_rho; e.mu_p = T.prior.d_mu; e.rho_p = T.prior.d_rho;
+        e.out = T.d_sample_out; e.n = T.n; e.stream = T.stream_id; e.block_begin = blk;
+        e.prior_kind = T.prior.kind; e.out_dt = T.out_dtype;
+        uintptr_t align_bits = (uintptr_t)T.d_mu | (uintptr_t)T.d_rho;
+        if (T.prior.kind == BF_PRIOR_GAUSSIAN) align_bits |= (uintptr_t)T.prior.d_mu | (uintptr_t)T.prior.d_rho;
+        e.vec_in = (align_bits & 15) == 0;
+        const size_t osz = bf_dtype_size(T.out_dtype);
+        e.vec_out = T.d_sample_out && ((uintptr_t)T.d_sample_out % (4 * osz)) == 0 && (T.n % 4) == 0;
+        if (T.prior.kind == BF_PRIOR_MIXTURE) {
+            const double pi = T.prior.pi, s1 = T.prior.sigma1, s2 = T.prior.sigma2;
+            e.a1 = (float)(-0.5 / (s1 * s1));
+            e.a2 = (float)(-0.5 / (s2 * s2));
+            e.b1 = (float)(log(pi) - log(s1) - 0.91893853320467274178);
+            e.b2 = (float)(log1p(-pi) - log(s2) - 0.91893853320467274178);
+        }
+        if (h_block_begin) h_block_begin[t] = blk;
+        const uint32_t nb = blocks_for(T.n);
+        for (uint32_t b = 0; b < nb; ++b) map[blk + b] = (uint32_t)t;
+        blk += nb;
+    }
+    if (h_block_begin) h_block_begin[n_tensors] = blk;
+    return 0;
+}
+
+int bf_launch_sample_table(const void* d_blob, int n_tensors, uint32_t block_begin, uint32_t block_end, int S,
+                           uint64_t seed, uint32_t sample_base, double* d_partials, hipStream_t stream) {
+    if (!d_blob || !d_partials) BF_FAIL("bf_sample_logprob_table: NULL blob or partials");
+    if (S < 1 || block_end <= block_begin) BF_FAIL("bf_sample_logprob_table: empty launch (S=%d)", S);
+    const TableEntry* ent = reinterpret_cast<const TableEntry*>(d_blob);
+    const uint32_t* map = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(d_blob) +
+                                                            bf_align_up((size_t)n_tensors * sizeof(TableEntry), 256));
+    const uint32_t blk = block_end - block_begin;
+    const int ny = pick_ny(blk, S);
+    hipLaunchKernelGGL(bf_sample_table_kernel, dim3(blk, (uint32_t)ny), dim3(kThreads), 0, stream, ent, map,
+                       block_begin, S, ny, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, d_partials);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int bf_launch_reduce_groups(const double* d_partials, const uint32_t* d_rows, int G, int S, double* d_out,
+                            hipStream_t stream) {
+    if (!d_partials || !d_rows || !d_out) BF_FAIL("bf_reduce_logprob: NULL argument");
+    if (G < 1 || S < 1) BF_FAIL("bf_reduce_logprob: bad G=%d S=%d", G, S);
+    hipLaunchKernelGGL(bf_reduce_groups_kernel, dim3((uint32_t)(2 * S), (uint32_t)G), dim3(256), 0, stream,
+                       d_partials, d_rows, S, d_out);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int bf_launch_sample_logprob(const bf_tensor_t* tensors, int n_tensors, int S, uint64_t seed, uint32_t sample_base,
                              double* d_logprob_out, void* d_workspace, size_t workspace_bytes, hipStream_t stream) {
     if (n_tensors < 1 || n_tensors > kMaxSeg) BF_FAIL("bf_sample_logprob: n_tensors must be 1 or 2 (got %d)", n_tensors);
@@ -310,71 +570,39 @@ int bf_launch_sample_logprob(const bf_tensor_t* tensors, int n_tensors, int S, u
     const size_t need = bf_sample_partials_bytes(tensors, n_tensors, S);
     if (!d_workspace || workspace_bytes < need)
         BF_FAIL("bf_sample_logprob: workspace too small (%zu < %zu bytes)", workspace_bytes, need);
-
-    SampleParams p{};
-    p.nseg = n_tensors;
-    p.S = S;
-    p.k0 = (uint32_t)seed;
-    p.k1 = (uint32_t)(seed >> 32);
-    p.sample_base = sample_base;
-    p.partials = reinterpret_cast<double*>(d_workspace);
-    uint32_t blk = 0;
+    uint32_t nblk = 0;
     for (int t = 0; t < n_tensors; ++t) {
         const bf_tensor_t& T = tensors[t];
-        if (!T.d_mu || !T.d_rho) BF_FAIL("bf_sample_logprob: tensor %d has NULL mu/rho", t);
-        if (T.n == 0) BF_FAIL("bf_sample_logprob: tensor %d is empty", t);
-        SegDesc& sg = p.seg[t];
-        sg.mu = T.d_mu;
-        sg.rho = T.d_rho;
-        sg.n = T.n;
-        sg.out = T.d_sample_out;
-        sg.out_dtype = T.out_dtype;
-        sg.stream = T.stream_id;
-        sg.prior_kind = T.prior.kind;
-        sg.mu_p = T.prior.d_mu;
-        sg.rho_p = T.prior.d_rho;
-        uintptr_t align_bits = (uintptr_t)T.d_mu | (uintptr_t)T.d_rho;
-        switch (T.prior.kind) {
-            case BF_PRIOR_MIXTURE: {
-                const double pi = T.prior.pi, s1 = T.prior.sigma1, s2 = T.prior.sigma2;
-                if (!(s1 > 0.0) || !(s2 > 0.0) || !(pi >= 0.0) || !(pi <= 1.0))
-                    BF_FAIL("bf_sample_logprob: bad mixture prior (pi=%g sigma1=%g sigma2=%g)", pi, s1, s2);
-                sg.a1 = (float)(-0.5 / (s1 * s1));
-                sg.a2 = (float)(-0.5 / (s2 * s2));
-                sg.b1 = (float)(log(pi) - log(s1) - 0.91893853320467274178);
-                sg.b2 = (float)(log1p(-pi) - log(s2) - 0.91893853320467274178);
-                break;
-            }
-            case BF_PRIOR_GAUSSIAN:
-                if (!T.prior.d_mu || !T.prior.d_rho) BF_FAIL("bf_sample_logprob: gaussian prior needs d_mu/d_rho");
-                align_bits |= (uintptr_t)T.prior.d_mu | (uintptr_t)T.prior.d_rho;
-                break;
-            case BF_PRIOR_NONE:
-                break;
-            default:
-                BF_FAIL("bf_sample_logprob: unknown prior kind %d", T.prior.kind);
-        }
-        if (T.d_sample_out && (T.out_dtype < BF_DT_F32 || T.out_dtype > BF_DT_F16))
-            BF_FAIL("bf_sample_logprob: bad out_dtype %d", T.out_dtype);
-        sg.vec_in = (align_bits & 15) == 0;
-        sg.vec_out = T.d_sample_out && ((uintptr_t)T.d_sample_out & 15) == 0 && (T.n % 8) == 0;
-        sg.block_begin = blk;
-        blk += blocks_for(T.n);
+        if (int rc = validate_tensor(T, t)) return rc;
+        nblk += blocks_for(T.n);
     }
-    p.nblk = blk;
-    // enough (block, sample-chunk) pairs to fill 256 CUs x 8 blocks, without re-evaluating softplus more than needed
-    int ny = (int)((2048 + blk - 1) / blk);
-    if (ny > S) ny = S;
-    if (ny < 1) ny = 1;
-    int chunk = (S + ny - 1) / ny;
-    if (chunk > kMaxSChunk) chunk = kMaxSChunk;
-    ny = (S + chunk - 1) / chunk;
-    p.s_chunk = chunk;
-
-    hipLaunchKernelGGL(bf_sample_logprob_kernel, dim3(blk, (uint32_t)ny), dim3(kThreads), 0, stream, p);
-    BF_HIP_CHECK(hipGetLastError());
+    double* partials = reinterpret_cast<double*>(d_workspace);
+    // one launch when the two tensors can share a kernel instantiation: same prior kind (and identical mixture
+    // constants), second tensor written as fp32 (or not at all)
+    bool together = n_tensors == 2 && tensors[0].prior.kind == tensors[1].prior.kind &&
+                    (!tensors[1].d_sample_out || tensors[1].out_dtype == BF_DT_F32);
+    if (together && tensors[0].prior.kind == BF_PRIOR_MIXTURE)
+        together = tensors[0].prior.pi == tensors[1].prior.pi && tensors[0].prior.sigma1 == tensors[1].prior.sigma1 &&
+                   tensors[0].prior.sigma2 == tensors[1].prior.sigma2;
+    int rc;
+    if (n_tensors == 1 || together) {
+        rc = launch_group(tensors, 0, n_tensors, 0, S, seed, sample_base, partials, nblk, stream);
+    } else {
+        bf_tensor_t second = tensors[1];
+        rc = launch_group(tensors, 0, 1, 0, S, seed, sample_base, partials, nblk, stream);
+        if (rc) return rc;
+        if (second.d_sample_out && second.out_dtype != BF_DT_F32) {
+            // a lone tensor is "segment 0": written in its own dtype
+            rc = launch_group(&second, 0, 1, blocks_for(tensors[0].n), S, seed, sample_base, partials, nblk, stream);
+        } else {
+            // written as fp32 through the segment-0 path of the F32 instantiation
+            second.out_dtype = BF_DT_F32;
+            rc = launch_group(&second, 0, 1, blocks_for(tensors[0].n), S, seed, sample_base, partials, nblk, stream);
+        }
+    }
+    if (rc) return rc;
     hipLaunchKernelGGL(bf_reduce_partials_kernel, dim3((uint32_t)(2 * S)), dim3(256), 0, stream,
-                       (const double*)p.partials, blk, S, d_logprob_out);
+                       (const double*)partials, nblk, S, d_logprob_out);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -39,6 +39,20 @@ class _LinearFn(torch.autograd.Function):
             "run the forward + ELBO value under torch.no_grad()")
 
 
+class _PlannedLinearFn(torch.autograd.Function):
+    """Forward of a layer whose weights were sampled by the model's cross-layer plan: only the MFMA GEMM is left."""
+
+    @staticmethod
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, w_s, b_s, S, N, K):
+        return ops.planned_linear_forward(x, w_s, b_s, S, N, K)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise NotImplementedError(
+            "bayeformers_amd: backward of the fused Monte-Carlo forward is not implemented yet; "
+            "run the forward + ELBO value under torch.no_grad()")
+
+
 class Linear(Module):
     """Bayesian Linear layer with Gaussian weight/bias posteriors and a prior per parameter.
 
@@ -110,6 +124,13 @@ class Linear(Module):
         x2 = input.reshape(-1, self.in_features)
         mu_b = self.bias.mu if isinstance(self.bias, Gaussian) else None
         rho_b = self.bias.rho if isinstance(self.bias, Gaussian) else None
+        if ctx is not None and ctx.plan is not None:
+            w_s, b_s = ctx.plan.ensure(self, ctx.token, bfr.STATE.seed, base, ctx.lp_buf)
+            y = _PlannedLinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, w_s, b_s, S,
+                                       self.out_features, self.in_features)
+            self._lp_view = slot
+            self._lp_dirty = True
+            return y.view(*input.shape[:-1], self.out_features)
         y = _LinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, self, S, bfr.STATE.seed, base, slot)
         self._lp_view = slot
         self._lp_dirty = True

@@ -12,6 +12,7 @@ Additions for the MI355X path (all optional; with S = 1 the behaviour is the ref
   * all layers of one forward share the same reserved Monte-Carlo sample indices (bayeformers_amd.random).
 """
 import contextlib
+import itertools
 import warnings
 from typing import Any, Iterator, List, Optional
 
@@ -20,6 +21,7 @@ from torch import Tensor
 from torch.nn import Module
 
 from .. import random as bfr
+from ..plan import SamplePlan
 from .layers.linear import Linear
 
 
@@ -30,11 +32,17 @@ def is_module_bayesian(module: Module) -> bool:
     return log_prior and log_variational_posterior
 
 
-class _ForwardContext:
-    """What the Bayesian layers of one Model.forward share: the reserved sample indices and their log-prob slots."""
+_TOKENS = itertools.count(1)
 
-    def __init__(self, sample_base: int, S: int, slots: dict):
+
+class _ForwardContext:
+    """What the Bayesian layers of one Model.forward share: the reserved sample indices, their log-prob slots and
+    (when every layer is plannable) the cross-layer sampling plan."""
+
+    def __init__(self, sample_base: int, S: int, slots: dict, plan=None, lp_buf=None):
         self.sample_base, self.S, self._slots = sample_base, S, slots
+        self.plan, self.lp_buf = plan, lp_buf
+        self.token = next(_TOKENS)
 
     def slot(self, layer) -> Optional[Tensor]:
         return self._slots.get(id(layer))
@@ -55,6 +63,8 @@ class Model(Module):
         self._fused: Optional[List[Linear]] = None
         self._lp_buf: Optional[Tensor] = None
         self._last_base = None
+        self._plan: Optional[SamplePlan] = None
+        self.cross_layer_sampling = True  # one sampling launch per ~96 MB group of layers instead of one per layer
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, *args, **kwargs) -> Any:
@@ -75,11 +85,18 @@ class Model(Module):
             if buf is None or buf.shape[0] != len(layers) or buf.shape[1] != S or buf.device != dev:
                 buf = self._lp_buf = torch.zeros((len(layers), S, 2), dtype=torch.float64, device=dev)
             slots = {id(l): buf[i] for i, l in enumerate(layers)}
+        plan = None
+        if layers and self.cross_layer_sampling and SamplePlan.plannable(layers):
+            cdt = bfr.get_compute_dtype()
+            key = SamplePlan.make_key(layers, S, cdt)
+            if self._plan is None or self._plan.key != key:
+                self._plan = SamplePlan(layers, S, cdt, layers[0].weight.mu.device)
+            plan = self._plan
         rank, world = self._mc_shard
         # every rank reserves the GLOBAL S*world indices and runs its own contiguous slice of them
         base = bfr.reserve_samples(S * world) + rank * S
         self._last_base = base
-        bfr.STATE.ctx = _ForwardContext(base, S, slots)
+        bfr.STATE.ctx = _ForwardContext(base, S, slots, plan, self._lp_buf)
         try:
             return super(Model, self).__call__(*args, **kwargs)
         finally:
@@ -107,7 +124,7 @@ class Model(Module):
 
     def refresh(self) -> None:
         """Re-scan the children after the module tree was edited."""
-        self._fused, self._lp_buf = None, None
+        self._fused, self._lp_buf, self._plan = None, None, None
 
     # ------------------------------------------------------------------------------------------ log-probs
     @property

@@ -191,3 +191,20 @@ def _linear_forward_generic(layer, x, S, M, N, K, seed, sample_base, lp_out, cdt
     w = outs[0] if cdt == torch.float32 else outs[0].to(cdt)
     y = gemm_nt(x, w, outs[1] if has_bias else None, S, M, N, K, M * K, x.dtype)
     return y.view(S * M, N)
+
+
+def planned_linear_forward(x: Tensor, w_s: Tensor, b_s: Optional[Tensor], S: int, N: int, K: int) -> Tensor:
+    """y[s] = x[s] W_s^T + b_s with W_s/b_s already sampled by the model's cross-layer plan (plan.SamplePlan)."""
+    _require_device(x, "input")
+    if x.dtype not in _TORCH2BF:
+        raise _C.BayeFormersAMDError(f"unsupported input dtype {x.dtype}")
+    if x.dtype != torch.float32 and x.dtype != w_s.dtype:
+        raise _C.BayeFormersAMDError(
+            f"input dtype {x.dtype} does not match compute dtype {w_s.dtype} (fp32 inputs always do)")
+    if not x.is_contiguous():
+        x = x.contiguous()
+    rows = x.numel() // K
+    if rows % S:
+        raise _C.BayeFormersAMDError(f"input rows ({rows}) are not a multiple of the sample count S={S}")
+    M = rows // S
+    return gemm_nt(x, w_s, b_s, S, M, N, K, M * K, x.dtype).view(S * M, N)

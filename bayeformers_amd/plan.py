@@ -1,0 +1,163 @@
+"""Cross-layer sampling plan of a bnn.Model.
+
+The reference samples every layer's weights inside that layer's forward
+(/root/reference/bayeformers/nn/layers/linear.py:97).  Epsilon here is a pure function of
+(seed, sample, layer, element), so W_s does not depend on the activations and the sampling + log-prob work of
+many layers can be done by ONE launch (bf_sample_logprob_table) ahead of the GEMMs that consume it:
+
+  * the model's bnn.Linear layers are cut, in registration order, into groups whose sampled weights
+    (S x n x 2 B) total about GROUP_BYTES; a group is sampled when its first layer is about to run;
+  * groups alternate between two arenas, so the weights a GEMM reads were written a few hundred microseconds
+    earlier and are still in the 256 MiB Infinity Cache, and the footprint is 2 groups, not the whole model;
+  * each block leaves one [S][2] fp64 row of partial log-prob sums; one bf_reduce_logprob launch per group turns
+    them into the per-layer {log_prior, log_q}[S] the Model sums — instead of 2 launches per layer.
+
+If a layer runs while its arena holds another group (unusual execution order) the group is simply sampled again:
+same counters, same values.
+"""
+import ctypes
+from typing import List, Optional
+
+import torch
+
+from . import _C
+from . import ops
+from . import random as bfr
+
+GROUP_BYTES = 96 << 20
+
+
+class SamplePlan:
+    def __init__(self, layers, S: int, cdt: torch.dtype, device: torch.device):
+        from .nn.parameters.base import NoneParameter
+
+        self.S, self.cdt, self.device = S, cdt, device
+        self.layers = layers
+        self.key = self.make_key(layers, S, cdt)
+        lib = _C.lib()
+        esz = 4 if cdt == torch.float32 else 2
+
+        # groups of consecutive layers
+        self.group_of, groups, cur, cur_bytes = {}, [], [], 0
+        for l in layers:
+            b = S * l.weight.mu.numel() * esz
+            if cur and cur_bytes + b > GROUP_BYTES:
+                groups.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(l)
+            cur_bytes += b
+        if cur:
+            groups.append(cur)
+        self.groups = groups
+
+        # arena layout: per group, [W_s of each layer][b_s of each layer], 256-byte aligned slices
+        def align(x):
+            return (x + 255) // 256 * 256
+
+        self.slices = {}
+        group_bytes = []
+        for gi, g in enumerate(groups):
+            off = 0
+            for l in g:
+                wb = align(S * l.weight.mu.numel() * esz)
+                has_bias = not isinstance(l.bias, NoneParameter)
+                bb = align(S * l.out_features * 4) if has_bias else 0
+                self.slices[id(l)] = (gi, off, off + wb if has_bias else None)
+                self.group_of[id(l)] = gi
+                off += wb + bb
+            group_bytes.append(off)
+        arena_bytes = max(group_bytes)
+        self.arenas = [torch.empty(arena_bytes, dtype=torch.uint8, device=device) for _ in range(min(2, len(groups)))]
+        self.arena_owner = [None] * len(self.arenas)
+
+        # table: entries in layer order (weight, then bias)
+        n_entries = sum(1 + (self.slices[id(l)][2] is not None) for l in layers)
+        arr = (_C.bf_tensor_t * n_entries)()
+        self.views = {}
+        first_entry_of_layer = []
+        e = 0
+        for li, l in enumerate(layers):
+            gi, woff, boff = self.slices[id(l)]
+            arena = self.arenas[gi % len(self.arenas)]
+            first_entry_of_layer.append(e)
+            N, K = l.out_features, l.in_features
+            if not ops.fill_tensor(arr[e], l.weight, l.weight_prior, 2 * l.layer_id):
+                raise _C.BayeFormersAMDError("SamplePlan: user-defined priors are not plannable")
+            wv = arena[woff:woff + S * N * K * esz].view(cdt).view(S, N, K)
+            arr[e].d_sample_out, arr[e].out_dtype = wv.data_ptr(), ops._TORCH2BF[cdt]
+            e += 1
+            bv = None
+            if boff is not None:
+                if not ops.fill_tensor(arr[e], l.bias, l.bias_prior, 2 * l.layer_id + 1):
+                    raise _C.BayeFormersAMDError("SamplePlan: user-defined priors are not plannable")
+                bv = arena[boff:boff + S * N * 4].view(torch.float32).view(S, N)
+                arr[e].d_sample_out, arr[e].out_dtype = bv.data_ptr(), _C.BF_DT_F32
+                e += 1
+            self.views[id(l)] = (wv, bv)
+        total = ctypes.c_uint32()
+        nbytes = lib.bf_sample_table_bytes(arr, n_entries, ctypes.byref(total))
+        blob = torch.empty(nbytes, dtype=torch.uint8, pin_memory=False)
+        begin = torch.empty(n_entries + 1, dtype=torch.int32)
+        _C.check(lib.bf_sample_table_build(arr, n_entries, blob.data_ptr(), nbytes, begin.data_ptr()),
+                 "bf_sample_table_build")
+        self.n_entries, self.total_blocks = n_entries, total.value
+        self.blob = blob.to(device)
+        begin_l = begin.tolist()
+        layer_rows = [begin_l[fe] for fe in first_entry_of_layer] + [begin_l[-1]]
+        self.layer_rows = torch.tensor(layer_rows, dtype=torch.int32, device=device)
+        self.layer_rows_host = layer_rows
+        self.partials = torch.empty((self.total_blocks, S, 2), dtype=torch.float64, device=device)
+        # per group: (first layer index, number of layers, first block, end block)
+        self.group_span = []
+        li = 0
+        for g in groups:
+            self.group_span.append((li, len(g), layer_rows[li], layer_rows[li + len(g)]))
+            li += len(g)
+        self.scalars = sum(l.weight.mu.numel() + (l.out_features if self.slices[id(l)][2] is not None else 0) for l in layers)
+
+    @staticmethod
+    def make_key(layers, S, cdt):
+        from .nn.parameters.gaussian import Gaussian
+
+        key = [S, cdt]
+        for l in layers:
+            key.append(l.layer_id)
+            for g in (l.weight, l.bias, l.weight_prior, l.bias_prior):
+                if isinstance(g, Gaussian):
+                    key.append(g.mu.data_ptr())
+                    key.append(g.rho.data_ptr())
+                else:
+                    key.append(id(g))
+                    c = getattr(g, "constants", None)
+                    if c is not None:
+                        key.append(c())
+        return tuple(key)
+
+    @staticmethod
+    def plannable(layers) -> bool:
+        from .nn.parameters.base import NoneParameter
+        from .nn.parameters.gaussian import Gaussian, ScaledGaussianMixture
+
+        if not layers:
+            return False
+        ok = (Gaussian, ScaledGaussianMixture, NoneParameter)
+        dev = layers[0].weight.mu.device
+        return dev.type == "cuda" and all(
+            isinstance(l.weight_prior, ok) and isinstance(l.bias_prior, ok) and l.weight.mu.device == dev and
+            l.compute_dtype is None for l in layers)
+
+    def ensure(self, layer, token, seed: int, sample_base: int, lp_buf: torch.Tensor):
+        """Make sure `layer`'s group has been sampled for the forward identified by `token`; returns (W_s, b_s)."""
+        gi = self.group_of[id(layer)]
+        a = gi % len(self.arenas)
+        if self.arena_owner[a] != (gi, token):
+            l0, nl, b0, b1 = self.group_span[gi]
+            lib = _C.lib()
+            stream = ops._stream_ptr()
+            _C.check(lib.bf_sample_logprob_table(self.blob.data_ptr(), self.n_entries, b0, b1, self.S, seed,
+                                                 sample_base & 0xFFFFFFFF, self.partials.data_ptr(), stream),
+                     "bf_sample_logprob_table")
+            _C.check(lib.bf_reduce_logprob(self.partials.data_ptr(), self.layer_rows.data_ptr() + 4 * l0, nl, self.S,
+                                           lp_buf.data_ptr() + l0 * self.S * 2 * 8, stream), "bf_reduce_logprob")
+            self.arena_owner[a] = (gi, token)
+        return self.views[id(layer)]

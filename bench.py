@@ -91,7 +91,7 @@ def make_bert(device, S, dtype):
 
     cfgd = {"workload": "to_bayesian(BERT-base seq-cls, delta=0.05, freeze=True) fwd+ELBO", "samples_per_gpu": S,
             "batch": B, "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "bayesian_scalars": 85609730}
-    return step, cpu_baseline, cfgd
+    return step, cpu_baseline, cfgd, bmodel
 
 
 def make_linear(device, S, dtype, M):
@@ -132,7 +132,7 @@ def make_linear(device, S, dtype, M):
 
     cfgd = {"workload": f"bnn.Linear(768,768) default init + mixture prior, x=[{M},768], fwd+ELBO",
             "samples_per_gpu": S, "batch": M}
-    return step, cpu_baseline, cfgd
+    return step, cpu_baseline, cfgd, model
 
 
 def make_mlp(device, S, dtype):
@@ -168,7 +168,7 @@ def make_mlp(device, S, dtype):
                 "sample": f"{n} steps of S={S} serial samples, MLP 784-512-512-10 B=128, torch-CPU fp32, {dt:.1f}s"}
 
     return step, cpu_baseline, {"workload": "to_bayesian(MLP 784-512-512-10, delta=0.05) fwd+ELBO", "samples_per_gpu": S,
-                                "batch": 128}
+                                "batch": 128}, bmodel
 
 
 def main():
@@ -192,13 +192,13 @@ def main():
     bf.set_compute_dtype(dtype)
     bf.manual_seed(0x5EED)
     if args.workload == "bert_base":
-        step, cpu_baseline, cfgd = make_bert(device, S, dtype)
+        step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype)
     elif args.workload == "linear768":
-        step, cpu_baseline, cfgd = make_linear(device, S, dtype, 4096)
+        step, cpu_baseline, cfgd, bmodel = make_linear(device, S, dtype, 4096)
     elif args.workload == "linear768_m32":
-        step, cpu_baseline, cfgd = make_linear(device, S, dtype, 32)
+        step, cpu_baseline, cfgd, bmodel = make_linear(device, S, dtype, 32)
     else:
-        step, cpu_baseline, cfgd = make_mlp(device, S, dtype)
+        step, cpu_baseline, cfgd, bmodel = make_mlp(device, S, dtype)
 
     def barrier():
         if world > 1:
@@ -239,6 +239,13 @@ def main():
     if rank == 0:
         gn, gms, gflop = prof["gemm"]
         sn, sms, sbytes = prof["sample"]
+        plan = getattr(bmodel, "_plan", None)
+        if sbytes == 0 and plan is not None:
+            # cross-layer launches: algorithmic bytes = mu,rho (+ Gaussian prior mu,rho) read once, S samples written
+            from bayeformers_amd.nn import Gaussian
+            per_read = 16 if isinstance(plan.layers[0].weight_prior, Gaussian) else 8
+            esz = 4 if dtype == "fp32" else 2
+            sbytes = float(plan.scalars) * (per_read + S * esz) * prof_steps
         tflops = gflop / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (sampled-weight GEMM, all Bayesian linears)",
                     "achieved": round(tflops, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -84,6 +84,23 @@ size_t bf_sample_logprob_workspace_bytes(const bf_tensor_t* tensors, int n_tenso
 int bf_sample_logprob(const bf_tensor_t* tensors, int n_tensors, int S, uint64_t seed, uint32_t sample_base,
                       double* d_logprob_out, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Cross-layer batching of the same kernel: ONE launch over the blocks of many tensors (e.g. the six linears of a
+ * transformer layer, or a whole model), described by a device-resident table.
+ *   bf_sample_table_bytes  size of the table blob for `tensors` (and the total number of 1024-scalar blocks);
+ *   bf_sample_table_build  fills a HOST blob (the caller uploads it to the device once; it embeds the tensors'
+ *                          mu/rho/prior/d_sample_out pointers, so rebuild when any of them moves) and
+ *                          h_block_begin[n_tensors+1], the first block of each tensor;
+ *   bf_sample_logprob_table  samples + log-probs of blocks [block_begin, block_end) (whole tensors) and writes one
+ *                          [S][2] row of fp64 partial sums per block into d_partials[block] (total_blocks rows);
+ *   bf_reduce_logprob      d_out[g][s][{log_prior, log_q}] = fixed-order sum of partial rows [d_rows[g], d_rows[g+1]). */
+size_t bf_sample_table_bytes(const bf_tensor_t* tensors, int n_tensors, uint32_t* total_blocks);
+int bf_sample_table_build(const bf_tensor_t* tensors, int n_tensors, void* h_blob, size_t blob_bytes,
+                          uint32_t* h_block_begin);
+int bf_sample_logprob_table(const void* d_blob, int n_tensors, uint32_t block_begin, uint32_t block_end, int S,
+                            uint64_t seed, uint32_t sample_base, double* d_partials, void* stream);
+int bf_reduce_logprob(const double* d_partials, const uint32_t* d_rows, int n_groups, int S, double* d_out,
+                      void* stream);
+
 /* Batched NT GEMM on the matrix cores:  y[s] = x[s] * w[s]^T + bias[s]   (F.linear, layers/linear.py:104)
  *   x: [S or 1][M][K] of x_dtype, sample stride x_sample_stride elements (0 = one x shared by all samples)
  *   w: [S][N][K] of w_dtype (what bf_sample_logprob wrote);  bias: [S][N] fp32 or NULL
@@ -110,7 +127,8 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
  * this library is bracketed by two events; bf_profile_read() synchronises them and returns, per kind, the number
  * of launches, the summed kernel time and the summed ALGORITHMIC work:
  *   BF_PROF_GEMM   work = 2*S*M*N*K flop;
- *   BF_PROF_SAMPLE work = bytes: (8 | 16 with a Gaussian prior) per scalar read + S * sizeof(out) per scalar written. */
+ *   BF_PROF_SAMPLE work = bytes: (8 | 16 with a Gaussian prior) per scalar read + S * sizeof(out) per scalar written
+ *                  (0 for bf_sample_logprob_table launches: the caller knows the table's totals). */
 enum { BF_PROF_SAMPLE = 0, BF_PROF_GEMM = 1 };
 int bf_profile_enable(int on);
 int bf_profile_reset(void);
