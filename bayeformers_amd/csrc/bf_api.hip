@@ -254,4 +254,95 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
                              (hipStream_t)stream);
 }
 
+// workspace layout of bf_linear_bwd
+struct BwdLayout {
+    size_t w, wt, dyt, xt, dw, db, lp, part, total;
+};
+static BwdLayout bwd_layout(int S, int M, int N, int K, int has_bias, int dtype) {
+    const size_t es = bf_dtype_size(dtype);
+    BwdLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += bf_align_up(bytes, 256);
+        return o;
+    };
+    L.w = take((size_t)S * N * K * es);
+    L.wt = take((size_t)S * N * K * es);
+    L.dyt = take((size_t)S * N * M * es);
+    L.xt = take((size_t)S * K * M * es);
+    L.dw = take((size_t)S * N * K * sizeof(float));
+    L.db = take(has_bias ? (size_t)S * N * sizeof(float) : 0);
+    L.lp = take((size_t)S * 2 * sizeof(double));
+    bf_tensor_t t;
+    memset(&t, 0, sizeof(t));
+    t.n = (uint64_t)N * K;
+    L.part = take(bf_sample_partials_bytes(&t, 1, S));
+    L.total = off;
+    return L;
+}
+
+size_t bf_linear_bwd_workspace_bytes(int S, int M, int N, int K, int has_bias, int dtype) {
+    if (S < 1 || M < 1 || N < 1 || K < 1) return 0;
+    return bwd_layout(S, M, N, K, has_bias, dtype).total;
+}
+
+int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, int dtype, const bf_tensor_t* weight,
+                  const bf_tensor_t* bias, void* d_dx, float* d_dmu_w, float* d_drho_w, float* d_dmu_b,
+                  float* d_drho_b, int S, int M, int N, int K, uint64_t seed, uint32_t sample_base, void* d_workspace,
+                  size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d_x || !d_dy || !weight || !d_drho_w) BF_FAIL("bf_linear_bwd: NULL argument");
+    if (S < 1 || M < 1 || N < 1 || K < 1) BF_FAIL("bf_linear_bwd: bad shape S=%d M=%d N=%d K=%d", S, M, N, K);
+    if (weight->n != (uint64_t)N * (uint64_t)K) BF_FAIL("bf_linear_bwd: weight.n != N*K");
+    if (bias && (bias->n != (uint64_t)N || !d_drho_b)) BF_FAIL("bf_linear_bwd: bad bias arguments");
+    if (dtype < BF_DT_F32 || dtype > BF_DT_F16) BF_FAIL("bf_linear_bwd: bad dtype %d", dtype);
+    if (x_sample_stride != 0 && x_sample_stride != (int64_t)M * K) BF_FAIL("bf_linear_bwd: x_sample_stride must be 0 or M*K");
+    const BwdLayout L = bwd_layout(S, M, N, K, bias != nullptr, dtype);
+    if (!d_workspace || workspace_bytes < L.total)
+        BF_FAIL("bf_linear_bwd: workspace too small (%zu < %zu bytes)", workspace_bytes, L.total);
+    char* ws = reinterpret_cast<char*>(d_workspace);
+    const int es = (int)bf_dtype_size(dtype);
+
+    // 1. W_s again (same counters as the forward); no prior term needed
+    bf_tensor_t t = *weight;
+    t.prior.kind = BF_PRIOR_NONE;
+    t.d_sample_out = ws + L.w;
+    t.out_dtype = dtype;
+    int rc = bf_launch_sample_logprob(&t, 1, S, seed, sample_base, reinterpret_cast<double*>(ws + L.lp), ws + L.part,
+                                      L.total - L.part, stream);
+    if (rc) return rc;
+    if (d_dx) {
+        // 2. dx[s] = dy[s] [M][N] x (W_s^T [K][N])^T : the NT kernel wants the reduction axis (n) contiguous in both
+        if ((rc = bf_launch_transpose(ws + L.w, ws + L.wt, es, S, N, K, stream))) return rc;
+        if ((rc = bf_launch_gemm_nt(d_dy, dtype, (int64_t)M * N, ws + L.wt, dtype, nullptr, d_dx, dtype, S, M, K, N, stream)))
+            return rc;
+    }
+    // 3. dW_s = dy[s]^T x[s] = (dy^T [N][M]) x (x^T [K][M])^T, fp32 out
+    if ((rc = bf_launch_transpose(d_dy, ws + L.dyt, es, S, M, N, stream))) return rc;
+    const int xs_batch = x_sample_stride == 0 ? 1 : S;
+    if ((rc = bf_launch_transpose(d_x, ws + L.xt, es, xs_batch, M, K, stream))) return rc;
+    // operands: "x" = dy^T [S][N][M] (stride N*M), "w" = x^T [S][K][M]; a shared x is broadcast by passing it S times
+    if (x_sample_stride == 0) {
+        for (int s = 0; s < S; ++s)
+            if ((rc = bf_launch_gemm_nt(ws + L.dyt + (size_t)s * N * M * es, dtype, 0, ws + L.xt, dtype, nullptr,
+                                        ws + L.dw + (size_t)s * N * K * sizeof(float), BF_DT_F32, 1, N, K, M, stream)))
+                return rc;
+    } else if ((rc = bf_launch_gemm_nt(ws + L.dyt, dtype, (int64_t)N * M, ws + L.xt, dtype, nullptr, ws + L.dw, BF_DT_F32,
+                                       S, N, K, M, stream))) {
+        return rc;
+    }
+    // 4. reduce over samples with eps regenerated
+    if ((rc = bf_launch_param_grad(reinterpret_cast<const float*>(ws + L.dw), weight->d_rho, weight->n, S, seed,
+                                   sample_base, weight->stream_id, d_dmu_w, d_drho_w, stream)))
+        return rc;
+    if (bias) {
+        if ((rc = bf_launch_colsum(d_dy, dtype, reinterpret_cast<float*>(ws + L.db), S, M, N, stream))) return rc;
+        if ((rc = bf_launch_param_grad(reinterpret_cast<const float*>(ws + L.db), bias->d_rho, bias->n, S, seed,
+                                       sample_base, bias->stream_id, d_dmu_b, d_drho_b, stream)))
+            return rc;
+    }
+    return 0;
+}
+
 }  // extern "C"

@@ -47,3 +47,7 @@ int bf_launch_reduce_groups(const double* d_partials, const uint32_t* d_rows, in
                             hipStream_t stream);
 int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
                       const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, hipStream_t stream);
+int bf_launch_transpose(const void* d_in, void* d_out, int elem_size, int batch, int rows, int cols, hipStream_t stream);
+int bf_launch_colsum(const void* d_dy, int dtype, float* d_out, int S, int M, int N, hipStream_t stream);
+int bf_launch_param_grad(const float* d_dw, const float* d_rho, uint64_t n, int S, uint64_t seed, uint32_t sample_base,
+                         uint32_t stream_id, float* d_dmu, float* d_drho, hipStream_t stream);

@@ -121,6 +121,10 @@ __device__ __forceinline__ void tile_coords(unsigned lt, int tiles_m, int tiles_
 // rows padded by 16 B (2-way bank aliasing only), then every wave streams 32 rows back with ds_read_b128 and stores
 // them with dwordx4 (512 contiguous bytes per row for bf16).  fp32 outputs take two passes of 128 rows.
 constexpr int EPI_PAD = 16;
+#ifndef BF_NT_STORES
+#define BF_NT_STORES 1
+#endif
+constexpr bool NT_STORES = BF_NT_STORES;
 template <typename YT>
 __device__ __forceinline__ void epilogue_via_lds(char* smem, const f32x4_t (&acc)[4][8], const float* bias, YT* y,
                                                  int m0, int n0, int M, int N, int wm, int wn, int wid, int lane) {
@@ -477,7 +481,9 @@ __device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&ac
                 const f32x4_t v = *reinterpret_cast<const f32x4_t*>(region + rd_off + it * ROWS_PER_INST * ROW);
                 YT* o = y + (unsigned)(m * N + n);
                 if (n_full) {
-                    *reinterpret_cast<f32x4_t*>(o) = v;
+                    // streaming store: y is not re-read by this kernel, keep it from evicting operand panels in L2
+                    if (NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(o));
+                    else *reinterpret_cast<f32x4_t*>(o) = v;
                 } else {
                     const YT* e = reinterpret_cast<const YT*>(&v);
                     for (int j = 0; j < EPC; ++j)

@@ -24,33 +24,46 @@ from ..parameters.initializations import DEFAULT_UNIFORM, Initialization
 _LOGPROB_NAMES = ("log_prior", "log_variational_posterior")
 
 
+def _backward(ctx, grad):
+    """Shared backward of the per-layer and the planned forward: one bf_linear_bwd call."""
+    (x,) = ctx.saved_tensors
+    layer, S, seed, base, cdt = ctx.layer, ctx.S, ctx.seed, ctx.base, ctx.cdt
+    need_x, need_mu_w, _, need_mu_b, _ = ctx.needs_input_grad[:5]
+    return ops.linear_backward(layer, x, grad, S, seed, base, cdt, need_x, need_mu_w, need_mu_b)
+
+
 class _LinearFn(torch.autograd.Function):
-    """Autograd node of the fused forward.  Backward (dL/dmu = dL/dW, dL/drho = dL/dW * eps * sigmoid(rho) with eps
-    regenerated from the Philox counter) is the next milestone."""
+    """Autograd node of the fused forward (bf_linear_fwd).  Backward = bf_linear_bwd: the reference's graph, i.e.
+    gradients through F.linear(x, mu + eps*softplus(rho)) with eps regenerated from the Philox counter and the
+    log-prob scalars detached (they carry no gradient in the reference, layers/linear.py:99-102)."""
 
     @staticmethod
     def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, layer, S, seed, base, lp_out):
+        ctx.layer, ctx.S, ctx.seed, ctx.base = layer, S, seed, base
+        ctx.cdt = layer.compute_dtype or bfr.get_compute_dtype()
+        ctx.save_for_backward(x)
         return ops.linear_forward(layer, x, S, seed, base, lp_out)
 
     @staticmethod
     def backward(ctx, grad):
-        raise NotImplementedError(
-            "bayeformers_amd: backward of the fused Monte-Carlo forward is not implemented yet; "
-            "run the forward + ELBO value under torch.no_grad()")
+        dx, dmu_w, drho_w, dmu_b, drho_b = _backward(ctx, grad)
+        return dx, dmu_w, drho_w, dmu_b, drho_b, None, None, None, None, None
 
 
 class _PlannedLinearFn(torch.autograd.Function):
     """Forward of a layer whose weights were sampled by the model's cross-layer plan: only the MFMA GEMM is left."""
 
     @staticmethod
-    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, w_s, b_s, S, N, K):
-        return ops.planned_linear_forward(x, w_s, b_s, S, N, K)
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, w_s, b_s, layer, S, seed, base):
+        ctx.layer, ctx.S, ctx.seed, ctx.base = layer, S, seed, base
+        ctx.cdt = w_s.dtype
+        ctx.save_for_backward(x)
+        return ops.planned_linear_forward(x, w_s, b_s, S, layer.out_features, layer.in_features)
 
     @staticmethod
     def backward(ctx, grad):
-        raise NotImplementedError(
-            "bayeformers_amd: backward of the fused Monte-Carlo forward is not implemented yet; "
-            "run the forward + ELBO value under torch.no_grad()")
+        dx, dmu_w, drho_w, dmu_b, drho_b = _backward(ctx, grad)
+        return dx, dmu_w, drho_w, dmu_b, drho_b, None, None, None, None, None, None
 
 
 class Linear(Module):
@@ -126,8 +139,8 @@ class Linear(Module):
         rho_b = self.bias.rho if isinstance(self.bias, Gaussian) else None
         if ctx is not None and ctx.plan is not None:
             w_s, b_s = ctx.plan.ensure(self, ctx.token, bfr.STATE.seed, base, ctx.lp_buf)
-            y = _PlannedLinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, w_s, b_s, S,
-                                       self.out_features, self.in_features)
+            y = _PlannedLinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, w_s, b_s, self, S,
+                                       bfr.STATE.seed, base)
             self._lp_view = slot
             self._lp_dirty = True
             return y.view(*input.shape[:-1], self.out_features)

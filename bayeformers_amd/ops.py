@@ -208,3 +208,38 @@ def planned_linear_forward(x: Tensor, w_s: Tensor, b_s: Optional[Tensor], S: int
         raise _C.BayeFormersAMDError(f"input rows ({rows}) are not a multiple of the sample count S={S}")
     M = rows // S
     return gemm_nt(x, w_s, b_s, S, M, N, K, M * K, x.dtype).view(S * M, N)
+
+
+def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_base: int, cdt: torch.dtype,
+                    need_x: bool, need_mu_w: bool, need_mu_b: bool):
+    """Gradients of the sampled-weight linear layer (bf_linear_bwd).  Returns (dx, dmu_w, drho_w, dmu_b, drho_b);
+    entries that are not needed are None.  x: [S*M, K] as saved by the forward; grad_y: [S*M, N]."""
+    from .nn.parameters.base import NoneParameter
+
+    K, N = layer.in_features, layer.out_features
+    M = x.shape[0] // S
+    has_bias = not isinstance(layer.bias, NoneParameter)
+    xg = x if x.dtype == cdt else x.to(cdt)
+    dy = grad_y.reshape(S * M, N)
+    dy = (dy if dy.dtype == cdt else dy.to(cdt)).contiguous()
+    dev = x.device
+    w, b = _C.bf_tensor_t(), _C.bf_tensor_t()
+    fill_tensor(w, layer.weight, NoneParameter(), 2 * layer.layer_id)
+    if has_bias:
+        fill_tensor(b, layer.bias, NoneParameter(), 2 * layer.layer_id + 1)
+    dx = torch.empty((S * M, K), dtype=cdt, device=dev) if need_x else None
+    dmu_w = torch.empty((N, K), dtype=torch.float32, device=dev) if need_mu_w else None
+    drho_w = torch.empty((N, K), dtype=torch.float32, device=dev)
+    dmu_b = torch.empty((N,), dtype=torch.float32, device=dev) if (has_bias and need_mu_b) else None
+    drho_b = torch.empty((N,), dtype=torch.float32, device=dev) if has_bias else None
+    lib = _C.lib()
+    need = lib.bf_linear_bwd_workspace_bytes(S, M, N, K, int(has_bias), _TORCH2BF[cdt])
+    ws = workspace(dev, need)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    _C.check(lib.bf_linear_bwd(xg.data_ptr(), M * K, dy.data_ptr(), _TORCH2BF[cdt], ctypes.byref(w),
+                               ctypes.byref(b) if has_bias else None, ptr(dx), ptr(dmu_w), ptr(drho_w), ptr(dmu_b),
+                               ptr(drho_b), S, M, N, K, seed, sample_base & 0xFFFFFFFF, ws.data_ptr(), ws.numel(),
+                               _stream_ptr()), "bf_linear_bwd")
+    if dx is not None and dx.dtype != x.dtype:
+        dx = dx.to(x.dtype)
+    return dx, dmu_w, drho_w, dmu_b, drho_b

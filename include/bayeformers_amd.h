@@ -122,6 +122,19 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
                   uint64_t seed, uint32_t sample_base, double* d_logprob_out, void* d_workspace,
                   size_t workspace_bytes, void* stream);
 
+/* Backward of bf_linear_fwd, reproducing the reference's autograd graph: gradients flow through
+ * F.linear(input, mu + eps*softplus(rho), ...) (layers/linear.py:97,104, gaussian.py:100-101) with eps a constant and
+ * the two log-prob scalars detached (linear.py:99-102: the KL terms carry no gradient in the reference).
+ *   dx[s] = dy[s] W_s;  dW_s = dy[s]^T x[s];  dmu = sum_s dW_s;  drho = (sum_s dW_s*eps_s) * softplus'(rho); same for b.
+ * eps is regenerated from (seed, sample_base + s, stream) — the same values the forward used.  x, dy and dx share
+ * one dtype, which is also the MFMA operand type (BF16 | F16 | F32).  Any of d_dx, d_dmu_w, d_dmu_b may be NULL
+ * (not needed); d_drho_b/d_dmu_b are ignored when bias is NULL.  Gradients are written, not accumulated. */
+size_t bf_linear_bwd_workspace_bytes(int S, int M, int N, int K, int has_bias, int dtype);
+int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, int dtype, const bf_tensor_t* weight,
+                  const bf_tensor_t* bias, void* d_dx, float* d_dmu_w, float* d_drho_w, float* d_dmu_b,
+                  float* d_drho_b, int S, int M, int N, int K, uint64_t seed, uint32_t sample_base, void* d_workspace,
+                  size_t workspace_bytes, void* stream);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * While enabled, every sampling launch (kind BF_PROF_SAMPLE) and every GEMM launch (BF_PROF_GEMM) made through
  * this library is bracketed by two events; bf_profile_read() synchronises them and returns, per kind, the number

@@ -208,6 +208,49 @@ def bert_case(tiny):
             "log_prior": t2n(lp), "lvp": t2n(lq), "nll": float(nll)}
 
 
+def grad_cases():
+    """Gradients of the reference's autograd graph (likelihood path only: its log-probs are detached)."""
+    out = {}
+
+    def run(name, layer, x, S, base):
+        clock = {"seed": SEED, "sample": base}
+        inject(layer, clock)
+        x = x.clone().requires_grad_(True)
+        g = torch.randn(S, x.shape[0], layer.out_features)
+        for p_ in layer.parameters():
+            p_.grad = None
+        loss = 0.0
+        for s in range(S):
+            clock["sample"] = base + s
+            loss = loss + (layer(x) * g[s]).sum()
+        loss.backward()
+        d = {"x": t2n(x), "g": t2n(g), "S": S, "base": base, "w_mu": t2n(layer.weight.mu), "w_rho": t2n(layer.weight.rho),
+             "dx": t2n(x.grad), "dw_rho": t2n(layer.weight.rho.grad)}
+        if layer.weight.mu.grad is not None:
+            d["dw_mu"] = t2n(layer.weight.mu.grad)
+        if isinstance(layer.bias, rbnn.Gaussian):
+            d["b_mu"], d["b_rho"] = t2n(layer.bias.mu), t2n(layer.bias.rho)
+            d["db_rho"] = t2n(layer.bias.rho.grad)
+            if layer.bias.mu.grad is not None:
+                d["db_mu"] = t2n(layer.bias.mu.grad)
+        for k, v in d.items():
+            out[f"{name}/{k}"] = v
+
+    torch.manual_seed(11)
+    run("mix_bias", rbnn.Linear(40, 24), torch.randn(5, 40), 3, 0)
+    torch.manual_seed(12)
+    run("nobias_oddK", rbnn.Linear(33, 7, bias=False), torch.randn(4, 33), 2, 7)
+    torch.manual_seed(13)
+    freq = torch.nn.Linear(64, 48)
+    run("moped_frozen", rbnn.Linear.from_frequentist(freq, delta=0.05, freeze=True), torch.randn(6, 64), 3, 100)
+    torch.manual_seed(14)
+    big = rbnn.Linear(128, 192)
+    with torch.no_grad():
+        big.weight.rho[0, :8] = 25.0  # softplus threshold branch of the backward
+    run("big", big, torch.randn(96, 128), 2, 9)
+    return out
+
+
 def conversion_case():
     """to_bayesian / from_frequentist numerics and state-dict layout (bayeformers/__init__.py:19-63)."""
     torch.manual_seed(7)
@@ -230,11 +273,16 @@ def conversion_case():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-bert", action="store_true")
+    ap.add_argument("--only-grads", action="store_true")
     args = ap.parse_args()
     torch.set_num_threads(8)
+    if args.only_grads:
+        np.savez_compressed(os.path.join(HERE, "linear_grads.npz"), **grad_cases())
+        return
     print("eps KAT"); np.savez_compressed(os.path.join(HERE, "eps_kat.npz"), seed=SEED,
                                          z_s0_str0=bo.normals(64, SEED, 0, 0), z_s9_str5_off3=bo.normals(64, SEED, 9, 5, 3))
     print("linear cases"); np.savez_compressed(os.path.join(HERE, "linear_cases.npz"), **linear_cases())
+    print("grad cases"); np.savez_compressed(os.path.join(HERE, "linear_grads.npz"), **grad_cases())
     print("conversion"); np.savez_compressed(os.path.join(HERE, "conversion.npz"), **conversion_case())
     print("mlp C1"); np.savez_compressed(os.path.join(HERE, "mlp_c1.npz"), **mlp_case())
     print("bert tiny"); np.savez_compressed(os.path.join(HERE, "bert_tiny.npz"), **bert_case(True))
