@@ -19,7 +19,7 @@ from .nn.parameters.gaussian import DEFAULT_SCALED_GAUSSIAN_MIXTURE
 from .nn.parameters.initializations import DEFAULT_UNIFORM, Initialization
 from .random import get_compute_dtype, manual_seed, set_compute_dtype  # noqa: F401
 
-__all__ = ["to_bayesian", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype"]
+__all__ = ["to_bayesian", "fuse_activations", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype"]
 
 
 def to_bayesian(model: torch.nn.Module, initialization: Optional[Initialization] = DEFAULT_UNIFORM,
@@ -42,3 +42,36 @@ def to_bayesian(model: torch.nn.Module, initialization: Optional[Initialization]
     new_model = deepcopy(model)
     swap(new_model)
     return Model(model=new_model)
+
+
+class _FusedIntoDense(torch.nn.Module):
+    """Placeholder left where an activation was folded into the preceding Bayesian layer's GEMM epilogue."""
+
+    def forward(self, x):
+        return x
+
+
+def _is_exact_gelu(fn) -> bool:
+    if isinstance(fn, torch.nn.GELU):
+        return fn.approximate == "none"
+    if fn is torch.nn.functional.gelu:
+        return True
+    # transformers.activations.GELUActivation (ACT2FN["gelu"]): .act is torch.nn.functional.gelu
+    return fn.__class__.__name__ == "GELUActivation" and getattr(fn, "act", None) is torch.nn.functional.gelu
+
+
+def fuse_activations(model: torch.nn.Module) -> int:
+    """Fold `dense -> exact GELU` pairs into the dense layer's GEMM epilogue (bf_gemm_nt_act).
+
+    Recognises the HuggingFace pattern `module.dense` (a bnn.Linear) followed by `module.intermediate_act_fn`
+    (BertIntermediate and its relatives).  Forward-only optimisation: whenever a gradient may be needed the layer
+    falls back to a separate GELU so autograd stays intact.  Returns the number of fused pairs."""
+    fused = 0
+    for m in model.modules():
+        dense = getattr(m, "dense", None)
+        act = getattr(m, "intermediate_act_fn", None)
+        if isinstance(dense, nn.Linear) and act is not None and _is_exact_gelu(act):
+            dense.activation = "gelu"
+            m.intermediate_act_fn = _FusedIntoDense()
+            fused += 1
+    return fused

@@ -188,6 +188,14 @@ int bf_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void
                              (hipStream_t)stream);
 }
 
+int bf_gemm_nt_act(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
+                   const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, int act, void* stream) {
+    if (act != BF_ACT_NONE && act != BF_ACT_GELU) BF_FAIL("bf_gemm_nt_act: unknown activation %d", act);
+    ProfScope prof(BF_PROF_GEMM, 2.0 * S * M * (double)N * K, (hipStream_t)stream);
+    return bf_launch_gemm_nt(d_x, x_dtype, x_sample_stride, d_w, w_dtype, d_bias, d_y, y_dtype, S, M, N, K,
+                             (hipStream_t)stream, act);
+}
+
 // workspace layout of bf_linear_fwd: [W_s : S*N*K compute_dtype][b_s : S*N fp32][log-prob partials]
 static void linear_ws_layout(int S, int N, int K, int has_bias, int compute_dtype, size_t* off_w, size_t* off_b,
                              size_t* off_p, size_t* total) {

@@ -46,7 +46,30 @@ int bf_launch_sample_table(const void* d_blob, int n_tensors, uint32_t block_beg
 int bf_launch_reduce_groups(const double* d_partials, const uint32_t* d_rows, int G, int S, double* d_out,
                             hipStream_t stream);
 int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
-                      const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, hipStream_t stream);
+                      const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, hipStream_t stream,
+                      int act = BF_ACT_NONE);
+
+// erf-GELU x/2 (1 + erf(x / sqrt 2)), the activation of HF BERT's intermediate layer, on the fp32 accumulators.
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32-exact for a bf16/fp16 or fp32 epilogue) on the
+// hardware rcp/exp2 units: ~14 VALU ops per value instead of libm erff's ~45.
+__device__ __forceinline__ float bf_gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float erf_abs = fmaf(-p * t, e, 1.0f);
+    return 0.5f * x * (1.0f + __builtin_copysignf(erf_abs, x));
+}
+__device__ __forceinline__ f32x4_t bf_apply_act(f32x4_t v, int act) {
+    if (act == BF_ACT_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = bf_gelu(v[j]);
+    }
+    return v;
+}
 int bf_launch_transpose(const void* d_in, void* d_out, int elem_size, int batch, int rows, int cols, hipStream_t stream);
 int bf_launch_colsum(const void* d_dy, int dtype, float* d_out, int S, int M, int N, hipStream_t stream);
 int bf_launch_param_grad(const float* d_dw, const float* d_rho, uint64_t n, int S, uint64_t seed, uint32_t sample_base,

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmParams p) {
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const long long m = m0 + wm * 64 + mb * 16 + (lane & 15);
-            store4<YT>(y, m, n, M, N, acc[nb][mb] + b, vec_ok);
+            store4<YT>(y, m, n, M, N, bf_apply_act(acc[nb][mb] + b, p.act), vec_ok);
         }
     }
 }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void gemm_nt_f32_kernel(const GemmParams p) {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const long long m = m0 + wm * 32 + mb * 16 + (lane & 15);
-            store4<float>(y, m, n, M, N, acc[nb][mb] + b, vec_ok);
+            store4<float>(y, m, n, M, N, bf_apply_act(acc[nb][mb] + b, p.act), vec_ok);
         }
     }
 }
@@ -277,7 +277,8 @@ int launch_16_xy(const GemmParams& p, int x_dtype, int y_dtype, int t_dtype, boo
 }  // namespace
 
 int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
-                      const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, hipStream_t stream) {
+                      const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, hipStream_t stream,
+                      int act) {
     if (!d_x || !d_w || !d_y) BF_FAIL("bf_gemm_nt: NULL operand");
     if (S < 1 || M < 1 || N < 1 || K < 1) BF_FAIL("bf_gemm_nt: bad shape S=%d M=%d N=%d K=%d", S, M, N, K);
     if (S > 65535) BF_FAIL("bf_gemm_nt: S=%d exceeds gridDim.y", S);
@@ -291,6 +292,7 @@ int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, con
     p.M = M;
     p.N = N;
     p.K = K;
+    p.act = act;
     if (w_dtype == BF_DT_F32) {
         if (x_dtype != BF_DT_F32 || y_dtype != BF_DT_F32) BF_FAIL("bf_gemm_nt: fp32 weights need fp32 x and y");
         p.tiles_m = (M + FM - 1) / FM;

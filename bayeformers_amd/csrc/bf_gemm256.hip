@@ -127,7 +127,8 @@ constexpr int EPI_PAD = 16;
 constexpr bool NT_STORES = BF_NT_STORES;
 template <typename YT>
 __device__ __forceinline__ void epilogue_via_lds(char* smem, const f32x4_t (&acc)[4][8], const float* bias, YT* y,
-                                                 int m0, int n0, int M, int N, int wm, int wn, int wid, int lane) {
+                                                 int m0, int n0, int M, int N, int wm, int wn, int wid, int lane,
+                                                 int act) {
     constexpr int ROW = TN * (int)sizeof(YT) + EPI_PAD;
     constexpr int PASSES = sizeof(YT) == 4 ? 2 : 1;
     constexpr int ROWS_PER_PASS = TM / PASSES;
@@ -142,7 +143,7 @@ __device__ __forceinline__ void epilogue_via_lds(char* smem, const f32x4_t (&acc
 #pragma unroll
                 for (int mb = 0; mb < 8; ++mb) {
                     const int ml = (PASSES == 1 ? wm * 128 : 0) + mb * 16 + (lane & 15);
-                    const f32x4_t v = acc[nb][mb];
+                    const f32x4_t v = bf_apply_act(acc[nb][mb], act);
                     char* dst = smem + ml * ROW + nl * (int)sizeof(YT);
                     if constexpr (sizeof(YT) == 4)
                         *reinterpret_cast<f32x4_t*>(dst) = v;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb) {
             const long long m = m0 + wm * 128 + mb * 16 + (lane & 15);
-            store4<YT>(y, m, n, M, N, acc[nb][mb] + b, vec_ok);
+            store4<YT>(y, m, n, M, N, bf_apply_act(acc[nb][mb] + b, p.act), vec_ok);
         }
     }
 }
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_pp_kernel(const GemmParams p) 
 
     if (p.flags & 8) return;
     YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
-    epilogue_via_lds<YT>(smem, acc, nullptr, y, m0, n0, M, N, wm, wn, wid, lane);
+    epilogue_via_lds<YT>(smem, acc, nullptr, y, m0, n0, M, N, wm, wn, wid, lane, p.act);
 }
 
 
@@ -433,7 +434,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_pp_kernel(const GemmParams p) 
 //     until the next tile's first k-step retires them together with that step's DMA.
 template <typename YT>
 __device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&acc)[4][8], const float* bias, YT* y,
-                                                int m0, int n0, int M, int N, int wm, int wn, int wid, int lane) {
+                                                int m0, int n0, int M, int N, int wm, int wn, int wid, int lane,
+                                                int act) {
     constexpr int ROW = TN * (int)sizeof(YT) + EPI_PAD;
     constexpr int PASS_ROWS = sizeof(YT) == 4 ? 32 : 64;
     constexpr int PASSES = TM / PASS_ROWS;            // 4 or 8
@@ -460,7 +462,7 @@ __device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&ac
 #pragma unroll
                 for (int k = 0; k < MB_PER_PASS; ++k) {
                     const int mb = (pass % PASSES_PER_GROUP) * MB_PER_PASS + k;
-                    const f32x4_t v = acc[nb][mb];
+                    const f32x4_t v = bf_apply_act(acc[nb][mb], act);
                     char* dst = region + wr_off + k * 16 * ROW + nb * 16 * (int)sizeof(YT);
                     if constexpr (sizeof(YT) == 4)
                         *reinterpret_cast<f32x4_t*>(dst) = v;
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
         YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
         if (!(p.flags & 8))
             epilogue_passes<YT>(smem + ((g - 1) & 1) * STAGE_BYTES, acc, nullptr, y, m0, n0, (p.flags & 16) ? 0 : M, N, wm,
-                                wn, wid, lane);
+                                wn, wid, lane, p.act);
         if (!has_next) break;
         vb = vbn;
         tile_setup(vb, cur, s, m0, n0);

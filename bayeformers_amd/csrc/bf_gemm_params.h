@@ -11,6 +11,7 @@ struct GemmParams {
     long long x_sstride;  // elements between samples of x (0 = one x shared by all samples)
     int S, M, N, K;
     int tiles_m, tiles_n;
+    int act;      // BF_ACT_* applied to y in the epilogue
     int stagger;  // first-round start offset step in 100 MHz wall-clock ticks (0 = off)
     int flags;  // developer ablation bits (BF_GEMM_ABLATE): 1 = no DMA in the k-loop, 2 = no MFMA, 4 = no fragment reads, 8 = no stores
 };

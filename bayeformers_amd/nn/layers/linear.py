@@ -54,16 +54,16 @@ class _PlannedLinearFn(torch.autograd.Function):
     """Forward of a layer whose weights were sampled by the model's cross-layer plan: only the MFMA GEMM is left."""
 
     @staticmethod
-    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, w_s, b_s, layer, S, seed, base):
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, w_s, b_s, layer, S, seed, base, act):
         ctx.layer, ctx.S, ctx.seed, ctx.base = layer, S, seed, base
         ctx.cdt = w_s.dtype
         ctx.save_for_backward(x)
-        return ops.planned_linear_forward(x, w_s, b_s, S, layer.out_features, layer.in_features)
+        return ops.planned_linear_forward(x, w_s, b_s, S, layer.out_features, layer.in_features, act)
 
     @staticmethod
     def backward(ctx, grad):
         dx, dmu_w, drho_w, dmu_b, drho_b = _backward(ctx, grad)
-        return dx, dmu_w, drho_w, dmu_b, drho_b, None, None, None, None, None, None
+        return dx, dmu_w, drho_w, dmu_b, drho_b, None, None, None, None, None, None, None
 
 
 class Linear(Module):
@@ -98,6 +98,7 @@ class Linear(Module):
 
         self.layer_id = bfr.new_layer_id()
         self.compute_dtype = None
+        self.activation = None  # "gelu": exact GELU fused into the GEMM epilogue (bayeformers_amd.fuse_activations)
         self._plan = ops.LinearPlan()
         self._lp_own = None    # [S, 2] float64 buffer when the layer is used outside a bnn.Model
         self._lp_view = None   # where the last forward wrote {log_prior, log_q} per sample
@@ -137,14 +138,23 @@ class Linear(Module):
         x2 = input.reshape(-1, self.in_features)
         mu_b = self.bias.mu if isinstance(self.bias, Gaussian) else None
         rho_b = self.bias.rho if isinstance(self.bias, Gaussian) else None
+        # the fused activation has no backward: when a gradient may be needed it runs as a separate op
+        want_act = self.activation == "gelu"
+        need_grad = torch.is_grad_enabled() and (x2.requires_grad or self.weight.rho.requires_grad or
+                                                 self.weight.mu.requires_grad)
         if ctx is not None and ctx.plan is not None:
             w_s, b_s = ctx.plan.ensure(self, ctx.token, bfr.STATE.seed, base, ctx.lp_buf)
+            fused = want_act and not need_grad
             y = _PlannedLinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, w_s, b_s, self, S,
-                                       bfr.STATE.seed, base)
+                                       bfr.STATE.seed, base, 1 if fused else 0)
+            if want_act and not fused:
+                y = torch.nn.functional.gelu(y)
             self._lp_view = slot
             self._lp_dirty = True
             return y.view(*input.shape[:-1], self.out_features)
         y = _LinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, self, S, bfr.STATE.seed, base, slot)
+        if want_act:
+            y = torch.nn.functional.gelu(y)
         self._lp_view = slot
         self._lp_dirty = True
         return y.view(*input.shape[:-1], self.out_features)

@@ -118,12 +118,12 @@ def sample_logprob(gaussians, priors, stream_ids, S: int, seed: int, sample_base
 
 
 def gemm_nt(x: Tensor, w: Tensor, bias: Optional[Tensor], S: int, M: int, N: int, K: int, x_sample_stride: int,
-            y_dtype: torch.dtype) -> Tensor:
-    """y[s] = x[s] w[s]^T + bias[s] on the matrix cores (bf_gemm_nt).  w: [S,N,K]; returns [S,M,N]."""
+            y_dtype: torch.dtype, act: int = 0) -> Tensor:
+    """y[s] = act(x[s] w[s]^T + bias[s]) on the matrix cores (bf_gemm_nt_act).  w: [S,N,K]; returns [S,M,N]."""
     y = torch.empty((S, M, N), dtype=y_dtype, device=x.device)
-    _C.check(_C.lib().bf_gemm_nt(x.data_ptr(), _TORCH2BF[x.dtype], x_sample_stride, w.data_ptr(), _TORCH2BF[w.dtype],
-                                 bias.data_ptr() if bias is not None else None, y.data_ptr(), _TORCH2BF[y_dtype],
-                                 S, M, N, K, _stream_ptr()), "bf_gemm_nt")
+    _C.check(_C.lib().bf_gemm_nt_act(x.data_ptr(), _TORCH2BF[x.dtype], x_sample_stride, w.data_ptr(),
+                                     _TORCH2BF[w.dtype], bias.data_ptr() if bias is not None else None, y.data_ptr(),
+                                     _TORCH2BF[y_dtype], S, M, N, K, act, _stream_ptr()), "bf_gemm_nt_act")
     return y
 
 
@@ -193,7 +193,7 @@ def _linear_forward_generic(layer, x, S, M, N, K, seed, sample_base, lp_out, cdt
     return y.view(S * M, N)
 
 
-def planned_linear_forward(x: Tensor, w_s: Tensor, b_s: Optional[Tensor], S: int, N: int, K: int) -> Tensor:
+def planned_linear_forward(x: Tensor, w_s: Tensor, b_s: Optional[Tensor], S: int, N: int, K: int, act: int = 0) -> Tensor:
     """y[s] = x[s] W_s^T + b_s with W_s/b_s already sampled by the model's cross-layer plan (plan.SamplePlan)."""
     _require_device(x, "input")
     if x.dtype not in _TORCH2BF:
@@ -207,7 +207,7 @@ def planned_linear_forward(x: Tensor, w_s: Tensor, b_s: Optional[Tensor], S: int
     if rows % S:
         raise _C.BayeFormersAMDError(f"input rows ({rows}) are not a multiple of the sample count S={S}")
     M = rows // S
-    return gemm_nt(x, w_s, b_s, S, M, N, K, M * K, x.dtype).view(S * M, N)
+    return gemm_nt(x, w_s, b_s, S, M, N, K, M * K, x.dtype, act).view(S * M, N)
 
 
 def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_base: int, cdt: torch.dtype,

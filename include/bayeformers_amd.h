@@ -110,6 +110,13 @@ int bf_reduce_logprob(const double* d_partials, const uint32_t* d_rows, int n_gr
 int bf_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
                const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, void* stream);
 
+/* Same GEMM with an activation fused into the epilogue (applied to the fp32 accumulators after the bias):
+ * BF_ACT_GELU = x/2 (1 + erf(x/sqrt 2)), the `intermediate_act_fn` that follows the dense layer of HF BERT's
+ * BertIntermediate — saves one full read+write of the [S*B*L, 3072] activation per transformer layer. */
+enum { BF_ACT_NONE = 0, BF_ACT_GELU = 1 };
+int bf_gemm_nt_act(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
+                   const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, int act, void* stream);
+
 /* The whole of Linear.forward (layers/linear.py:83-104) for S Monte-Carlo samples in one call:
  * sample W_s and b_s, accumulate both log-probs, y[s] = x[s] W_s^T + b_s.
  *   weight.n must be N*K (row-major [N][K], as nn.Linear), bias may be NULL (NoneParameter, base.py:55-69);

@@ -174,3 +174,17 @@ def test_full_size_layer_768(M):
         if s == 0:
             W = bo.gaussian_sample(mu_w, rho_w, eps_w)
             assert (Ws[0].cpu() - W).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("S,M,N,K", [(2, 300, 200, 128), (1, 40, 24, 72), (2, 513, 259, 192)])
+def test_gemm_fused_gelu(S, M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(7)
+    w = torch.randn(S, N, K, device="cuda", generator=g).bfloat16()
+    x = torch.randn(S, M, K, device="cuda", generator=g).bfloat16()
+    bias = torch.randn(S, N, device="cuda", generator=g)
+    pre = torch.einsum("smk,snk->smn", x.double(), w.double()) + bias[:, None, :].double()
+    ref = torch.nn.functional.gelu(pre)
+    for ydt in (torch.bfloat16, torch.float32):
+        y = ops.gemm_nt(x, w, bias, S, M, N, K, M * K, ydt, act=1)
+        tol = 2.0 ** -8 if ydt == torch.bfloat16 else 1e-5
+        assert (y.double() - ref).abs().max().item() <= tol * ref.abs().max().item() + 1e-5 * np.sqrt(K)

@@ -107,3 +107,22 @@ def test_bert(golden_dir, fixture, tiny, dtype, tol):
     n_batches = 2105  # SST-2 train set / batch 32
     ref_loss = (g["lvp"].mean() - g["log_prior"].mean()) / n_batches + float(g["nll"])
     assert float(elbo(lp, lq, nll.double(), n_batches)) == pytest.approx(ref_loss, rel=1e-3)
+
+
+def test_fused_gelu_matches_unfused_bert():
+    """fuse_activations(): dense + exact GELU in the GEMM epilogue gives the same logits as the separate GELU op."""
+    cfg, model = _bert(True)
+    inputs = None
+    outs = []
+    for fuse in (False, True):
+        bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().cuda().to(torch.bfloat16)
+        if fuse:
+            assert bf.fuse_activations(bmodel) == cfg.num_hidden_layers
+        torch.manual_seed(3)
+        ids = torch.randint(0, cfg.vocab_size, (4, 16)).cuda()
+        bf.manual_seed(SEED)
+        with torch.no_grad():
+            raw, mean, lp, lq = sample_bayesian(bmodel, {"input_ids": ids}, 3)
+        outs.append((raw[0].float(), float(lp), float(lq)))
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 2e-2
+    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
