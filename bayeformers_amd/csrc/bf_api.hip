@@ -1,4 +1,5 @@
 // bf_api.hip — the extern "C" surface declared in include/bayeformers_amd.h.
+#include <stdlib.h>
 #include <string.h>
 
 #include "bf_common.h"
@@ -205,7 +206,9 @@ static void linear_ws_layout(int S, int N, int K, int has_bias, int compute_dtyp
     memset(t, 0, sizeof(t));
     t[0].n = (uint64_t)N * K;
     t[1].n = (uint64_t)N;
-    const size_t pbytes = bf_sample_partials_bytes(t, has_bias ? 2 : 1, S);
+    size_t pbytes = bf_sample_partials_bytes(t, has_bias ? 2 : 1, S);
+    const size_t fbytes = bf_align_up(bf_fused_small_partial_rows(N) * (size_t)S * 2 * sizeof(double), 256);
+    if (fbytes > pbytes) pbytes = fbytes;  // the single-kernel small-M path keeps one partial row per 16 features
     *off_w = 0;
     *off_b = wbytes;
     *off_p = wbytes + bbytes;
@@ -237,6 +240,21 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
     if (!d_workspace || workspace_bytes < total)
         BF_FAIL("bf_linear_fwd: workspace too small (%zu < %zu bytes)", workspace_bytes, total);
     char* ws = reinterpret_cast<char*>(d_workspace);
+
+    // small M: one fused kernel (epsilon in registers -> MFMA operand), no sampled weights in memory
+    static const bool fused_off = getenv("BF_NO_FUSED_SMALL") != nullptr;
+    if (!fused_off && bf_fused_small_supported(x_dtype, y_dtype, compute_dtype, x_sample_stride, d_x, weight, bias, S, M, N, K)) {
+        for (int i = 0; i < (bias ? 2 : 1); ++i)
+            if ((i ? bias : weight)->prior.kind == BF_PRIOR_GAUSSIAN &&
+                (!(i ? bias : weight)->prior.d_mu || !(i ? bias : weight)->prior.d_rho))
+                BF_FAIL("bf_linear_fwd: gaussian prior needs d_mu/d_rho");
+        ProfScope prof(BF_PROF_GEMM, 2.0 * S * M * (double)N * K, (hipStream_t)stream);
+        int rc = bf_launch_fused_small(d_x, x_dtype, x_sample_stride, weight, bias, d_y, compute_dtype, S, M, N, K, seed,
+                                       sample_base, reinterpret_cast<double*>(ws + op), (hipStream_t)stream);
+        if (rc) return rc;
+        return bf_launch_reduce_partials(reinterpret_cast<const double*>(ws + op),
+                                         (uint32_t)bf_fused_small_partial_rows(N), S, d_logprob_out, (hipStream_t)stream);
+    }
 
     bf_tensor_t t[2];
     t[0] = *weight;

@@ -552,6 +552,13 @@ int bf_launch_sample_table(const void* d_blob, int n_tensors, uint32_t block_beg
     return 0;
 }
 
+int bf_launch_reduce_partials(const double* d_partials, uint32_t nrows, int S, double* d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(bf_reduce_partials_kernel, dim3((uint32_t)(2 * S)), dim3(256), 0, stream, d_partials, nrows, S,
+                       d_out);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int bf_launch_reduce_groups(const double* d_partials, const uint32_t* d_rows, int G, int S, double* d_out,
                             hipStream_t stream) {
     if (!d_partials || !d_rows || !d_out) BF_FAIL("bf_reduce_logprob: NULL argument");

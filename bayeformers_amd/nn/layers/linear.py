@@ -98,6 +98,7 @@ class Linear(Module):
 
         self.layer_id = bfr.new_layer_id()
         self.compute_dtype = None
+        self._small_m = False   # seen with <= 64 rows per sample: single fused kernel, left out of the sampling plan
         self.activation = None  # "gelu": exact GELU fused into the GEMM epilogue (bayeformers_amd.fuse_activations)
         self._plan = ops.LinearPlan()
         self._lp_own = None    # [S, 2] float64 buffer when the layer is used outside a bnn.Model
@@ -142,7 +143,11 @@ class Linear(Module):
         want_act = self.activation == "gelu"
         need_grad = torch.is_grad_enabled() and (x2.requires_grad or self.weight.rho.requires_grad or
                                                  self.weight.mu.requires_grad)
-        if ctx is not None and ctx.plan is not None:
+        rows_per_sample = x2.shape[0] // S
+        small = rows_per_sample <= 64 and self.in_features % 32 == 0 and x2.dtype != torch.float64
+        if small != self._small_m:
+            self._small_m = small  # the model rebuilds its sampling plan without / with this layer next forward
+        if ctx is not None and ctx.plan is not None and not small and id(self) in ctx.plan.group_of:
             w_s, b_s = ctx.plan.ensure(self, ctx.token, bfr.STATE.seed, base, ctx.lp_buf)
             fused = want_act and not need_grad
             y = _PlannedLinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, w_s, b_s, self, S,

@@ -87,11 +87,15 @@ class Model(Module):
             slots = {id(l): buf[i] for i, l in enumerate(layers)}
         plan = None
         if layers and self.cross_layer_sampling and SamplePlan.plannable(layers):
-            cdt = bfr.get_compute_dtype()
-            key = SamplePlan.make_key(layers, S, cdt)
-            if self._plan is None or self._plan.key != key:
-                self._plan = SamplePlan(layers, S, cdt, layers[0].weight.mu.device)
-            plan = self._plan
+            # layers seen with <= 64 rows per sample run the single fused kernel instead (Linear.forward marks them)
+            planned = [(i, l) for i, l in enumerate(layers) if not l._small_m]
+            if planned:
+                cdt = bfr.get_compute_dtype()
+                pl = [l for _, l in planned]
+                key = SamplePlan.make_key(pl, S, cdt)
+                if self._plan is None or self._plan.key != key:
+                    self._plan = SamplePlan(pl, S, cdt, layers[0].weight.mu.device, index=[i for i, _ in planned])
+                plan = self._plan
         rank, world = self._mc_shard
         # every rank reserves the GLOBAL S*world indices and runs its own contiguous slice of them
         base = bfr.reserve_samples(S * world) + rank * S

@@ -28,24 +28,29 @@ GROUP_BYTES = 96 << 20
 
 
 class SamplePlan:
-    def __init__(self, layers, S: int, cdt: torch.dtype, device: torch.device):
+    def __init__(self, layers, S: int, cdt: torch.dtype, device: torch.device, index=None):
+        """layers: the planned bnn.Linear modules; index[i] = row of layers[i] in the model's [L, S, 2] log-prob
+        buffer (layers that take the single-kernel small-M path are left out, so rows may have gaps)."""
         from .nn.parameters.base import NoneParameter
 
         self.S, self.cdt, self.device = S, cdt, device
         self.layers = layers
+        self.index = list(index) if index is not None else list(range(len(layers)))
         self.key = self.make_key(layers, S, cdt)
         lib = _C.lib()
         esz = 4 if cdt == torch.float32 else 2
 
         # groups of consecutive layers
         self.group_of, groups, cur, cur_bytes = {}, [], [], 0
-        for l in layers:
+        prev_row = None
+        for l, row in zip(layers, self.index):
             b = S * l.weight.mu.numel() * esz
-            if cur and cur_bytes + b > GROUP_BYTES:
+            if cur and (cur_bytes + b > GROUP_BYTES or row != prev_row + 1):
                 groups.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(l)
             cur_bytes += b
+            prev_row = row
         if cur:
             groups.append(cur)
         self.groups = groups
@@ -107,11 +112,11 @@ class SamplePlan:
         self.layer_rows = torch.tensor(layer_rows, dtype=torch.int32, device=device)
         self.layer_rows_host = layer_rows
         self.partials = torch.empty((self.total_blocks, S, 2), dtype=torch.float64, device=device)
-        # per group: (first layer index, number of layers, first block, end block)
+        # per group: (first plan-layer index, number of layers, first block, end block, first row of the model buffer)
         self.group_span = []
         li = 0
         for g in groups:
-            self.group_span.append((li, len(g), layer_rows[li], layer_rows[li + len(g)]))
+            self.group_span.append((li, len(g), layer_rows[li], layer_rows[li + len(g)], self.index[li]))
             li += len(g)
         self.scalars = sum(l.weight.mu.numel() + (l.out_features if self.slices[id(l)][2] is not None else 0) for l in layers)
 
@@ -119,7 +124,7 @@ class SamplePlan:
     def make_key(layers, S, cdt):
         from .nn.parameters.gaussian import Gaussian
 
-        key = [S, cdt]
+        key = [S, cdt, len(layers)]
         for l in layers:
             key.append(l.layer_id)
             for g in (l.weight, l.bias, l.weight_prior, l.bias_prior):
@@ -151,13 +156,13 @@ class SamplePlan:
         gi = self.group_of[id(layer)]
         a = gi % len(self.arenas)
         if self.arena_owner[a] != (gi, token):
-            l0, nl, b0, b1 = self.group_span[gi]
+            l0, nl, b0, b1, row0 = self.group_span[gi]
             lib = _C.lib()
             stream = ops._stream_ptr()
             _C.check(lib.bf_sample_logprob_table(self.blob.data_ptr(), self.n_entries, b0, b1, self.S, seed,
                                                  sample_base & 0xFFFFFFFF, self.partials.data_ptr(), stream),
                      "bf_sample_logprob_table")
             _C.check(lib.bf_reduce_logprob(self.partials.data_ptr(), self.layer_rows.data_ptr() + 4 * l0, nl, self.S,
-                                           lp_buf.data_ptr() + l0 * self.S * 2 * 8, stream), "bf_reduce_logprob")
+                                           lp_buf.data_ptr() + row0 * self.S * 2 * 8, stream), "bf_reduce_logprob")
             self.arena_owner[a] = (gi, token)
         return self.views[id(layer)]

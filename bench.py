@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="bert_base", choices=["bert_base", "linear768", "linear768_m32", "mlp"])
+    ap.add_argument("--workload", default="bert_base", choices=["bert_base", "bert_large_qa", "linear768", "linear768_m32", "mlp"])
     ap.add_argument("--samples", type=int, default=None, help="MC samples per GPU per step (default: workload's)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -93,6 +93,49 @@ def make_bert(device, S, dtype):
     cfgd = {"workload": "to_bayesian(BERT-base seq-cls, delta=0.05, freeze=True) fwd+ELBO", "samples_per_gpu": S,
             "batch": B, "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "bayesian_scalars": 85609730,
             "gelu_fused_into_gemm": n_fused}
+    return step, cpu_baseline, cfgd, bmodel
+
+
+def make_bert_large_qa(device, S, dtype):
+    """BASELINE config 5: to_bayesian(BERT-large QA) SQuAD-shaped forward + ELBO, seq=384, batch=16."""
+    import bayeformers_amd as bf
+    from bayeformers_amd.sampling import elbo, sample_bayesian
+    from transformers import BertConfig, BertForQuestionAnswering
+
+    B, L, n_batches = 16, 384, 5475  # SQuAD v1.1: 87,599 train questions / 16
+    torch.manual_seed(0)
+    cfg = BertConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+    model = BertForQuestionAnswering(cfg).eval()
+    bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().to(device)
+    n_fused = bf.fuse_activations(bmodel)
+    if dtype != "fp32":
+        bmodel = bmodel.to(torch.bfloat16 if dtype == "bf16" else torch.float16)
+    g = torch.Generator().manual_seed(654)
+    ids = torch.randint(0, cfg.vocab_size, (B, L), generator=g)
+    sp, ep = torch.randint(0, L, (B,), generator=g).to(device), torch.randint(0, L, (B,), generator=g).to(device)
+    inputs = {"input_ids": ids.to(device), "attention_mask": torch.ones(B, L, dtype=torch.long, device=device)}
+
+    def step():
+        with torch.no_grad():
+            raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S)
+            ce = torch.nn.functional.cross_entropy
+            nll = 0.5 * (ce(mean[0].float(), sp) + ce(mean[1].float(), ep))  # examples/bert_squad.py:474-481
+            return elbo(lp, lq, nll.double(), n_batches)
+
+    def cpu_baseline():
+        from oracle.model_oracle import log_probs, to_oracle
+
+        omodel = to_oracle(model, delta=0.05).eval()
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            omodel(input_ids=ids, attention_mask=torch.ones(B, L, dtype=torch.long))
+            log_probs(omodel)
+            dt = time.perf_counter() - t0
+        return {"value": 1 / dt, "unit": "MC-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"1 MC sample (fwd + log-probs) of the same BERT-large B=16 L=384 batch, torch-CPU fp32, {dt:.1f}s"}
+
+    cfgd = {"workload": "to_bayesian(BERT-large QA, delta=0.05, freeze=True) fwd+ELBO", "samples_per_gpu": S, "batch": B,
+            "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "gelu_fused_into_gemm": n_fused}
     return step, cpu_baseline, cfgd, bmodel
 
 
@@ -188,13 +231,15 @@ def main():
     import bayeformers_amd as bf
     from bayeformers_amd import _C
 
-    defaults = {"bert_base": (10, "bf16"), "linear768": (10, "bf16"), "linear768_m32": (10, "bf16"), "mlp": (5, "bf16")}
+    defaults = {"bert_base": (10, "bf16"), "bert_large_qa": (10, "fp16"), "linear768": (10, "bf16"), "linear768_m32": (10, "bf16"), "mlp": (5, "bf16")}
     S = args.samples or defaults[args.workload][0]
     dtype = args.dtype or defaults[args.workload][1]
     bf.set_compute_dtype(dtype)
     bf.manual_seed(0x5EED)
     if args.workload == "bert_base":
         step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype)
+    elif args.workload == "bert_large_qa":
+        step, cpu_baseline, cfgd, bmodel = make_bert_large_qa(device, S, dtype)
     elif args.workload == "linear768":
         step, cpu_baseline, cfgd, bmodel = make_linear(device, S, dtype, 4096)
     elif args.workload == "linear768_m32":

@@ -251,6 +251,39 @@ def grad_cases():
     return out
 
 
+def bert_large_qa_case():
+    """BASELINE config 5: to_bayesian(BERT-large QA), S=10, seq=384, batch=16 (examples/bert_squad.py:190-212,:222)."""
+    from transformers import BertConfig, BertForQuestionAnswering
+
+    cfg = BertConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+    S, B, L = 10, 16, 384
+    torch.manual_seed(0)
+    model = BertForQuestionAnswering(cfg).eval()
+    bmodel = ref_to_bayesian(model, delta=0.05, freeze=True).eval()
+    csum = checksum(bmodel)
+    torch.manual_seed(654)
+    ids = torch.randint(0, cfg.vocab_size, (B, L))
+    mask = torch.ones(B, L, dtype=torch.long)
+    clock = {"seed": SEED, "sample": 0}
+    layers = inject(bmodel, clock)
+    start = torch.zeros(S, B, L)
+    end = torch.zeros(S, B, L)
+    lp = torch.zeros(S, dtype=torch.float64)
+    lq = torch.zeros(S, dtype=torch.float64)
+    t0 = time.time()
+    with torch.no_grad():
+        for s in range(S):  # sample_bayesian, examples/bert_squad.py:198-203
+            clock["sample"] = s
+            out = bmodel(input_ids=ids, attention_mask=mask)
+            start[s], end[s] = out[0], out[1]
+            lp[s] = float(bmodel.log_prior())
+            lq[s] = float(bmodel.log_variational_posterior())
+            print(f"    sample {s}: {time.time() - t0:.0f}s", flush=True)
+    return {"S": S, "B": B, "L": L, "model_seed": 0, "input_seed": 654, "delta": 0.05, "n_layers": len(layers),
+            "checksum": csum, "ids_sum": int(ids.sum()), "start_mean": t2n(start.mean(0)), "end_mean": t2n(end.mean(0)),
+            "start_s0": t2n(start[0]), "end_s9": t2n(end[9]), "log_prior": t2n(lp), "lvp": t2n(lq)}
+
+
 def conversion_case():
     """to_bayesian / from_frequentist numerics and state-dict layout (bayeformers/__init__.py:19-63)."""
     torch.manual_seed(7)
@@ -274,8 +307,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-bert", action="store_true")
     ap.add_argument("--only-grads", action="store_true")
+    ap.add_argument("--only-bert-large", action="store_true")
     args = ap.parse_args()
     torch.set_num_threads(8)
+    if args.only_bert_large:
+        np.savez_compressed(os.path.join(HERE, "bert_large_qa_c5.npz"), **bert_large_qa_case())
+        return
     if args.only_grads:
         np.savez_compressed(os.path.join(HERE, "linear_grads.npz"), **grad_cases())
         return

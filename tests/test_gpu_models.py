@@ -126,3 +126,41 @@ def test_fused_gelu_matches_unfused_bert():
         outs.append((raw[0].float(), float(lp), float(lq)))
     assert (outs[0][0] - outs[1][0]).abs().max().item() < 2e-2
     assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-2), ("bf16", 8e-2)])
+def test_bert_large_qa_c5(golden_dir, dtype, tol):
+    """BASELINE config 5: to_bayesian(BERT-large QA), S=10, seq=384, batch=16, fp16 MFMA (and bf16), vs the reference."""
+    from transformers import BertConfig, BertForQuestionAnswering
+
+    g = np.load(f"{golden_dir}/bert_large_qa_c5.npz")
+    S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
+    cfg = BertConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+    torch.manual_seed(int(g["model_seed"]))
+    model = BertForQuestionAnswering(cfg).eval()
+    bmodel = bf.to_bayesian(model, delta=float(g["delta"]), freeze=True).eval()
+    assert len(bmodel.fused_children()) == int(g["n_layers"])
+    assert checksum(bmodel) == pytest.approx(float(g["checksum"]), rel=1e-6)
+    torch.manual_seed(int(g["input_seed"]))
+    ids = torch.randint(0, cfg.vocab_size, (B, L))
+    assert int(ids.sum()) == int(g["ids_sum"])
+    tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    bmodel = bmodel.cuda().to(tdt)
+    bf.fuse_activations(bmodel)
+    bf.manual_seed(SEED)
+    bf.set_compute_dtype(dtype)
+    try:
+        with torch.no_grad():
+            inputs = {"input_ids": ids.cuda(), "attention_mask": torch.ones(B, L, dtype=torch.long, device="cuda")}
+            raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S)
+    finally:
+        bf.set_compute_dtype("bf16")
+    lps = bmodel.log_prob_samples().cpu().numpy()
+    np.testing.assert_allclose(lps[:, 0], g["log_prior"], rtol=2e-6)
+    np.testing.assert_allclose(lps[:, 1], g["lvp"], rtol=2e-6)
+    start, end = raw[0].float().cpu().numpy(), raw[1].float().cpu().numpy()
+    scale = max(1.0, np.abs(g["start_mean"]).max())
+    assert np.abs(start.mean(0) - g["start_mean"]).max() < tol * scale
+    assert np.abs(end.mean(0) - g["end_mean"]).max() < tol * scale
+    assert np.abs(start[0] - g["start_s0"]).max() < tol * scale
+    assert np.abs(end[9] - g["end_s9"]).max() < tol * scale
