@@ -42,6 +42,7 @@ _tp = ctypes.POINTER(bf_tensor_t)
 SYMBOLS = {
     "bf_version": (_i, []),
     "bf_last_error": (ctypes.c_char_p, []),
+    "bf_set_sample_counter": (_i, [_vp]),
     "bf_device_info": (_i, [ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "bf_philox_normal_host": (_i, [_vp, _u64, _u64, _u32, _u32, _u64]),
     "bf_philox_normal": (_i, [_vp, _u64, _i, _u64, _u32, _u32, _vp]),

@@ -6,6 +6,9 @@
 #include "bf_philox.h"
 
 static thread_local char g_err[512] = "";
+static const uint32_t* g_sample_counter = nullptr;
+
+const uint32_t* bf_sample_counter() { return g_sample_counter; }
 
 void bf_set_error(const char* fmt, ...) {
     va_list ap;
@@ -109,6 +112,11 @@ int bf_profile_read(int kind, uint64_t* launches, double* total_ms, double* tota
 }
 
 int bf_version(void) { return BF_VERSION_MAJOR * 1000 + BF_VERSION_MINOR; }
+
+int bf_set_sample_counter(const uint32_t* d_counter) {
+    g_sample_counter = d_counter;
+    return 0;
+}
 
 const char* bf_last_error(void) { return g_err; }
 

@@ -58,8 +58,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, f
 // dmu[e] = sum_s dw[s][e];  drho[e] = (sum_s dw[s][e] * eps(s, e)) * softplus'(rho[e]).  thread = 4 scalars.
 __global__ __launch_bounds__(256) void param_grad_kernel(const float* __restrict__ dw, const float* __restrict__ rho,
                                                          unsigned long long n, int S, uint32_t k0, uint32_t k1,
-                                                         uint32_t sample_base, uint32_t stream,
-                                                         float* __restrict__ dmu, float* __restrict__ drho) {
+                                                         uint32_t sample_base, const uint32_t* __restrict__ counter,
+                                                         uint32_t stream, float* __restrict__ dmu,
+                                                         float* __restrict__ drho) {
+    sample_base += counter ? *counter : 0u;
     const unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     const unsigned long long e0 = g * 4;
     if (e0 >= n) return;
@@ -120,7 +122,7 @@ int bf_launch_param_grad(const float* d_dw, const float* d_rho, uint64_t n, int 
     if (n == 0 || S < 1) BF_FAIL("bf_param_grad: empty");
     const uint64_t groups = (n + 3) / 4;
     hipLaunchKernelGGL(param_grad_kernel, dim3((uint32_t)((groups + 255) / 256)), dim3(256), 0, stream, d_dw, d_rho,
-                       (unsigned long long)n, S, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, stream_id, d_dmu,
+                       (unsigned long long)n, S, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, bf_sample_counter(), stream_id, d_dmu,
                        d_drho);
     BF_HIP_CHECK(hipGetLastError());
     return 0;

@@ -33,6 +33,9 @@ void bf_set_error(const char* fmt, ...);
 static inline size_t bf_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline size_t bf_dtype_size(int dt) { return dt == BF_DT_F32 ? 4 : 2; }
 
+// optional device-resident Monte-Carlo sample counter (bf_set_sample_counter): kernels add *counter to sample_base
+const uint32_t* bf_sample_counter();
+
 // internal launchers (defined in bf_sample.hip / bf_gemm.hip), all asynchronous on `stream`
 int bf_launch_philox_normal(float* d_out, uint64_t n, int S, uint64_t seed, uint32_t sample_base, uint32_t stream_id,
                             hipStream_t stream);

@@ -37,6 +37,7 @@ struct FusedParams {
     const float* mu_pb;
     const float* rho_pb;
     double* partials;  // [gridDim.x][S][2]
+    const uint32_t* counter;  // optional device counter added to sample_base
     float a1, b1, a2, b2;      // weight mixture constants
     float ba1, bb1, ba2, bb2;  // bias mixture constants
     int prior_w, prior_b;
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(NW * 64) void fused_small_kernel(const FusedParams 
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int s = blockIdx.y, n0 = blockIdx.x * 16;
     const int M = p.M, N = p.N, K = p.K;
-    const uint32_t sample = p.sample_base + (uint32_t)s;
+    const uint32_t sample = p.sample_base + (p.counter ? *p.counter : 0u) + (uint32_t)s;
 
     const int nrow = n0 + (lane & 15);        // the weight row this lane generates
     const bool nvalid = nrow < N;
@@ -384,6 +385,7 @@ int bf_launch_fused_small(const void* d_x, int x_dtype, int64_t x_sample_stride,
     p.M = M; p.N = N; p.K = K; p.S = S;
     p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32);
     p.sample_base = sample_base;
+    p.counter = bf_sample_counter();
     p.stream_w = weight->stream_id;
     const dim3 grid((uint32_t)((N + 15) / 16), (uint32_t)S);
     const int MB = (M + 15) / 16;

@@ -56,6 +56,7 @@ struct SampleParams {
     int ny;  // sample chunks (gridDim.y)
     uint32_t k0, k1;
     uint32_t sample_base;
+    const uint32_t* counter;  // optional device counter added to sample_base
     uint32_t nblk;
     double* partials;  // [nblk][S][2]
 };
@@ -268,7 +269,8 @@ __global__ __launch_bounds__(kThreads) void bf_sample_logprob_kernel(const Sampl
     a.a1 = p.a1; a.b1 = p.b1; a.a2 = p.a2; a.b2 = p.b2;
     a.stream = sg.stream; a.rel_block = blockIdx.x - sg.block_begin;
     a.vec_in = sg.vec_in; a.vec_out = sg.vec_out; a.out_dt = BF_DT_F32;
-    a.S = p.S; a.ny = p.ny; a.k0 = p.k0; a.k1 = p.k1; a.sample_base = p.sample_base;
+    a.S = p.S; a.ny = p.ny; a.k0 = p.k0; a.k1 = p.k1;
+    a.sample_base = p.sample_base + (p.counter ? *p.counter : 0u);
     a.partial_row = p.partials + (size_t)blockIdx.x * p.S * 2;
     if (si == 0) sample_body<PRIOR, OUT_DT>(a, red, cst);
     else sample_body<PRIOR, BF_DT_F32>(a, red, cst);
@@ -294,6 +296,7 @@ __global__ __launch_bounds__(kThreads) void bf_sample_table_kernel(const TableEn
                                                                    const uint32_t* __restrict__ entry_of_block,
                                                                    uint32_t block0, int S, int ny, uint32_t k0,
                                                                    uint32_t k1, uint32_t sample_base,
+                                                                   const uint32_t* __restrict__ counter,
                                                                    double* __restrict__ partials) {
     __shared__ float red[4][kMaxSChunk][2];
     __shared__ float cst[4][2];
@@ -304,7 +307,8 @@ __global__ __launch_bounds__(kThreads) void bf_sample_table_kernel(const TableEn
     a.a1 = e.a1; a.b1 = e.b1; a.a2 = e.a2; a.b2 = e.b2;
     a.stream = e.stream; a.rel_block = gb - e.block_begin;
     a.vec_in = e.vec_in; a.vec_out = e.vec_out; a.out_dt = e.out_dt;
-    a.S = S; a.ny = ny; a.k0 = k0; a.k1 = k1; a.sample_base = sample_base;
+    a.S = S; a.ny = ny; a.k0 = k0; a.k1 = k1;
+    a.sample_base = sample_base + (counter ? *counter : 0u);
     a.partial_row = partials + (size_t)gb * S * 2;
     const int pk = __builtin_amdgcn_readfirstlane(e.prior_kind);
     if (pk == BF_PRIOR_GAUSSIAN) sample_body<BF_PRIOR_GAUSSIAN, OUT_RUNTIME>(a, red, cst);
@@ -407,6 +411,7 @@ static int launch_group(const bf_tensor_t* tensors, int first, int count, uint32
     p.k0 = (uint32_t)seed;
     p.k1 = (uint32_t)(seed >> 32);
     p.sample_base = sample_base;
+    p.counter = bf_sample_counter();
     // this group's blocks write partial rows [blk_offset, blk_offset + blk)
     p.partials = partials + (size_t)blk_offset * (size_t)S * 2;
     uint32_t blk = 0;
@@ -547,7 +552,7 @@ int bf_launch_sample_table(const void* d_blob, int n_tensors, uint32_t block_beg
     const uint32_t blk = block_end - block_begin;
     const int ny = pick_ny(blk, S);
     hipLaunchKernelGGL(bf_sample_table_kernel, dim3(blk, (uint32_t)ny), dim3(kThreads), 0, stream, ent, map,
-                       block_begin, S, ny, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, d_partials);
+                       block_begin, S, ny, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, bf_sample_counter(), d_partials);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -158,6 +158,8 @@ class Linear(Module):
             self._lp_dirty = True
             return y.view(*input.shape[:-1], self.out_features)
         y = _LinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, self, S, bfr.STATE.seed, base, slot)
+        if ctx is None:
+            bfr.commit_samples(1)
         if want_act:
             y = torch.nn.functional.gelu(y)
         self._lp_view = slot

@@ -105,6 +105,7 @@ class Model(Module):
             return super(Model, self).__call__(*args, **kwargs)
         finally:
             bfr.STATE.ctx = None
+            bfr.commit_samples(S * world)
 
     @contextlib.contextmanager
     def monte_carlo(self, samples: int, shard=(0, 1)):

@@ -62,6 +62,7 @@ class Gaussian(Parameter):
         base = bfr.reserve_samples(1)
         outs, _ = ops.sample_logprob([self], [NoneParameter()], [self.stream_id], 1, bfr.STATE.seed, base,
                                      out_dtype=torch.float32)
+        bfr.commit_samples(1)
         return outs[0][0]
 
     def log_prob(self, input: Tensor) -> Tensor:

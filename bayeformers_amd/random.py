@@ -27,6 +27,7 @@ class _State(threading.local):
         self.ctx = None  # (sample_base, S) while a bnn.Model forward is running
         self.compute_dtype = torch.bfloat16
         self.next_layer_id = 0
+        self.device_counter = None  # 1-element int32 device tensor when the sample counter lives on the GPU
 
 
 STATE = _State()
@@ -36,6 +37,9 @@ def manual_seed(seed: int, next_sample: int = 0) -> None:
     """Seed the Philox key and rewind the Monte-Carlo sample counter."""
     STATE.seed = int(seed) & (2 ** 64 - 1)
     STATE.next_sample = int(next_sample) & 0xFFFFFFFF
+    if STATE.device_counter is not None:
+        v = STATE.next_sample if STATE.next_sample < 2 ** 31 else STATE.next_sample - 2 ** 32
+        STATE.device_counter.fill_(v)
 
 
 def get_state():
@@ -43,10 +47,41 @@ def get_state():
 
 
 def reserve_samples(n: int) -> int:
-    """Reserve n consecutive MC sample indices; returns the first."""
+    """Reserve n consecutive MC sample indices; returns the first (host-side part of it).
+
+    With a device-resident counter (use_device_counter) the host part is always 0: the kernels add the counter
+    themselves and commit_samples() advances it after the forward has been enqueued."""
+    if STATE.device_counter is not None:
+        return 0
     base = STATE.next_sample
     STATE.next_sample = (base + int(n)) & 0xFFFFFFFF
     return base
+
+
+def commit_samples(n: int) -> None:
+    """Call after the kernels of a forward are enqueued: moves a device-resident counter past the n indices used."""
+    if STATE.device_counter is not None:
+        STATE.device_counter.add_(int(n))
+
+
+def use_device_counter(enable: bool = True, device="cuda") -> None:
+    """Keep the Monte-Carlo sample counter in device memory (bf_set_sample_counter).
+
+    Needed to capture a step in a HIP graph (torch.cuda.graph): a graph bakes kernel arguments, so a host-side
+    sample index would make every replay draw the same epsilon; with the counter on the device the captured
+    `counter += S` gives each replay fresh samples — replay k of a graph behaves like the k-th eager step."""
+    from . import _C
+
+    if enable:
+        if STATE.device_counter is None:
+            v = STATE.next_sample if STATE.next_sample < 2 ** 31 else STATE.next_sample - 2 ** 32
+            STATE.device_counter = torch.full((1,), v, dtype=torch.int32, device=device)
+        _C.check(_C.lib().bf_set_sample_counter(STATE.device_counter.data_ptr()), "bf_set_sample_counter")
+    else:
+        if STATE.device_counter is not None:
+            STATE.next_sample = int(STATE.device_counter.item()) & 0xFFFFFFFF
+        _C.check(_C.lib().bf_set_sample_counter(None), "bf_set_sample_counter")
+        STATE.device_counter = None
 
 
 def set_compute_dtype(dtype) -> None:

@@ -81,17 +81,30 @@ def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callabl
     raw = tuple(o.reshape(s_local, o.shape[0] // s_local, *o.shape[1:]) for o in outs)
     lp = model.log_prob_samples()  # [S_local, 2] float64
 
-    sums = [r.sum(0, dtype=torch.float64).reshape(-1) for r in raw]
-    packed = torch.cat(sums + [lp.sum(0)])
-    if distributed:
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
-    packed = packed / samples
+    # sums over this rank's samples: outputs in fp32 (fused convert-on-load, they can be large), the two log-prob
+    # scalars in fp64; small outputs ride in the same fp64 buffer so that a distributed step is ONE collective
+    n_out = sum(r[0].numel() for r in raw)
+    one_buffer = n_out <= 65536
+    acc_dt = torch.float64 if one_buffer else torch.float32
+    sums = [r.sum(0, dtype=acc_dt).reshape(-1) for r in raw]
+    if one_buffer:
+        packed = torch.cat(sums + [lp.sum(0)])
+        if distributed:
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        packed = packed / samples
+        out_part, lp_part = packed[:n_out], packed[n_out:]
+    else:
+        out_part, lp_part = torch.cat(sums) if len(sums) > 1 else sums[0], lp.sum(0)
+        if distributed:
+            dist.all_reduce(out_part, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(lp_part, op=dist.ReduceOp.SUM, group=group)
+        out_part, lp_part = out_part / samples, lp_part / samples
     means, off = [], 0
     for r in raw:
         n = r[0].numel()
-        means.append(packed[off:off + n].reshape(r.shape[1:]).to(r.dtype))
+        means.append(out_part[off:off + n].reshape(r.shape[1:]).to(r.dtype))
         off += n
-    log_prior, lvp = packed[off], packed[off + 1]
+    log_prior, lvp = lp_part[0], lp_part[1]
     if distributed and gather_raw:
         gathered = []
         for r in raw:

@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--samples", type=int, default=None, help="MC samples per GPU per step (default: workload's)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="capture the step in a HIP graph (device-resident sample counter); auto = on for the "
+                         "launch-bound single-layer / MLP workloads")
     return ap.parse_args()
 
 
@@ -251,6 +254,26 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # Launch-bound workloads (tens of microseconds of GPU work per step) are replayed from a HIP graph: the whole
+    # step — sampling, GEMMs, ELBO — is captured once; the Monte-Carlo sample counter lives on the device so every
+    # replay draws fresh epsilon (bayeformers_amd.use_device_counter).
+    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and
+                                       args.workload in ("linear768", "linear768_m32", "mlp"))
+    if use_graph:
+        bf.use_device_counter(True, device=device)
+        for _ in range(3):
+            step()  # builds plans / workspaces outside the capture
+        torch.cuda.synchronize()
+        static_out = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = step()
+        eager_step = step
+
+        def step():  # noqa: F811
+            graph.replay()
+            return static_out
+
     # Every step's ELBO lands in host-visible (pinned) memory through an asynchronous copy on the compute stream;
     # the host only waits once, after the K-th step, so consecutive steps are not serialised on a readback.
     elbo_host = torch.empty(max(args.steps, 1), dtype=torch.float64, pin_memory=True)
@@ -275,8 +298,9 @@ def main():
     lib.bf_profile_reset()
     lib.bf_profile_enable(1)
     prof_steps = max(1, min(args.steps, 5))
+    prof_step = eager_step if use_graph else step
     for _ in range(prof_steps):
-        step()
+        prof_step()
     torch.cuda.synchronize()
     lib.bf_profile_enable(0)
     prof = {}
@@ -311,7 +335,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
         total_samples = S * world * args.steps
-        cfgd.update({"parallelism": f"mc-sample-shard x{world}", "last_elbo": last})
+        cfgd.update({"parallelism": f"mc-sample-shard x{world}", "last_elbo": last, "hip_graph": bool(use_graph)})
         out = {"metric": "MC-samples/sec (fwd+ELBO)", "value": round(total_samples / dt, 3), "unit": "MC-samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",

@@ -60,6 +60,12 @@ typedef struct bf_tensor {
 int bf_version(void);
 const char* bf_last_error(void);
 
+/* Device-resident Monte-Carlo sample counter (optional, process-wide; NULL = off, the default).  While set, every
+ * kernel adds the uint32 at d_counter to its `sample_base` argument.  This is what makes a whole step capturable in
+ * a hipGraph: the graph bakes the host-side sample_base, and a captured one-element `counter += S` moves every
+ * replay on to fresh epsilon. */
+int bf_set_sample_counter(const uint32_t* d_counter);
+
 /* Number of compute units / name of the current device (diagnostics for bench.py). */
 int bf_device_info(char* name, size_t name_len, int* n_cu, int* wave_size);
 

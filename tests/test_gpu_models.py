@@ -164,3 +164,38 @@ def test_bert_large_qa_c5(golden_dir, dtype, tol):
     assert np.abs(end.mean(0) - g["end_mean"]).max() < tol * scale
     assert np.abs(start[0] - g["start_s0"]).max() < tol * scale
     assert np.abs(end[9] - g["end_s9"]).max() < tol * scale
+
+
+def test_hip_graph_replay_draws_fresh_samples():
+    """A step captured in a HIP graph with the device-resident sample counter: replay k == eager step k."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.ReLU(), torch.nn.Linear(96, 10))
+    bmodel = bf.to_bayesian(net, delta=0.05).cuda()
+    x = torch.randn(16, 64, device="cuda")
+
+    def step():
+        with torch.no_grad():
+            raw, mean, lp, lq = sample_bayesian(bmodel, x, 4)
+            return torch.cat([mean[0].double().reshape(-1), lp.reshape(1), lq.reshape(1)])
+
+    bf.manual_seed(SEED)
+    eager = [step().clone() for _ in range(5)]          # steps 0..4, host-side counter
+    try:
+        bf.use_device_counter(True)
+        bf.manual_seed(SEED)
+        for _ in range(2):
+            step()                                        # steps 0, 1 eagerly with the device counter
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = step()                                  # capture (does not execute)
+        got = []
+        for _ in range(3):                                # replays = steps 2, 3, 4
+            g.replay()
+            got.append(out.clone())
+        torch.cuda.synchronize()
+    finally:
+        bf.use_device_counter(False)
+    for k in range(3):
+        assert torch.equal(got[k], eager[2 + k]), k
+    assert not torch.equal(got[0], got[1])
