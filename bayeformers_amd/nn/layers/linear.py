@@ -137,6 +137,18 @@ class Linear(Module):
                 self._lp_own = torch.zeros((S, 2), dtype=torch.float64, device=input.device)
             slot = self._lp_own
         x2 = input.reshape(-1, self.in_features)
+        if x2.shape[0] == 0:
+            # empty batch: like the reference, the weights are still sampled and the log-probs refreshed
+            gs = [self.weight] + ([self.bias] if isinstance(self.bias, Gaussian) else [])
+            prs = [self.weight_prior] + ([self.bias_prior] if isinstance(self.bias, Gaussian) else [])
+            sids = [2 * self.layer_id + i for i in range(len(gs))]
+            _, lp = ops.sample_logprob(gs, prs, sids, S, bfr.STATE.seed, base)
+            slot.copy_(lp)
+            if ctx is None:
+                bfr.commit_samples(1)
+            self._lp_view = slot
+            self._lp_dirty = True
+            return input.new_empty(*input.shape[:-1], self.out_features)
         mu_b = self.bias.mu if isinstance(self.bias, Gaussian) else None
         rho_b = self.bias.rho if isinstance(self.bias, Gaussian) else None
         # the fused activation has no backward: when a gradient may be needed it runs as a separate op

@@ -188,3 +188,37 @@ def test_gemm_fused_gelu(S, M, N, K):
         y = ops.gemm_nt(x, w, bias, S, M, N, K, M * K, ydt, act=1)
         tol = 2.0 ** -8 if ydt == torch.bfloat16 else 1e-5
         assert (y.double() - ref).abs().max().item() <= tol * ref.abs().max().item() + 1e-5 * np.sqrt(K)
+
+
+def test_empty_and_ragged_inputs(cases):
+    c = load_case(cases, "mix_bias")
+    layer = layer_from_case(c)
+    bf.manual_seed(SEED, next_sample=0)
+    with torch.no_grad():
+        y = layer(torch.empty(0, 40, device="cuda"))
+    assert y.shape == (0, 24)
+    _, _, _, lp64, lq64, (mag_p, mag_q) = oracle_layer(c, 0)
+    assert float(layer.log_prior) == pytest.approx(lp64, abs=1e-5 * mag_p)      # fp32 attribute
+    assert float(layer.log_variational_posterior) == pytest.approx(lq64, abs=1e-5 * mag_q)
+    # rows not divisible by the sample count
+    model = bnn.Model(layer)
+    with torch.no_grad(), model.monte_carlo(3), pytest.raises(bf._C.BayeFormersAMDError, match="multiple of the sample count"):
+        model(torch.randn(7, 40, device="cuda"))
+    # 3-D input, batch of one row
+    with torch.no_grad():
+        y = layer(torch.randn(1, 1, 40, device="cuda"))
+    assert y.shape == (1, 1, 24)
+
+
+def test_many_samples_in_one_call(cases):
+    """S = 64 (config 4's sample count) in one launch: every sample equals its serial counterpart."""
+    c = load_case(cases, "moped")
+    x = torch.from_numpy(c["x"]).cuda()
+    layer = layer_from_case(c)
+    y, lp = run_layer(layer, x, 64, 1000)
+    for s in (0, 17, 63):
+        ys, lps = run_layer(layer, x, 1, 1000 + s)
+        assert torch.equal(ys[0], y[s]) and torch.equal(lps[0], lp[s])
+    _, _, _, lp64, lq64, (mag_p, mag_q) = oracle_layer(c, 1063)
+    assert float(lp[63, 0]) == pytest.approx(lp64, abs=LOGPROB_RTOL * mag_p)
+    assert float(lp[63, 1]) == pytest.approx(lq64, abs=LOGPROB_RTOL * mag_q)
