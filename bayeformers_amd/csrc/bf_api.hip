@@ -288,6 +288,11 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
                              (hipStream_t)stream);
 }
 
+int bf_kl_grad(const bf_tensor_t* tensor, int S, uint64_t seed, uint32_t sample_base, const double* d_g,
+               float* d_dmu, float* d_drho, void* stream) {
+    return bf_launch_kl_grad(tensor, S, seed, sample_base, d_g, d_dmu, d_drho, (hipStream_t)stream);
+}
+
 // workspace layout of bf_linear_bwd
 struct BwdLayout {
     size_t w, wt, dyt, xt, dw, db, lp, part, total;

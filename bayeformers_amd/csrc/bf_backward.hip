@@ -87,7 +87,106 @@ __global__ __launch_bounds__(256) void param_grad_kernel(const float* __restrict
     }
 }
 
+// Opt-in Bayes-by-Backprop gradient of the KL terms (the reference detaches them, layers/linear.py:99-102):
+//   L = sum_s gp[s] * log_prior_s + gq[s] * log_q_s,   W_s = mu + softplus(rho) * eps_s
+//   dL/dmu[e]  = sum_s gp[s] * score(W_s[e])
+//   dL/drho[e] = softplus'(rho[e]) * sum_s ( gp[s] * score(W_s[e]) * eps_s[e]  -  gq[s] / sigma[e] )
+// score(w) = d log p(w) / dw:  Gaussian prior -(w - mu_p) / sigma_p^2;  mixture -w * (r1/s1^2 + r2/s2^2) with the
+// responsibilities r_i of the two components.  eps regenerated from the Philox counter; thread = 4 scalars.
+struct KlParams {
+    const float* mu;
+    const float* rho;
+    const float* mu_p;
+    const float* rho_p;
+    const double* g;  // [S][2] = {dL/dlog_prior_s, dL/dlog_q_s}
+    float* dmu;
+    float* drho;
+    unsigned long long n;
+    float a1, b1, a2, b2;  // mixture: t_i = a_i w^2 + b_i (natural log), a_i = -1/(2 s_i^2)
+    int prior;
+    int S;
+    uint32_t k0, k1, sample_base, stream;
+    const uint32_t* counter;
+};
+
+__global__ __launch_bounds__(256) void kl_grad_kernel(const KlParams p) {
+    const unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long e0 = g * 4;
+    if (e0 >= p.n) return;
+    const int nv = p.n - e0 >= 4 ? 4 : (int)(p.n - e0);
+    const uint32_t base = p.sample_base + (p.counter ? *p.counter : 0u);
+    float mu[4], sg[4], dsp[4], pmu[4], pinv2[4], am[4] = {0.f, 0.f, 0.f, 0.f}, ar[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) {
+        const bool ok = i < nv;
+        mu[i] = ok ? p.mu[e0 + i] : 0.f;
+        const float r = ok ? p.rho[e0 + i] : 0.f;
+        const float zr = expf(r);
+        sg[i] = r > 20.0f ? r : log1pf(zr);
+        dsp[i] = r > 20.0f ? 1.0f : zr / (zr + 1.0f);
+        pmu[i] = 0.f;
+        pinv2[i] = 0.f;
+        if (p.prior == BF_PRIOR_GAUSSIAN && ok) {
+            const float rp = p.rho_p[e0 + i];
+            const float sp = rp > 20.0f ? rp : log1pf(expf(rp));
+            pmu[i] = p.mu_p[e0 + i];
+            pinv2[i] = 1.0f / (sp * sp);
+        }
+    }
+    for (int s = 0; s < p.S; ++s) {
+        const float gp = (float)p.g[2 * s], gq = (float)p.g[2 * s + 1];
+        float z[4];
+        bf_normal4_dev((uint32_t)g, (uint32_t)(g >> 32), base + (uint32_t)s, p.stream, p.k0, p.k1, z);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float w = fmaf(sg[i], z[i], mu[i]);
+            float score = 0.f;
+            if (p.prior == BF_PRIOR_GAUSSIAN) {
+                score = -(w - pmu[i]) * pinv2[i];
+            } else if (p.prior == BF_PRIOR_MIXTURE) {
+                const float w2 = w * w;
+                const float t1 = fmaf(p.a1, w2, p.b1), t2 = fmaf(p.a2, w2, p.b2);
+                const float m = fmaxf(t1, t2);
+                const float e1 = expf(t1 - m), e2 = expf(t2 - m);
+                const float r1 = e1 / (e1 + e2);
+                // 1/s_i^2 = -2 a_i
+                score = 2.0f * w * (r1 * p.a1 + (1.0f - r1) * p.a2);
+            }
+            am[i] = fmaf(gp, score, am[i]);
+            ar[i] += gp * score * z[i] - gq / sg[i];
+        }
+    }
+    for (int i = 0; i < nv; ++i) {
+        if (p.dmu) p.dmu[e0 + i] = am[i];
+        p.drho[e0 + i] = ar[i] * dsp[i];
+    }
+}
+
 }  // namespace
+
+int bf_launch_kl_grad(const bf_tensor_t* t, int S, uint64_t seed, uint32_t sample_base, const double* d_g,
+                      float* d_dmu, float* d_drho, hipStream_t stream) {
+    if (!t || !t->d_mu || !t->d_rho || !d_g || !d_drho) BF_FAIL("bf_kl_grad: NULL argument");
+    if (t->n == 0 || S < 1) BF_FAIL("bf_kl_grad: empty");
+    KlParams p{};
+    p.mu = t->d_mu; p.rho = t->d_rho; p.mu_p = t->prior.d_mu; p.rho_p = t->prior.d_rho;
+    p.g = d_g; p.dmu = d_dmu; p.drho = d_drho; p.n = t->n; p.prior = t->prior.kind; p.S = S;
+    p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32); p.sample_base = sample_base; p.stream = t->stream_id;
+    p.counter = bf_sample_counter();
+    if (p.prior == BF_PRIOR_MIXTURE) {
+        const double pi = t->prior.pi, s1 = t->prior.sigma1, s2 = t->prior.sigma2;
+        if (!(s1 > 0.0) || !(s2 > 0.0) || !(pi >= 0.0) || !(pi <= 1.0)) BF_FAIL("bf_kl_grad: bad mixture prior");
+        p.a1 = (float)(-0.5 / (s1 * s1));
+        p.a2 = (float)(-0.5 / (s2 * s2));
+        p.b1 = (float)(log(pi) - log(s1));
+        p.b2 = (float)(log1p(-pi) - log(s2));
+    } else if (p.prior == BF_PRIOR_GAUSSIAN && (!p.mu_p || !p.rho_p)) {
+        BF_FAIL("bf_kl_grad: gaussian prior needs d_mu/d_rho");
+    }
+    const uint64_t groups = (t->n + 3) / 4;
+    hipLaunchKernelGGL(kl_grad_kernel, dim3((uint32_t)((groups + 255) / 256)), dim3(256), 0, stream, p);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int bf_launch_transpose(const void* d_in, void* d_out, int elem_size, int batch, int rows, int cols, hipStream_t stream) {
     if (!d_in || !d_out) BF_FAIL("bf_transpose: NULL argument");

@@ -84,3 +84,5 @@ size_t bf_fused_small_partial_rows(int N);
 int bf_launch_fused_small(const void* d_x, int x_dtype, int64_t x_sample_stride, const bf_tensor_t* weight,
                           const bf_tensor_t* bias, void* d_y, int compute_dtype, int S, int M, int N, int K, uint64_t seed,
                           uint32_t sample_base, double* d_partials, hipStream_t stream);
+int bf_launch_kl_grad(const bf_tensor_t* t, int S, uint64_t seed, uint32_t sample_base, const double* d_g,
+                      float* d_dmu, float* d_drho, hipStream_t stream);

@@ -29,7 +29,8 @@ def _backward(ctx, grad):
     (x,) = ctx.saved_tensors
     layer, S, seed, base, cdt = ctx.layer, ctx.S, ctx.seed, ctx.base, ctx.cdt
     need_x, need_mu_w, _, need_mu_b, _ = ctx.needs_input_grad[:5]
-    return ops.linear_backward(layer, x, grad, S, seed, base, cdt, need_x, need_mu_w, need_mu_b)
+    with bfr.counter_override(ctx.counter):
+        return ops.linear_backward(layer, x, grad, S, seed, base, cdt, need_x, need_mu_w, need_mu_b)
 
 
 class _LinearFn(torch.autograd.Function):
@@ -40,6 +41,7 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, layer, S, seed, base, lp_out):
         ctx.layer, ctx.S, ctx.seed, ctx.base = layer, S, seed, base
+        ctx.counter = bfr.counter_snapshot()
         ctx.cdt = layer.compute_dtype or bfr.get_compute_dtype()
         ctx.save_for_backward(x)
         return ops.linear_forward(layer, x, S, seed, base, lp_out)
@@ -56,6 +58,7 @@ class _PlannedLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, w_s, b_s, layer, S, seed, base, act):
         ctx.layer, ctx.S, ctx.seed, ctx.base = layer, S, seed, base
+        ctx.counter = bfr.counter_snapshot()
         ctx.cdt = w_s.dtype
         ctx.save_for_backward(x)
         return ops.planned_linear_forward(x, w_s, b_s, S, layer.out_features, layer.in_features, act)

@@ -48,6 +48,33 @@ class _ForwardContext:
         return self._slots.get(id(layer))
 
 
+class _KLFn(torch.autograd.Function):
+    """[S, 2] per-sample {log_prior, log_q} of the model as a differentiable function of every layer's mu and rho
+    (opt-in, bayeformers_amd.set_kl_gradient).  Backward = one bf_kl_grad launch per parameter tensor."""
+
+    @staticmethod
+    def forward(ctx, lp, model, S, seed, base, counter, *params):
+        ctx.model, ctx.S, ctx.seed, ctx.base, ctx.counter = model, S, seed, base, counter
+        return lp.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import ops
+        from .parameters.gaussian import Gaussian
+
+        g = g.to(torch.float64).contiguous()
+        grads = []
+        with bfr.counter_override(ctx.counter):
+            for layer in ctx.model.fused_children():
+                pairs = [(layer.weight, layer.weight_prior, 2 * layer.layer_id)]
+                if isinstance(layer.bias, Gaussian):
+                    pairs.append((layer.bias, layer.bias_prior, 2 * layer.layer_id + 1))
+                for gauss, prior, sid in pairs:
+                    dmu, drho = ops.kl_grad(gauss, prior, sid, ctx.S, ctx.seed, ctx.base, g, gauss.mu.requires_grad)
+                    grads += [dmu, drho if gauss.rho.requires_grad else None]
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
 class Model(Module):
     """Wrapper gathering log_prior and log_variational_posterior from Bayesian children.
 
@@ -99,7 +126,8 @@ class Model(Module):
         rank, world = self._mc_shard
         # every rank reserves the GLOBAL S*world indices and runs its own contiguous slice of them
         base = bfr.reserve_samples(S * world) + rank * S
-        self._last_base = base
+        self._last_base, self._last_seed, self._last_S = base, bfr.STATE.seed, S
+        self._last_counter = bfr.counter_snapshot() if bfr.STATE.kl_gradient else None
         bfr.STATE.ctx = _ForwardContext(base, S, slots, plan, self._lp_buf)
         try:
             return super(Model, self).__call__(*args, **kwargs)
@@ -148,6 +176,8 @@ class Model(Module):
             warnings.warn("No Bayesian Child is present in this model")
         if len(children) and self._lp_buf is not None and self._only_fused():
             # one reduction over the [L, S, 2] buffer the kernels wrote: sum over layers, mean over samples
+            if bfr.STATE.kl_gradient and torch.is_grad_enabled():
+                return self.log_prob_samples()[:, index].mean().to(torch.float32)
             return self._lp_buf[:, :, index].sum(0).mean().to(torch.float32)
         value = 0.0
         for child in children:
@@ -162,11 +192,28 @@ class Model(Module):
         """Sum of the children's log_variational_posterior (model.py:81-89); mean over the S samples."""
         return self._sum(1, "log_variational_posterior")
 
+    def _kl_params(self):
+        from .parameters.gaussian import Gaussian
+
+        params = []
+        for layer in self.fused_children():
+            params += [layer.weight.mu, layer.weight.rho]
+            if isinstance(layer.bias, Gaussian):
+                params += [layer.bias.mu, layer.bias.rho]
+        return params
+
     def log_prob_samples(self) -> Tensor:
-        """[S, 2] float64: per-sample {log_prior, log_variational_posterior} summed over the fused layers."""
+        """[S, 2] float64: per-sample {log_prior, log_variational_posterior} summed over the fused layers.
+
+        Detached, as in the reference, unless bayeformers_amd.set_kl_gradient(True): then the result carries the
+        Bayes-by-Backprop gradient w.r.t. every layer's mu and rho."""
         if self._lp_buf is None:
             raise RuntimeError("no forward has run yet")
-        return self._lp_buf.sum(0)
+        lp = self._lp_buf.sum(0)
+        if bfr.STATE.kl_gradient and torch.is_grad_enabled() and self._only_fused():
+            lp = _KLFn.apply(lp, self, self._last_S, self._last_seed, self._last_base, self._last_counter,
+                             *self._kl_params())
+        return lp
 
     def log_prior_samples(self) -> Tensor:
         return self.log_prob_samples()[:, 0]

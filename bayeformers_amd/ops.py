@@ -243,3 +243,17 @@ def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_
     if dx is not None and dx.dtype != x.dtype:
         dx = dx.to(x.dtype)
     return dx, dmu_w, drho_w, dmu_b, drho_b
+
+
+def kl_grad(gaussian, prior, stream_id: int, S: int, seed: int, sample_base: int, g: Tensor, need_mu: bool):
+    """Gradient of sum_s g[s,0]*log_prior_s + g[s,1]*log_q_s w.r.t. one Gaussian's (mu, rho) (bf_kl_grad)."""
+    t = _C.bf_tensor_t()
+    if not fill_tensor(t, gaussian, prior, stream_id):
+        raise _C.BayeFormersAMDError("kl_grad: user-defined priors have no kernel gradient")
+    dev = gaussian.mu.device
+    dmu = torch.empty_like(gaussian.mu, dtype=torch.float32) if need_mu else None
+    drho = torch.empty_like(gaussian.rho, dtype=torch.float32)
+    _C.check(_C.lib().bf_kl_grad(ctypes.byref(t), S, seed, sample_base & 0xFFFFFFFF, g.data_ptr(),
+                                 dmu.data_ptr() if dmu is not None else None, drho.data_ptr(), _stream_ptr()),
+             "bf_kl_grad")
+    return dmu, drho

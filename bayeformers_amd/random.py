@@ -28,6 +28,7 @@ class _State(threading.local):
         self.compute_dtype = torch.bfloat16
         self.next_layer_id = 0
         self.device_counter = None  # 1-element int32 device tensor when the sample counter lives on the GPU
+        self.kl_gradient = False    # opt-in Bayes-by-Backprop gradient of the KL terms (the reference has none)
 
 
 STATE = _State()
@@ -97,3 +98,34 @@ def new_layer_id() -> int:
     i = STATE.next_layer_id
     STATE.next_layer_id += 1
     return i
+
+
+def set_kl_gradient(enable: bool = True) -> None:
+    """Make `Model.log_prior()` / `log_variational_posterior()` differentiable w.r.t. mu and rho (bf_kl_grad).
+
+    Off by default: the reference stores its log-probs with `.data =` (layers/linear.py:99-102), so its ELBO only
+    trains the likelihood term; switching this on gives the gradient the ELBO formula implies (Blundell et al.)."""
+    STATE.kl_gradient = bool(enable)
+
+
+def counter_snapshot():
+    """In device-counter mode: a copy of the counter as the forward saw it (backward regenerates the same eps)."""
+    return STATE.device_counter.clone() if STATE.device_counter is not None else None
+
+
+class counter_override:
+    """Temporarily point the kernels at a saved counter value (used by backward passes)."""
+
+    def __init__(self, snapshot):
+        self.snapshot = snapshot
+
+    def __enter__(self):
+        if self.snapshot is not None:
+            from . import _C
+            _C.check(_C.lib().bf_set_sample_counter(self.snapshot.data_ptr()), "bf_set_sample_counter")
+
+    def __exit__(self, *exc):
+        if self.snapshot is not None:
+            from . import _C
+            cur = STATE.device_counter
+            _C.check(_C.lib().bf_set_sample_counter(cur.data_ptr() if cur is not None else None), "bf_set_sample_counter")

@@ -148,6 +148,16 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
                   float* d_drho_b, int S, int M, int N, int K, uint64_t seed, uint32_t sample_base, void* d_workspace,
                   size_t workspace_bytes, void* stream);
 
+/* Opt-in Bayes-by-Backprop gradient of the KL terms.  The reference detaches its log-probs (layers/linear.py:99-102
+ * store them with `.data =`), so `loss = (lvp - log_prior)/n_batches + nll` (bert_glue.py:235) trains the likelihood
+ * only; this entry gives the gradient the formula implies.  For one tensor t and S samples, with
+ *   L = sum_s d_g[s][0] * log_prior_s + d_g[s][1] * log_q_s,   W_s = mu + softplus(rho) * eps_s:
+ *   d_dmu[e]  = sum_s g_p[s] * score(W_s[e]),                        score = d log prior / dw
+ *   d_drho[e] = softplus'(rho[e]) * sum_s (g_p[s] * score(W_s[e]) * eps_s[e] - g_q[s] / sigma[e]).
+ * eps is regenerated from the Philox counter.  d_dmu may be NULL.  Gradients are written, not accumulated. */
+int bf_kl_grad(const bf_tensor_t* tensor, int S, uint64_t seed, uint32_t sample_base, const double* d_g,
+               float* d_dmu, float* d_drho, void* stream);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * While enabled, every sampling launch (kind BF_PROF_SAMPLE) and every GEMM launch (BF_PROF_GEMM) made through
  * this library is bracketed by two events; bf_profile_read() synchronises them and returns, per kind, the number

@@ -86,3 +86,60 @@ def test_backward_through_a_small_mlp_is_finite_and_deterministic():
     assert len(grads[0]) == 8  # mu and rho of two weights and two biases
     for a, b in zip(*grads):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["mix_bias", "moped"])
+def test_kl_gradient_opt_in_matches_autograd_of_the_closed_forms(golden_dir, name):
+    """set_kl_gradient(True): d/d(mu,rho) of sum_s a_s*log_prior_s + b_s*log_q_s == torch autograd through the
+    oracle's fp64 closed forms with the same Philox epsilon (the reference itself has no such gradient)."""
+    from oracle import bayes_oracle as bo
+    from util import layer_from_case, oracle_priors
+
+    g = np.load(f"{golden_dir}/linear_cases.npz")
+    c = load_case(g, name)
+    S, base = 3, 40
+    layer = layer_from_case(c)
+    for p_ in (layer.weight.mu, layer.weight.rho, layer.bias.mu, layer.bias.rho):
+        p_.requires_grad_(True)
+    model = bnn.Model(layer)
+    coef = torch.tensor([[0.7, -1.3], [-0.2, 0.9], [1.1, 0.4]], dtype=torch.float64, device="cuda")
+    x = torch.from_numpy(c["x"]).cuda().repeat(S, 1)
+    bf.manual_seed(SEED, next_sample=base)
+    bf.set_kl_gradient(True)
+    try:
+        with model.monte_carlo(S):
+            model(x)
+        lps = model.log_prob_samples()
+        assert lps.requires_grad
+        (lps * coef).sum().backward()
+    finally:
+        bf.set_kl_gradient(False)
+    assert not model.log_prob_samples().requires_grad  # default: detached, like the reference
+
+    # oracle: differentiable fp64 closed forms
+    t = lambda k: torch.from_numpy(c[k]).double().requires_grad_(True)
+    mu_w, rho_w, mu_b, rho_b = t("w_mu"), t("w_rho"), t("b_mu"), t("b_rho")
+    pw, pb = oracle_priors(c)
+    total = 0.0
+    for s in range(S):
+        for mu, rho, pr, tid in ((mu_w, rho_w, pw, 0), (mu_b, rho_b, pb, 1)):
+            eps = bo.eps_tensor(mu.shape, SEED, base + s, 0, tid).double()
+            sig = torch.nn.functional.softplus(rho)
+            w = mu + eps * sig
+            lq = (-bo.LOG_SQRT_2PI - torch.log(sig) - 0.5 * eps ** 2).sum()
+            if pr[0] == "mixture":
+                lp = bo.mixture_log_prob_terms_f64(w, *pr[1:]).sum()
+            else:
+                sp = torch.nn.functional.softplus(pr[2].double())
+                lp = (-bo.LOG_SQRT_2PI - torch.log(sp) - (w - pr[1].double()) ** 2 / (2 * sp ** 2)).sum()
+            total = total + coef[s, 0].item() * lp + coef[s, 1].item() * lq
+    total.backward()
+    for got, ref, what in ((layer.weight.mu.grad, mu_w.grad, "dmu_w"), (layer.weight.rho.grad, rho_w.grad, "drho_w"),
+                           (layer.bias.mu.grad, mu_b.grad, "dmu_b"), (layer.bias.rho.grad, rho_b.grad, "drho_b")):
+        scale = ref.abs().max().item()
+        # the mixture's score changes by ~1e5 per unit of w around the component crossover (|w| ~ 0.0086): an
+        # fp32 ulp of w there is worth ~1e-4 of gradient, so the mixture case gets a looser bound
+        tol = 2e-3 if pr[0] == "mixture" else 2e-5
+        err = (got.double().cpu() - ref).abs()
+        assert err.max().item() <= tol * scale, what
+        assert (err > 2e-5 * scale).double().mean().item() < 0.1, what  # only the few values near the crossover
