@@ -143,3 +143,32 @@ def test_kl_gradient_opt_in_matches_autograd_of_the_closed_forms(golden_dir, nam
         err = (got.double().cpu() - ref).abs()
         assert err.max().item() <= tol * scale, what
         assert (err > 2e-5 * scale).double().mean().item() < 0.1, what  # only the few values near the crossover
+
+
+def test_training_loop_reduces_the_elbo():
+    """End to end: to_bayesian(MLP) trained for a few steps with the reference's recipe (examples/mlp_mnist.py:
+    mean prediction over S samples, loss = (lvp - log_prior)/n_batches + nll) and the opt-in KL gradient."""
+    from bayeformers_amd.sampling import elbo, sample_bayesian
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.ReLU(), torch.nn.Linear(64, 4), torch.nn.LogSoftmax(dim=1))
+    bmodel = bf.to_bayesian(net, delta=0.05).cuda()
+    x = torch.randn(256, 32, device="cuda")
+    labels = (x[:, :4].argmax(1)).long()
+    opt = torch.optim.Adam([p for p in bmodel.parameters() if p.requires_grad], lr=2e-2)
+    bf.manual_seed(SEED)
+    bf.set_kl_gradient(True)
+    losses = []
+    try:
+        for _ in range(30):
+            opt.zero_grad()
+            raw, mean, lp, lq = sample_bayesian(bmodel, x, 4)
+            nll = torch.nn.functional.nll_loss(mean[0], labels, reduction="sum")
+            loss = elbo(lp, lq, nll.double(), 10)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+    finally:
+        bf.set_kl_gradient(False)
+    assert all(np.isfinite(losses))
+    assert losses[-1] < 0.85 * losses[0], (losses[0], losses[-1])
