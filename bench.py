@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--samples", type=int, default=None, help="MC samples per GPU per step (default: workload's)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="capture the step in a HIP graph (device-resident sample counter); auto = on for the "
                          "launch-bound single-layer / MLP workloads")
@@ -219,6 +220,67 @@ def make_mlp(device, S, dtype):
                                 "batch": 128}, bmodel
 
 
+def alg_gemm_bytes(bmodel, cfgd, S, dtype):
+    """Algorithmic HBM bytes per 256x256-tile GEMM launch: S*(M*K + N*K + M*N)*elem, averaged over the Bayesian
+    linears that take that kernel (M = rows per sample >= 128)."""
+    es = 4 if dtype == "fp32" else 2
+    M = cfgd.get("batch", 1) * cfgd.get("seq_len", 1)
+    if M < 128:
+        return None
+    tot = [S * (M * l.in_features + l.out_features * l.in_features + M * l.out_features) * es
+           for l in bmodel.fused_children() if not l._small_m]
+    return round(sum(tot) / len(tot)) if tot else None
+
+
+def measure_traffic(args):
+    """roofline.traffic: HBM bytes per GEMM launch from the PMC counters, collected as MI355X_MICROARCH.md's HBM
+    section prescribes — FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (kernel-trace only) over a short
+    run of this same workload, values in KiB, FETCH_SIZE doubled (gfx950 reports half the bytes of wide 16 B/lane
+    reads, which is what the LDS-DMA loads are; calibrated here on the sampling kernel's known 16 B/scalar reads),
+    WRITE_SIZE as is for the 16-byte epilogue stores (calibrated on their known byte count).  Returns None if the
+    profiler is unavailable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="bf_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "t", "--",
+                   sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-traffic", "--graph", "off"]
+            if args.samples:
+                cmd += ["--samples", str(args.samples)]
+            if args.dtype:
+                cmd += ["--dtype", args.dtype]
+            env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            vals = []
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if "gemm256" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None
+            out[counter] = sum(vals) / len(vals) * 1024.0
+        return {"bytes_per_launch": 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"], "fetch_bytes": 2.0 * out["FETCH_SIZE"],
+                "write_bytes": out["WRITE_SIZE"]}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -321,7 +383,7 @@ def main():
             esz = 4 if dtype == "fp32" else 2
             sbytes = float(plan.scalars) * (per_read + S * esz) * prof_steps
         tflops = gflop / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (sampled-weight GEMM, all Bayesian linears)",
+        roofline = {"bound": "mfma", "kernel": "gemm256_persist_kernel (sampled-weight GEMM; mean over all Bayesian linears of the step)",
                     "achieved": round(tflops, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tflops / PEAK_TFLOPS, 4), "traffic": None,
                     "launches_per_step": gn // prof_steps, "avg_launch_us": round(1e3 * gms / max(gn, 1), 2),
@@ -334,6 +396,13 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
+        if world == 1 and not args.no_traffic and gn > 0:
+            tr = measure_traffic(args)
+            if tr is not None:
+                roofline["traffic"] = round(tr["bytes_per_launch"])
+                roofline["traffic_detail"] = {"unit": "bytes per GEMM launch (mean over the step's launches)",
+                                              "hbm_fetch": round(tr["fetch_bytes"]), "hbm_write": round(tr["write_bytes"]),
+                                              "algorithmic": alg_gemm_bytes(bmodel, cfgd, S, dtype)}
         total_samples = S * world * args.steps
         cfgd.update({"parallelism": f"mc-sample-shard x{world}", "last_elbo": last, "hip_graph": bool(use_graph)})
         out = {"metric": "MC-samples/sec (fwd+ELBO)", "value": round(total_samples / dt, 3), "unit": "MC-samples/s",
