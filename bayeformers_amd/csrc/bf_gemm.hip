@@ -22,7 +22,7 @@ namespace {
 // developer knob: BF_GEMM_VARIANT=0 forces the generic kernel (read on every call; a getenv is ~50 ns)
 int gemm_variant() {
     const char* v = getenv("BF_GEMM_VARIANT");
-    return v ? atoi(v) : 3;  // 3 = persistent ping-pong (default), 2 = ping-pong, 1 = lockstep, 0 = generic
+    return v ? atoi(v) : 1;  // 0 = force the generic kernel, anything else = the 256x256x64 persistent ping-pong kernel
 }
 
 template <typename T>
@@ -306,7 +306,7 @@ int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, con
     const int variant = gemm_variant();
     if (variant != 0 && (long long)M * N >= 128 * 128 && ((uintptr_t)d_bias & 15) == 0 &&
         bf_gemm256_supported(x_dtype, w_dtype, y_dtype, S, M, N, K, d_x, d_w, x_sample_stride))
-        return bf_launch_gemm256(p, w_dtype, y_dtype, variant, stream);
+        return bf_launch_gemm256(p, w_dtype, y_dtype, stream);
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
     const size_t xs = bf_dtype_size(x_dtype);

@@ -26,7 +26,6 @@ constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int ROW_BYTES = TK * 2;                 // 128
 constexpr int X_BYTES = TM * ROW_BYTES;           // 32 KiB
 constexpr int STAGE_BYTES = (TM + TN) * ROW_BYTES;  // 64 KiB
-constexpr int SMEM_BYTES = 256 * (512 + 16);        // k-loop needs 2 stages = 128 KiB, the epilogue tile 132 KiB
 
 template <typename T>
 struct Mfma16;
@@ -51,25 +50,6 @@ typedef const __attribute__((address_space(1))) void glb_void;
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
     // 64 lanes x 16 B: lane i lands at lds_wave_base + 16*i (wave-uniform base)
     __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
-}
-
-template <typename YT>
-__device__ __forceinline__ void store4(YT* y, long long m, int n, int M, int N, f32x4_t v, bool vec_ok) {
-    if (m >= M || n >= N) return;
-    YT* o = y + m * (long long)N + n;
-    if (vec_ok && n + 3 < N) {
-        if constexpr (sizeof(YT) == 4) {
-            *reinterpret_cast<f32x4_t*>(o) = v;
-        } else if constexpr (__is_same(YT, __bf16)) {
-            *reinterpret_cast<bf16x4_t*>(o) = __builtin_convertvector(v, bf16x4_t);
-        } else {
-            *reinterpret_cast<f16x4_t*>(o) = __builtin_convertvector(v, f16x4_t);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n + j < N) o[j] = (YT)v[j];
-    }
 }
 
 
@@ -116,178 +96,19 @@ __device__ __forceinline__ void tile_coords(unsigned lt, int tiles_m, int tiles_
     tm = grp * 4 + (in - tn * gm);
 }
 
-// Epilogue: accumulators (+bias) -> LDS as a row-major [256][256] tile of YT -> whole-row 16-byte global stores.
-// A lane's fragment registers are 4 consecutive n of one m (8 B for 16-bit outputs): written with ds_write_b64 into
-// rows padded by 16 B (2-way bank aliasing only), then every wave streams 32 rows back with ds_read_b128 and stores
-// them with dwordx4 (512 contiguous bytes per row for bf16).  fp32 outputs take two passes of 128 rows.
+// Epilogue: accumulators -> LDS as row-major rows of YT (in passes, see epilogue_passes) -> whole-row 16-byte global
+// stores.  A lane's fragment registers are 4 consecutive n of one m (8 B for 16-bit outputs): written with
+// ds_write_b64 into rows padded by 16 B (2-way bank aliasing only), then every wave streams rows back with
+// ds_read_b128 and stores them with dwordx4 (512 contiguous bytes per row for bf16).
 constexpr int EPI_PAD = 16;
 #ifndef BF_NT_STORES
 #define BF_NT_STORES 1
 #endif
 constexpr bool NT_STORES = BF_NT_STORES;
-template <typename YT>
-__device__ __forceinline__ void epilogue_via_lds(char* smem, const f32x4_t (&acc)[4][8], const float* bias, YT* y,
-                                                 int m0, int n0, int M, int N, int wm, int wn, int wid, int lane,
-                                                 int act) {
-    constexpr int ROW = TN * (int)sizeof(YT) + EPI_PAD;
-    constexpr int PASSES = sizeof(YT) == 4 ? 2 : 1;
-    constexpr int ROWS_PER_PASS = TM / PASSES;
-    const bool vec_ok = (N % (16 / (int)sizeof(YT))) == 0 && ((uintptr_t)y % 16) == 0;
-#pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-        __builtin_amdgcn_s_barrier();  // LDS is free: k-loop reads (pass 0) / previous pass's row reads are done
-        if (PASSES == 1 || wm == pass) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const int nl = wn * 64 + nb * 16 + (lane >> 4) * 4;
-#pragma unroll
-                for (int mb = 0; mb < 8; ++mb) {
-                    const int ml = (PASSES == 1 ? wm * 128 : 0) + mb * 16 + (lane & 15);
-                    const f32x4_t v = bf_apply_act(acc[nb][mb], act);
-                    char* dst = smem + ml * ROW + nl * (int)sizeof(YT);
-                    if constexpr (sizeof(YT) == 4)
-                        *reinterpret_cast<f32x4_t*>(dst) = v;
-                    else if constexpr (__is_same(YT, __bf16))
-                        *reinterpret_cast<bf16x4_t*>(dst) = __builtin_convertvector(v, bf16x4_t);
-                    else
-                        *reinterpret_cast<f16x4_t*>(dst) = __builtin_convertvector(v, f16x4_t);
-                }
-            }
-        }
-        __builtin_amdgcn_s_barrier();
-        // stream rows out: one 16-byte chunk per lane
-        constexpr int CHUNKS = TN * (int)sizeof(YT) / 16;       // 32 (16-bit) or 64 (fp32) chunks per row
-        constexpr int ROWS_PER_INST = 64 / CHUNKS > 0 ? 64 / CHUNKS : 1;
-        constexpr int INST_PER_ROW = CHUNKS > 64 ? CHUNKS / 64 : 1;
-        constexpr int ROWS_PER_WAVE = ROWS_PER_PASS / 8;
-        constexpr int EPC = 16 / (int)sizeof(YT);              // elements per chunk
-#pragma unroll 4
-        for (int it = 0; it < ROWS_PER_WAVE / ROWS_PER_INST * INST_PER_ROW; ++it) {
-            const int rl = wid * ROWS_PER_WAVE + (it / INST_PER_ROW) * ROWS_PER_INST + (CHUNKS < 64 ? lane / CHUNKS : 0);
-            const int q = (CHUNKS < 64 ? lane % CHUNKS : lane) + (it % INST_PER_ROW) * 64;
-            const long long m = (long long)m0 + pass * ROWS_PER_PASS + rl;
-            const int n = n0 + q * EPC;
-            if (m < M && n < N) {
-                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(smem + rl * ROW + q * 16);
-                YT* o = y + m * N + n;
-                if (vec_ok && n + EPC <= N) {
-                    *reinterpret_cast<f32x4_t*>(o) = v;
-                } else {
-                    const YT* e = reinterpret_cast<const YT*>(&v);
-                    for (int j = 0; j < EPC; ++j)
-                        if (n + j < N) o[j] = e[j];
-                }
-            }
-        }
-    }
-}
-
-template <typename T, typename YT>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
-    using frag = typename Mfma16<T>::frag;
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
-    const int M = p.M, N = p.N, K = p.K;
-
-    // tile = (s, tn, tm), tm fastest: consecutive logical tiles share the W_s n-panel
-    const unsigned per_s = (unsigned)(p.tiles_m * p.tiles_n);
-    const unsigned lt = xcd_remap(blockIdx.x, gridDim.x);
-    const int s = lt / per_s;
-    const unsigned rem = lt - s * per_s;
-    const int tn = rem / p.tiles_m, tm = rem - tn * p.tiles_m;
-    const int m0 = tm * TM, n0 = tn * TN;
-
-    const T* x = reinterpret_cast<const T*>(p.x) + (long long)s * p.x_sstride;
-    const T* w = reinterpret_cast<const T*>(p.w) + (long long)s * N * K;
-
-    // ---- DMA source addressing.  Instruction i of wave `wid` fills rows rb*8 .. rb*8+7, rb = i*8 + wid:
-    // lane -> row rb*8 + (lane>>3), chunk position lane&7, which holds source chunk pos ^ ((row>>1)&7).
-    const int prow = lane >> 3;
-    const int kc = (lane & 7) ^ ((((wid & 1) << 2) + (lane >> 4)) & 7);
-    const T* xsrc[4];
-    const T* wsrc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (i * 8 + wid) * 8 + prow;
-        xsrc[i] = x + (long long)min(m0 + row, M - 1) * K + kc * 8;
-        wsrc[i] = w + (long long)min(n0 + row, N - 1) * K + kc * 8;
-    }
-    auto stage = [&](int kt, int buf) {
-        char* base = smem + buf * STAGE_BYTES;
-        const int k = kt * TK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(xsrc[i] + k, base + (i * 8 + wid) * 1024);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(wsrc[i] + k, base + X_BYTES + (i * 8 + wid) * 1024);
-    };
-
-    // ---- fragment read addressing (swizzle depends on lane only: tile row offsets are multiples of 16)
-    const int fsw = (lane >> 1) & 7;
-    const int foff0 = (lane & 15) * ROW_BYTES + ((((lane >> 4)) ^ fsw) << 4);
-    const int foff1 = (lane & 15) * ROW_BYTES + (((4 + (lane >> 4)) ^ fsw) << 4);
-    const int xfrag_base = wm * 128 * ROW_BYTES;
-    const int wfrag_base = X_BYTES + wn * 64 * ROW_BYTES;
-
-    f32x4_t acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = K / TK;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        // tile kt has landed for every wave, and every wave is done reading the other buffer
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        const char* sb = smem + buf * STAGE_BYTES;
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            const int fo = kh ? foff1 : foff0;
-            frag wf[4], xf[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                wf[i] = *reinterpret_cast<const frag*>(sb + wfrag_base + i * 16 * ROW_BYTES + fo);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                xf[j] = *reinterpret_cast<const frag*>(sb + xfrag_base + j * 16 * ROW_BYTES + fo);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
-        }
-    }
-
-    // ---- epilogue: lane holds y[m][n .. n+3] for m = col of the fragment
-    YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
-    const float* bias = p.bias ? p.bias + (long long)s * N : nullptr;
-    const bool vec_ok = (N % 4) == 0 && ((uintptr_t)p.y % 16) == 0;
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        const int n = n0 + wn * 64 + nb * 16 + (lane >> 4) * 4;
-        f32x4_t b = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (n + j < N) b[j] = bias[n + j];
-        }
-#pragma unroll
-        for (int mb = 0; mb < 8; ++mb) {
-            const long long m = m0 + wm * 128 + mb * 16 + (lane & 15);
-            store4<YT>(y, m, n, M, N, bf_apply_act(acc[nb][mb] + b, p.act), vec_ok);
-        }
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------------------
-// Ping-pong variant.  The two waves that share a SIMD belong to different wave groups (G0 = waves 0-3 = rows
-// 0..127 of the tile, G1 = waves 4-7 = rows 128..255) and run the same slot sequence one slot apart:
+// The kernel: persistent ping-pong.
+// The two waves that share a SIMD belong to different wave groups (G0 = waves 0-3 = rows 0..127 of the tile,
+// G1 = waves 4-7 = rows 128..255) and run the same slot sequence one slot apart:
 //
 //      slot:   4t        4t+1      4t+2      4t+3      4t+4
 //      G0:     L0(t)     M0(t)     L1(t)     M1(t)     L0(t+1) ...
@@ -295,137 +116,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 //
 // L = 12 ds_read_b128 (the fragments of one 32-deep half of the k-tile) + lgkmcnt(0); M = 32 MFMAs on registers.
 // Every slot ends in one workgroup barrier, so a SIMD always has one wave on the matrix pipe while its partner is
-// on the LDS pipe.  The LDS DMA of tile t+1 is issued by each wave at the start of its own L0(t) and is only
+// on the LDS pipe.  The LDS DMA of k-step t+1 is issued by each wave at the start of its own L0(t) and is only
 // waited for at the last barrier before slot 4(t+1), i.e. it has 3-4 slots (>= 1500 cycles) to land.
-template <typename T, typename YT>
-__global__ __launch_bounds__(512, 2) void gemm256_pp_kernel(const GemmParams p) {
-    using frag = typename Mfma16<T>::frag;
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
-    const int M = p.M, N = p.N, K = p.K;
-
-    int s, tm, tn;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), p.tiles_m, p.tiles_n, s, tm, tn);
-    const int m0 = tm * TM, n0 = tn * TN;
-
-    const T* x = reinterpret_cast<const T*>(p.x) + (long long)s * p.x_sstride;
-    const T* w = reinterpret_cast<const T*>(p.w) + (long long)s * N * K;
-
-    const int prow = lane >> 3;
-    const int kc = (lane & 7) ^ ((((wid & 1) << 2) + (lane >> 4)) & 7);
-    const T* xsrc[4];
-    const T* wsrc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (i * 8 + wid) * 8 + prow;
-        xsrc[i] = x + (long long)min(m0 + row, M - 1) * K + kc * 8;
-        wsrc[i] = w + (long long)min(n0 + row, N - 1) * K + kc * 8;
-    }
-    auto stage = [&](int kt, int buf) {
-        char* base = smem + buf * STAGE_BYTES;
-        const int k = kt * TK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(xsrc[i] + k, base + (i * 8 + wid) * 1024);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(wsrc[i] + k, base + X_BYTES + (i * 8 + wid) * 1024);
-    };
-
-    const int fsw = (lane >> 1) & 7;
-    const int foff0 = (lane & 15) * ROW_BYTES + ((((lane >> 4)) ^ fsw) << 4);
-    const int foff1 = (lane & 15) * ROW_BYTES + (((4 + (lane >> 4)) ^ fsw) << 4);
-    const int xfrag_base = wm * 128 * ROW_BYTES;
-    const int wfrag_base = X_BYTES + wn * 64 * ROW_BYTES;
-
-    const float* bias = p.bias ? p.bias + (long long)s * N : nullptr;
-    f32x4_t acc[4][8];
-    init_acc(acc, bias, n0, N, wn, lane);
-
-    // De-synchronise the CUs: every tile takes the same time, so without this all 256 CUs stream their operands,
-    // run their MFMAs and write their output tiles in lock-step, and the HBM write burst of the epilogues overlaps
-    // with nothing.  Workgroups of the first dispatch round start 0..3 quarter-periods late (spread evenly inside
-    // each XCD); later workgroups inherit the offsets because they start when an earlier one retires.
-    if (p.stagger > 0 && blockIdx.x < 256u) {
-        const unsigned phase = (blockIdx.x >> 3) & 3u;
-        if (phase) {
-            const unsigned long long t0 = wall_clock64();
-            while (wall_clock64() - t0 < (unsigned long long)(phase * (unsigned)p.stagger)) __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    const int nk = K / TK;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();  // G1 runs one slot behind G0
-
-    frag wf[4], xf[8];
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const char* sb = smem + buf * STAGE_BYTES;
-        // ---- L0: DMA of the next k-tile, fragments of k-half 0
-        if (kt + 1 < nk && !(p.flags & 1)) stage(kt + 1, buf ^ 1);
-        if (!(p.flags & 4)) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                wf[i] = *reinterpret_cast<const frag*>(sb + wfrag_base + i * 16 * ROW_BYTES + foff0);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                xf[j] = *reinterpret_cast<const frag*>(sb + xfrag_base + j * 16 * ROW_BYTES + foff0);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---- M0
-        __builtin_amdgcn_s_setprio(1);
-        if (!(p.flags & 2)) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
-        }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---- L1: fragments of k-half 1
-        if (!(p.flags & 4)) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                wf[i] = *reinterpret_cast<const frag*>(sb + wfrag_base + i * 16 * ROW_BYTES + foff1);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                xf[j] = *reinterpret_cast<const frag*>(sb + xfrag_base + j * 16 * ROW_BYTES + foff1);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // G1's L1(t) is the last slot before G0 starts reading tile t+1: its DMA must have landed by now
-        if (wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---- M1
-        __builtin_amdgcn_s_setprio(1);
-        if (!(p.flags & 2)) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-    }
-    if (wm == 0) __builtin_amdgcn_s_barrier();  // balance G1's leading barrier
-
-    if (p.flags & 8) return;
-    YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
-    epilogue_via_lds<YT>(smem, acc, nullptr, y, m0, n0, M, N, wm, wn, wid, lane, p.act);
-}
-
-
-// ------------------------------------------------------------------------------------------------------------
-// Persistent ping-pong variant (the default).  One workgroup per CU walks tiles b, b+grid, b+2*grid, ... (same
-// XCD every time, so the L2-aware tile order is preserved).  Differences from gemm256_pp_kernel:
+// One workgroup per CU walks tiles b, b+grid, b+2*grid, ... (same XCD every time, so the L2-aware tile order is
+// preserved), and:
 //   * the LDS DMA issued in the LAST k-step of a tile fetches k-step 0 of the workgroup's NEXT tile into the buffer
 //     that would otherwise idle, and is retired by the k-loop's existing waits — the next tile starts without a
 //     cold-start load;
@@ -635,35 +329,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
 }
 
 template <typename T>
-int launch256(const GemmParams& p, int y_dtype, int variant, hipStream_t stream) {
-    const dim3 grid((uint32_t)(p.tiles_m * p.tiles_n * p.S));
-    if (variant >= 3) {
-        // persistent: one workgroup per CU (grid a multiple of 8 keeps a workgroup's tiles on one XCD)
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 256;
-            else n_cu = prop.multiProcessorCount / 8 * 8;
-            if (n_cu < 8) n_cu = 8;
-        }
-        const dim3 pgrid(grid.x < (uint32_t)n_cu ? grid.x : (uint32_t)n_cu);
-        if (y_dtype == BF_DT_F32)
-            hipLaunchKernelGGL((gemm256_persist_kernel<T, float>), pgrid, dim3(512), 0, stream, p);
-        else
-            hipLaunchKernelGGL((gemm256_persist_kernel<T, T>), pgrid, dim3(512), 0, stream, p);
-        BF_HIP_CHECK(hipGetLastError());
-        return 0;
+int launch256(const GemmParams& p, int y_dtype, hipStream_t stream) {
+    const uint32_t tiles = (uint32_t)(p.tiles_m * p.tiles_n * p.S);
+    // persistent: one workgroup per CU (a grid that is a multiple of 8 keeps a workgroup's tiles on one XCD)
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 256;
+        else n_cu = prop.multiProcessorCount / 8 * 8;
+        if (n_cu < 8) n_cu = 8;
     }
-    if (variant == 1) {
-        if (y_dtype == BF_DT_F32)
-            hipLaunchKernelGGL((gemm256_kernel<T, float>), grid, dim3(512), 0, stream, p);
-        else
-            hipLaunchKernelGGL((gemm256_kernel<T, T>), grid, dim3(512), 0, stream, p);
-    } else if (y_dtype == BF_DT_F32)
-        hipLaunchKernelGGL((gemm256_pp_kernel<T, float>), grid, dim3(512), 0, stream, p);
+    const dim3 grid(tiles < (uint32_t)n_cu ? tiles : (uint32_t)n_cu);
+    if (y_dtype == BF_DT_F32)
+        hipLaunchKernelGGL((gemm256_persist_kernel<T, float>), grid, dim3(512), 0, stream, p);
     else
-        hipLaunchKernelGGL((gemm256_pp_kernel<T, T>), grid, dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((gemm256_persist_kernel<T, T>), grid, dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -686,19 +367,13 @@ bool bf_gemm256_supported(int x_dtype, int w_dtype, int y_dtype, int S, int M, i
     return true;
 }
 
-int bf_launch_gemm256(const GemmParams& p0, int w_dtype, int y_dtype, int variant, hipStream_t stream) {
+int bf_launch_gemm256(const GemmParams& p0, int w_dtype, int y_dtype, hipStream_t stream) {
     GemmParams p = p0;
     const char* ab = getenv("BF_GEMM_ABLATE");
     p.flags = ab ? atoi(ab) : 0;
-    // quarter of a tile period: ~1.15 us per 64-deep k-step + ~9 us of prologue/epilogue, in 10 ns ticks
-    const char* st = getenv("BF_GEMM_STAGGER");
-    const double period_us = 1.15 * (p.K / TK) + 9.0;
-    const long long ntiles = (long long)((p.M + TM - 1) / TM) * ((p.N + TN - 1) / TN) * p.S;
-    p.stagger = st ? atoi(st) : 0;  // measured: no gain on MI355X (the epilogue was latency-, not HBM-burst-bound)
-    (void)period_us;
-    (void)ntiles;
+    p.stagger = 0;
     p.tiles_m = (p.M + TM - 1) / TM;
     p.tiles_n = (p.N + TN - 1) / TN;
-    if (w_dtype == BF_DT_BF16) return launch256<__bf16>(p, y_dtype, variant, stream);
-    return launch256<_Float16>(p, y_dtype, variant, stream);
+    if (w_dtype == BF_DT_BF16) return launch256<__bf16>(p, y_dtype, stream);
+    return launch256<_Float16>(p, y_dtype, stream);
 }

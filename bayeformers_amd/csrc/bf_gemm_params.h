@@ -12,11 +12,11 @@ struct GemmParams {
     int S, M, N, K;
     int tiles_m, tiles_n;
     int act;      // BF_ACT_* applied to y in the epilogue
-    int stagger;  // first-round start offset step in 100 MHz wall-clock ticks (0 = off)
+    int stagger;  // unused (kept for ABI stability of the kernel argument block)
     int flags;  // developer ablation bits (BF_GEMM_ABLATE): 1 = no DMA in the k-loop, 2 = no MFMA, 4 = no fragment reads, 8 = no stores
 };
 
 // fast 256x256x64 LDS-DMA kernel (bf_gemm256.hip)
 bool bf_gemm256_supported(int x_dtype, int w_dtype, int y_dtype, int S, int M, int N, int K, const void* d_x,
                           const void* d_w, int64_t x_sample_stride);
-int bf_launch_gemm256(const GemmParams& p, int w_dtype, int y_dtype, int variant, hipStream_t stream);
+int bf_launch_gemm256(const GemmParams& p, int w_dtype, int y_dtype, hipStream_t stream);

@@ -2,7 +2,8 @@
 //   hipcc --offload-arch=gfx950 -O2 tools/gemm_bench.cpp -Iinclude -Lbayeformers_amd/lib -lbayeformers_amd \
 //         -Wl,-rpath,'$ORIGIN/../bayeformers_amd/lib' -o tools/gemm_bench
 //   tools/gemm_bench [S M N K] ...        (defaults: the BERT-base shapes at S=10, M=4096)
-// For each shape: checks variant output against variant 0 (the robust 128x128 kernel), then times both.
+// For each shape: checks the 256x256x64 persistent kernel (variant 1) against variant 0 (the generic 128x128x32
+// kernel), then times both.  BF_GEMM_ABLATE bits: 1 no DMA in the k-loop, 8 no epilogue, 16 no global stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
