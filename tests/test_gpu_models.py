@@ -199,3 +199,34 @@ def test_hip_graph_replay_draws_fresh_samples():
     for k in range(3):
         assert torch.equal(got[k], eager[2 + k]), k
     assert not torch.equal(got[0], got[1])
+
+
+def test_rccl_single_rank_collective_path():
+    """The sharded harness through a real RCCL process group (world size 1: one GPU here): exercises backend init,
+    the packed fp64 all-reduce and the all-gather on device tensors, and must equal the non-distributed result."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.ReLU(), torch.nn.Linear(96, 10))
+    bmodel = bf.to_bayesian(net, delta=0.05).cuda()
+    x = torch.randn(16, 64, device="cuda")
+    bf.manual_seed(SEED)
+    with torch.no_grad():
+        ref = sample_bayesian(bmodel, x, 4)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        bf.manual_seed(SEED)
+        with torch.no_grad():
+            got = sample_bayesian(bmodel, x, 4, group=dist.group.WORLD, gather_raw=True)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(got[0][0], ref[0][0]) and torch.equal(got[1][0], ref[1][0])
+    assert float(got[2]) == float(ref[2]) and float(got[3]) == float(ref[3])
