@@ -20,7 +20,7 @@ from .nn.parameters.initializations import DEFAULT_UNIFORM, Initialization
 from .random import (get_compute_dtype, manual_seed, set_compute_dtype, set_kl_gradient,  # noqa: F401
                      use_device_counter)
 
-__all__ = ["to_bayesian", "fuse_activations", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
+__all__ = ["to_bayesian", "fuse_activations", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
            "use_device_counter", "set_kl_gradient"]
 
 
@@ -44,6 +44,15 @@ def to_bayesian(model: torch.nn.Module, initialization: Optional[Initialization]
     new_model = deepcopy(model)
     swap(new_model)
     return Model(model=new_model)
+
+
+def enable_embedding(enable: bool = True) -> None:
+    """Opt in to converting torch.nn.Embedding tables too (bnn.Embedding — an extension, the reference's TORCH2BAYE
+    holds only nn.Linear).  Off by default so that `to_bayesian` converts exactly what the reference converts."""
+    if enable:
+        TORCH2BAYE[torch.nn.Embedding] = nn.Embedding
+    else:
+        TORCH2BAYE.pop(torch.nn.Embedding, None)
 
 
 class _FusedIntoDense(torch.nn.Module):

@@ -293,6 +293,20 @@ int bf_kl_grad(const bf_tensor_t* tensor, int S, uint64_t seed, uint32_t sample_
     return bf_launch_kl_grad(tensor, S, seed, sample_base, d_g, d_dmu, d_drho, (hipStream_t)stream);
 }
 
+int bf_embedding_fwd(const int64_t* d_ids, const float* d_mu, const float* d_rho, void* d_out, int out_dtype,
+                     int64_t n_tokens, int64_t tokens_per_sample, int64_t V, int D, uint64_t seed, uint32_t sample_base,
+                     uint32_t stream_id, void* stream) {
+    return bf_launch_embedding_fwd((const long long*)d_ids, d_mu, d_rho, d_out, out_dtype, n_tokens, tokens_per_sample, V,
+                                   D, seed, sample_base, stream_id, (hipStream_t)stream);
+}
+
+int bf_embedding_bwd(const int64_t* d_ids, const void* d_grad, int grad_dtype, const float* d_rho, float* d_dmu,
+                     float* d_drho, int64_t n_tokens, int64_t tokens_per_sample, int64_t V, int D, uint64_t seed,
+                     uint32_t sample_base, uint32_t stream_id, void* stream) {
+    return bf_launch_embedding_bwd((const long long*)d_ids, d_grad, grad_dtype, d_rho, d_dmu, d_drho, n_tokens,
+                                   tokens_per_sample, V, D, seed, sample_base, stream_id, (hipStream_t)stream);
+}
+
 // workspace layout of bf_linear_bwd
 struct BwdLayout {
     size_t w, wt, dyt, xt, dw, db, lp, part, total;

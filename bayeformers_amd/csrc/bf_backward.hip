@@ -161,6 +161,118 @@ __global__ __launch_bounds__(256) void kl_grad_kernel(const KlParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- bnn.Embedding
+// out[t][:] = mu[id_t][:] + softplus(rho[id_t][:]) * eps(sample of token t, element id_t*D + d): only the gathered rows
+// are sampled; the same id inside one sample gets the same vector (one table draw per sample, as for bnn.Linear).
+template <typename OT>
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const long long* __restrict__ ids,
+                                                            const float* __restrict__ mu, const float* __restrict__ rho,
+                                                            OT* __restrict__ out, long long n_tokens,
+                                                            long long tokens_per_sample, long long V, int D, uint32_t k0,
+                                                            uint32_t k1, uint32_t sample_base,
+                                                            const uint32_t* __restrict__ counter, uint32_t stream) {
+    const int d4 = D >> 2;
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_tokens * d4) return;
+    const long long tk = q / d4;
+    const int d = (int)(q - tk * d4) * 4;
+    long long id = ids[tk];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const uint32_t sample = sample_base + (counter ? *counter : 0u) + (uint32_t)(tk / tokens_per_sample);
+    const unsigned long long e = (unsigned long long)id * D + d;
+    const f32x4_t m = *reinterpret_cast<const f32x4_t*>(mu + e);
+    const f32x4_t r = *reinterpret_cast<const f32x4_t*>(rho + e);
+    float z[4];
+    bf_normal4_dev((uint32_t)(e >> 2), (uint32_t)(e >> 34), sample, stream, k0, k1, z);
+    f32x4_t w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float zr = expf(r[i]);
+        const float sg = r[i] > 20.0f ? r[i] : log1pf(zr);
+        w[i] = fmaf(sg, z[i], m[i]);
+    }
+    OT* o = out + tk * D + d;
+    if constexpr (sizeof(OT) == 4) *reinterpret_cast<f32x4_t*>(o) = w;
+    else if constexpr (__is_same(OT, __bf16)) *reinterpret_cast<bf16x4_t*>(o) = __builtin_convertvector(w, bf16x4_t);
+    else *reinterpret_cast<f16x4_t*>(o) = __builtin_convertvector(w, f16x4_t);
+}
+
+// dmu[id] += g, drho[id] += g * eps * softplus'(rho): scatter-add with fp32 atomics (rows repeat across tokens)
+template <typename GT>
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const long long* __restrict__ ids, const GT* __restrict__ g,
+                                                            const float* __restrict__ rho, float* __restrict__ dmu,
+                                                            float* __restrict__ drho, long long n_tokens,
+                                                            long long tokens_per_sample, long long V, int D, uint32_t k0,
+                                                            uint32_t k1, uint32_t sample_base,
+                                                            const uint32_t* __restrict__ counter, uint32_t stream) {
+    const int d4 = D >> 2;
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_tokens * d4) return;
+    const long long tk = q / d4;
+    const int d = (int)(q - tk * d4) * 4;
+    long long id = ids[tk];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const uint32_t sample = sample_base + (counter ? *counter : 0u) + (uint32_t)(tk / tokens_per_sample);
+    const unsigned long long e = (unsigned long long)id * D + d;
+    float z[4];
+    bf_normal4_dev((uint32_t)(e >> 2), (uint32_t)(e >> 34), sample, stream, k0, k1, z);
+    const GT* gp = g + tk * D + d;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float gi = (float)gp[i];
+        const float r = rho[e + i];
+        const float zr = expf(r);
+        if (dmu) atomicAdd(dmu + e + i, gi);
+        atomicAdd(drho + e + i, gi * z[i] * (r > 20.0f ? 1.0f : zr / (zr + 1.0f)));
+    }
+}
+
+}  // namespace
+
+int bf_launch_embedding_fwd(const long long* d_ids, const float* d_mu, const float* d_rho, void* d_out, int out_dtype,
+                            long long n_tokens, long long tokens_per_sample, long long V, int D, uint64_t seed,
+                            uint32_t sample_base, uint32_t stream_id, hipStream_t stream) {
+    if (!d_ids || !d_mu || !d_rho || !d_out) BF_FAIL("bf_embedding_fwd: NULL argument");
+    if (n_tokens < 1 || tokens_per_sample < 1 || V < 1 || D < 4 || D % 4) BF_FAIL("bf_embedding_fwd: bad shape (D must be a multiple of 4)");
+    if (((uintptr_t)d_mu | (uintptr_t)d_rho | (uintptr_t)d_out) & 15) BF_FAIL("bf_embedding_fwd: operands must be 16-byte aligned");
+    const long long work = n_tokens * (D / 4);
+    const dim3 grid((uint32_t)((work + 255) / 256));
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (out_dtype == BF_DT_BF16)
+        hipLaunchKernelGGL(embedding_fwd_kernel<__bf16>, grid, dim3(256), 0, stream, d_ids, d_mu, d_rho, (__bf16*)d_out,
+                           n_tokens, tokens_per_sample, V, D, k0, k1, sample_base, bf_sample_counter(), stream_id);
+    else if (out_dtype == BF_DT_F16)
+        hipLaunchKernelGGL(embedding_fwd_kernel<_Float16>, grid, dim3(256), 0, stream, d_ids, d_mu, d_rho, (_Float16*)d_out,
+                           n_tokens, tokens_per_sample, V, D, k0, k1, sample_base, bf_sample_counter(), stream_id);
+    else
+        hipLaunchKernelGGL(embedding_fwd_kernel<float>, grid, dim3(256), 0, stream, d_ids, d_mu, d_rho, (float*)d_out,
+                           n_tokens, tokens_per_sample, V, D, k0, k1, sample_base, bf_sample_counter(), stream_id);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int bf_launch_embedding_bwd(const long long* d_ids, const void* d_grad, int grad_dtype, const float* d_rho, float* d_dmu,
+                            float* d_drho, long long n_tokens, long long tokens_per_sample, long long V, int D,
+                            uint64_t seed, uint32_t sample_base, uint32_t stream_id, hipStream_t stream) {
+    if (!d_ids || !d_grad || !d_rho || !d_drho) BF_FAIL("bf_embedding_bwd: NULL argument");
+    if (n_tokens < 1 || tokens_per_sample < 1 || V < 1 || D < 4 || D % 4) BF_FAIL("bf_embedding_bwd: bad shape");
+    const long long work = n_tokens * (D / 4);
+    const dim3 grid((uint32_t)((work + 255) / 256));
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    if (grad_dtype == BF_DT_BF16)
+        hipLaunchKernelGGL(embedding_bwd_kernel<__bf16>, grid, dim3(256), 0, stream, d_ids, (const __bf16*)d_grad, d_rho,
+                           d_dmu, d_drho, n_tokens, tokens_per_sample, V, D, k0, k1, sample_base, bf_sample_counter(), stream_id);
+    else if (grad_dtype == BF_DT_F16)
+        hipLaunchKernelGGL(embedding_bwd_kernel<_Float16>, grid, dim3(256), 0, stream, d_ids, (const _Float16*)d_grad,
+                           d_rho, d_dmu, d_drho, n_tokens, tokens_per_sample, V, D, k0, k1, sample_base, bf_sample_counter(), stream_id);
+    else
+        hipLaunchKernelGGL(embedding_bwd_kernel<float>, grid, dim3(256), 0, stream, d_ids, (const float*)d_grad, d_rho,
+                           d_dmu, d_drho, n_tokens, tokens_per_sample, V, D, k0, k1, sample_base, bf_sample_counter(), stream_id);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+namespace {
 }  // namespace
 
 int bf_launch_kl_grad(const bf_tensor_t* t, int S, uint64_t seed, uint32_t sample_base, const double* d_g,

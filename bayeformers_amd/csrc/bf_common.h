@@ -86,3 +86,9 @@ int bf_launch_fused_small(const void* d_x, int x_dtype, int64_t x_sample_stride,
                           uint32_t sample_base, double* d_partials, hipStream_t stream);
 int bf_launch_kl_grad(const bf_tensor_t* t, int S, uint64_t seed, uint32_t sample_base, const double* d_g,
                       float* d_dmu, float* d_drho, hipStream_t stream);
+int bf_launch_embedding_fwd(const long long* d_ids, const float* d_mu, const float* d_rho, void* d_out, int out_dtype,
+                            long long n_tokens, long long tokens_per_sample, long long V, int D, uint64_t seed,
+                            uint32_t sample_base, uint32_t stream_id, hipStream_t stream);
+int bf_launch_embedding_bwd(const long long* d_ids, const void* d_grad, int grad_dtype, const float* d_rho, float* d_dmu,
+                            float* d_drho, long long n_tokens, long long tokens_per_sample, long long V, int D,
+                            uint64_t seed, uint32_t sample_base, uint32_t stream_id, hipStream_t stream);

@@ -2,6 +2,7 @@
 """bayeformers_amd.nn — the names /root/reference/bayeformers/nn/__init__.py:2-25 exports."""
 import torch.nn as nn
 
+from .layers.embedding import Embedding
 from .layers.linear import Linear
 from .model import Model, is_module_bayesian
 from .parameters.base import NoneParameter, Parameter

@@ -18,10 +18,10 @@ from torch.nn import Module
 from ... import ops
 from ... import random as bfr
 from ..parameters.base import NoneParameter, Parameter
+from .base import KernelLayer
 from ..parameters.gaussian import DEFAULT_SCALED_GAUSSIAN_MIXTURE, Gaussian
 from ..parameters.initializations import DEFAULT_UNIFORM, Initialization
 
-_LOGPROB_NAMES = ("log_prior", "log_variational_posterior")
 
 
 def _backward(ctx, grad):
@@ -69,7 +69,7 @@ class _PlannedLinearFn(torch.autograd.Function):
         return dx, dmu_w, drho_w, dmu_b, drho_b, None, None, None, None, None, None, None
 
 
-class Linear(Module):
+class Linear(KernelLayer):
     """Bayesian Linear layer with Gaussian weight/bias posteriors and a prior per parameter.
 
     Attributes (as the reference): in_features, out_features, initialization, weight, weight_prior, bias,
@@ -96,49 +96,17 @@ class Linear(Module):
             self.bias = NoneParameter()
             self.bias_prior = NoneParameter()
 
-        self.register_parameter("log_prior", nn.Parameter(torch.tensor(0.), requires_grad=False))
-        self.register_parameter("log_variational_posterior", nn.Parameter(torch.tensor(0.), requires_grad=False))
-
-        self.layer_id = bfr.new_layer_id()
-        self.compute_dtype = None
+        self._init_kernel_layer()
         self._small_m = False   # seen with <= 64 rows per sample: single fused kernel, left out of the sampling plan
         self.activation = None  # "gelu": exact GELU fused into the GEMM epilogue (bayeformers_amd.fuse_activations)
         self._plan = ops.LinearPlan()
-        self._lp_own = None    # [S, 2] float64 buffer when the layer is used outside a bnn.Model
-        self._lp_view = None   # where the last forward wrote {log_prior, log_q} per sample
-        self._lp_dirty = False
-
-    # --- log_prior / log_variational_posterior are refreshed lazily from the kernel's [S, 2] output ---------------
-    def __getattr__(self, name):
-        if name in _LOGPROB_NAMES and self.__dict__.get("_lp_dirty", False):
-            self._sync_logprobs()
-        return super(Linear, self).__getattr__(name)
-
-    def _sync_logprobs(self) -> None:
-        self.__dict__["_lp_dirty"] = False
-        v = self._lp_view.mean(0).to(torch.float32)
-        self._parameters["log_prior"].data = v[0]
-        self._parameters["log_variational_posterior"].data = v[1]
-
-    @property
-    def log_prob_samples(self) -> Optional[Tensor]:
-        """[S, 2] float64 {log_prior, log_variational_posterior} of each sample of the last forward."""
-        return self._lp_view
 
     def forward(self, input: Tensor) -> Tensor:
         """y = x W^T + b with W ~ N(mu_w, softplus(rho_w)), b ~ N(mu_b, softplus(rho_b))  (linear.py:83-104).
 
         Inside `bnn.Model` with S Monte-Carlo samples in flight the input is [S*B, ..., in_features]
         (sample-major) and slab s is multiplied by W_s; otherwise S = 1 and one fresh sample index is used."""
-        ctx = bfr.STATE.ctx
-        if ctx is not None:
-            base, S, slot = ctx.sample_base, ctx.S, ctx.slot(self)
-        else:
-            base, S, slot = bfr.reserve_samples(1), 1, None
-        if slot is None:
-            if self._lp_own is None or self._lp_own.shape[0] != S or self._lp_own.device != input.device:
-                self._lp_own = torch.zeros((S, 2), dtype=torch.float64, device=input.device)
-            slot = self._lp_own
+        ctx, base, S, slot = self._begin(input.device)
         x2 = input.reshape(-1, self.in_features)
         if x2.shape[0] == 0:
             # empty batch: like the reference, the weights are still sampled and the log-probs refreshed
@@ -147,10 +115,7 @@ class Linear(Module):
             sids = [2 * self.layer_id + i for i in range(len(gs))]
             _, lp = ops.sample_logprob(gs, prs, sids, S, bfr.STATE.seed, base)
             slot.copy_(lp)
-            if ctx is None:
-                bfr.commit_samples(1)
-            self._lp_view = slot
-            self._lp_dirty = True
+            self._end(ctx, slot)
             return input.new_empty(*input.shape[:-1], self.out_features)
         mu_b = self.bias.mu if isinstance(self.bias, Gaussian) else None
         rho_b = self.bias.rho if isinstance(self.bias, Gaussian) else None
@@ -169,16 +134,12 @@ class Linear(Module):
                                        bfr.STATE.seed, base, 1 if fused else 0)
             if want_act and not fused:
                 y = torch.nn.functional.gelu(y)
-            self._lp_view = slot
-            self._lp_dirty = True
+            self._lp_view, self._lp_dirty = slot, True
             return y.view(*input.shape[:-1], self.out_features)
         y = _LinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, self, S, bfr.STATE.seed, base, slot)
-        if ctx is None:
-            bfr.commit_samples(1)
         if want_act:
             y = torch.nn.functional.gelu(y)
-        self._lp_view = slot
-        self._lp_dirty = True
+        self._end(ctx, slot)
         return y.view(*input.shape[:-1], self.out_features)
 
     @classmethod

@@ -22,6 +22,7 @@ from torch.nn import Module
 
 from .. import random as bfr
 from ..plan import SamplePlan
+from .layers.base import KernelLayer
 from .layers.linear import Linear
 
 
@@ -87,7 +88,7 @@ class Model(Module):
         self.model = model
         self._mc_samples = 1
         self._mc_shard = (0, 1)
-        self._fused: Optional[List[Linear]] = None
+        self._fused: Optional[List[KernelLayer]] = None
         self._lp_buf: Optional[Tensor] = None
         self._last_base = None
         self._plan: Optional[SamplePlan] = None
@@ -113,9 +114,10 @@ class Model(Module):
                 buf = self._lp_buf = torch.zeros((len(layers), S, 2), dtype=torch.float64, device=dev)
             slots = {id(l): buf[i] for i, l in enumerate(layers)}
         plan = None
-        if layers and self.cross_layer_sampling and SamplePlan.plannable(layers):
+        linears = [l for l in layers if isinstance(l, Linear)]
+        if linears and self.cross_layer_sampling and SamplePlan.plannable(linears):
             # layers seen with <= 64 rows per sample run the single fused kernel instead (Linear.forward marks them)
-            planned = [(i, l) for i, l in enumerate(layers) if not l._small_m]
+            planned = [(i, l) for i, l in enumerate(layers) if isinstance(l, Linear) and not l._small_m]
             if planned:
                 cdt = bfr.get_compute_dtype()
                 pl = [l for _, l in planned]
@@ -147,10 +149,11 @@ class Model(Module):
         finally:
             self._mc_samples, self._mc_shard = prev
 
-    def fused_children(self) -> List[Linear]:
-        """The bnn.Linear children in registration order; their layer_id (Philox stream) is that order."""
+    def fused_children(self) -> List[KernelLayer]:
+        """The kernel-backed children (bnn.Linear, bnn.Embedding) in registration order; their layer_id (Philox
+        stream) is that order."""
         if self._fused is None:
-            self._fused = [m for m in self.modules() if isinstance(m, Linear)]
+            self._fused = [m for m in self.modules() if isinstance(m, KernelLayer)]
             for i, l in enumerate(self._fused):
                 l.layer_id = i
         return self._fused
@@ -168,7 +171,7 @@ class Model(Module):
         return children
 
     def _only_fused(self) -> bool:
-        return all(isinstance(c, Linear) for c in self.bayesian_children)
+        return all(isinstance(c, KernelLayer) for c in self.bayesian_children)
 
     def _sum(self, index: int, name: str):
         children = list(self.bayesian_children)

@@ -257,3 +257,36 @@ def kl_grad(gaussian, prior, stream_id: int, S: int, seed: int, sample_base: int
                                  dmu.data_ptr() if dmu is not None else None, drho.data_ptr(), _stream_ptr()),
              "bf_kl_grad")
     return dmu, drho
+
+
+def embedding_forward(ids: Tensor, mu: Tensor, rho: Tensor, out_dtype: torch.dtype, S: int, seed: int,
+                      sample_base: int, stream_id: int) -> Tensor:
+    """Rows ids of S table draws W_s = mu + softplus(rho)*eps_s (bf_embedding_fwd); ids is [S*T] sample-major."""
+    _require_device(mu, "Embedding.weight.mu")
+    _require_device(ids, "Embedding input")
+    V, D = mu.shape
+    n = ids.numel()
+    if n % S:
+        raise _C.BayeFormersAMDError(f"embedding_forward: {n} tokens are not a multiple of S={S}")
+    out = torch.empty((n, D), dtype=out_dtype, device=mu.device)
+    if n:
+        _C.check(_C.lib().bf_embedding_fwd(ids.data_ptr(), mu.data_ptr(), rho.data_ptr(), out.data_ptr(),
+                                           _TORCH2BF[out_dtype], n, n // S, V, D, seed, sample_base & 0xFFFFFFFF,
+                                           stream_id, _stream_ptr()), "bf_embedding_fwd")
+    return out
+
+
+def embedding_backward(ids: Tensor, grad: Tensor, mu: Tensor, rho: Tensor, S: int, seed: int, sample_base: int,
+                       stream_id: int, need_mu: bool, need_rho: bool):
+    """Scatter-add of the output gradient into (dmu, drho) of the table (bf_embedding_bwd)."""
+    V, D = mu.shape
+    n = ids.numel()
+    grad = grad.contiguous()
+    dmu = torch.zeros_like(mu, dtype=torch.float32) if need_mu else None
+    drho = torch.zeros_like(rho, dtype=torch.float32) if need_rho else None
+    if n and (need_mu or need_rho):
+        _C.check(_C.lib().bf_embedding_bwd(ids.data_ptr(), grad.data_ptr(), _TORCH2BF[grad.dtype], rho.data_ptr(),
+                                           dmu.data_ptr() if need_mu else None, drho.data_ptr() if need_rho else None,
+                                           n, n // S, V, D, seed, sample_base & 0xFFFFFFFF, stream_id, _stream_ptr()),
+                 "bf_embedding_bwd")
+    return dmu, drho

@@ -158,6 +158,20 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
 int bf_kl_grad(const bf_tensor_t* tensor, int S, uint64_t seed, uint32_t sample_base, const double* d_g,
                float* d_dmu, float* d_drho, void* stream);
 
+/* bnn.Embedding — an EXTENSION: the north star names it, the reference has no such layer (TORCH2BAYE holds only
+ * nn.Linear, bayeformers/nn/__init__.py:25), so its semantics are defined here by analogy with Linear.forward and
+ * parity is unpinned.  One table draw per Monte-Carlo sample, of which only the gathered rows are materialised:
+ *   d_out[t][d] = mu[id_t][d] + softplus(rho[id_t][d]) * eps(seed, sample_base + t / tokens_per_sample, stream, id_t*D + d)
+ * (ids are int64, clamped to [0, V)).  The log-probs are those of the WHOLE table: bf_sample_logprob on (mu, rho) with
+ * d_sample_out = NULL and the same stream id.  bf_embedding_bwd scatter-adds (atomics; d_dmu/d_drho must be zeroed by
+ * the caller) dmu[id] += g, drho[id] += g * eps * softplus'(rho). */
+int bf_embedding_fwd(const int64_t* d_ids, const float* d_mu, const float* d_rho, void* d_out, int out_dtype,
+                     int64_t n_tokens, int64_t tokens_per_sample, int64_t V, int D, uint64_t seed, uint32_t sample_base,
+                     uint32_t stream_id, void* stream);
+int bf_embedding_bwd(const int64_t* d_ids, const void* d_grad, int grad_dtype, const float* d_rho, float* d_dmu,
+                     float* d_drho, int64_t n_tokens, int64_t tokens_per_sample, int64_t V, int D, uint64_t seed,
+                     uint32_t sample_base, uint32_t stream_id, void* stream);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * While enabled, every sampling launch (kind BF_PROF_SAMPLE) and every GEMM launch (BF_PROF_GEMM) made through
  * this library is bracketed by two events; bf_profile_read() synchronises them and returns, per kind, the number
