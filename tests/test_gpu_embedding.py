@@ -59,7 +59,7 @@ def test_forward_and_logprobs(delta, dtype, tol):
         out = model(ids.repeat(S, 1).cuda())
     assert out.shape == (S * B, T, D) and out.dtype == dtype
     ref, lps = oracle_rows(layer, ids, S, base)          # [S, B, T, D]
-    got = out.view(S, B, T, D).double().cpu().numpy()
+    got = out.detach().view(S, B, T, D).double().cpu().numpy()
     scale = np.abs(ref).max()
     assert np.abs(got - ref).max() <= tol * scale
     lp = model.log_prob_samples().cpu().numpy()
@@ -85,7 +85,7 @@ def test_backward_matches_autograd():
     rho = layer.weight.rho.detach().cpu().double().requires_grad_(True)
     loss = 0
     for s in range(S):
-        eps = torch.from_numpy(bo.eps_tensor((V, D), SEED, base + s, layer.layer_id, 0)).double()
+        eps = bo.eps_tensor((V, D), SEED, base + s, layer.layer_id, 0).double()
         w = mu + torch.log1p(torch.exp(rho)) * eps
         loss = loss + (torch.nn.functional.embedding(ids, w, padding_idx=7) * gy[s].double()).sum()
     loss.backward()
