@@ -6,6 +6,7 @@
 
 `to_bayesian` mirrors /root/reference/bayeformers/__init__.py:19-63.
 """
+import types
 from copy import deepcopy
 from typing import Optional
 
@@ -20,7 +21,7 @@ from .nn.parameters.initializations import DEFAULT_UNIFORM, Initialization
 from .random import (get_compute_dtype, manual_seed, set_compute_dtype, set_kl_gradient,  # noqa: F401
                      use_device_counter)
 
-__all__ = ["to_bayesian", "fuse_activations", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
+__all__ = ["to_bayesian", "fuse_activations", "fuse_residual_layernorm", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
            "use_device_counter", "set_kl_gradient"]
 
 
@@ -84,5 +85,39 @@ def fuse_activations(model: torch.nn.Module) -> int:
         if isinstance(dense, nn.Linear) and act is not None and _is_exact_gelu(act):
             dense.activation = "gelu"
             m.intermediate_act_fn = _FusedIntoDense()
+            fused += 1
+    return fused
+
+
+def _dense_residual_norm_forward(self, hidden_states, input_tensor):
+    """forward of an HF `*Output` block — LayerNorm(dropout(dense(h)) + input) — with the residual add and the
+    normalisation done by one HBM pass (bf_add_layernorm) behind the Bayesian dense layer's GEMM.  Whenever a
+    gradient may be needed or dropout is active, the framework ops run instead, so autograd stays intact."""
+    from . import ops
+
+    hidden_states = self.dense(hidden_states)
+    ln = self.LayerNorm
+    plain = (torch.is_grad_enabled() and (hidden_states.requires_grad or input_tensor.requires_grad or
+                                          ln.weight.requires_grad)) or \
+        (self.training and self.dropout.p > 0) or not hidden_states.is_cuda or \
+        hidden_states.dtype != input_tensor.dtype or hidden_states.shape != input_tensor.shape
+    if plain:
+        return ln(self.dropout(hidden_states) + input_tensor)
+    return ops.add_layernorm(hidden_states, input_tensor, ln.weight, ln.bias, ln.eps)
+
+
+def fuse_residual_layernorm(model: torch.nn.Module) -> int:
+    """Fuse `LayerNorm(dropout(dense(h)) + input)` blocks whose dense layer is a bnn.Linear (HF BertSelfOutput,
+    BertOutput and their relatives: attributes `dense`, `dropout`, `LayerNorm`, forward(hidden_states,
+    input_tensor)) into dense GEMM -> one add+LayerNorm pass.  Inference-time optimisation, like fuse_activations.
+    Returns the number of fused blocks."""
+    fused = 0
+    for m in model.modules():
+        dense, ln, drop = getattr(m, "dense", None), getattr(m, "LayerNorm", None), getattr(m, "dropout", None)
+        if (isinstance(dense, nn.Linear) and isinstance(ln, torch.nn.LayerNorm) and isinstance(drop, torch.nn.Dropout)
+                and ln.elementwise_affine and ln.bias is not None and len(ln.normalized_shape) == 1
+                and ln.normalized_shape[0] == dense.out_features and dense.out_features % 8 == 0
+                and dense.out_features <= 8192 and m.__class__.__name__.endswith("Output")):
+            m.forward = types.MethodType(_dense_residual_norm_forward, m)
             fused += 1
     return fused

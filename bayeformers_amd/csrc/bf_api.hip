@@ -307,6 +307,12 @@ int bf_embedding_bwd(const int64_t* d_ids, const void* d_grad, int grad_dtype, c
                                    tokens_per_sample, V, D, seed, sample_base, stream_id, (hipStream_t)stream);
 }
 
+int bf_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, int param_dtype,
+                     void* d_out, int dtype, int64_t rows, int N, float eps, void* stream) {
+    return bf_launch_add_layernorm(d_x, d_residual, d_gamma, d_beta, param_dtype, d_out, dtype, rows, N, eps,
+                                   (hipStream_t)stream);
+}
+
 // workspace layout of bf_linear_bwd
 struct BwdLayout {
     size_t w, wt, dyt, xt, dw, db, lp, part, total;

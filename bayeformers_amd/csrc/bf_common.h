@@ -92,3 +92,6 @@ int bf_launch_embedding_fwd(const long long* d_ids, const float* d_mu, const flo
 int bf_launch_embedding_bwd(const long long* d_ids, const void* d_grad, int grad_dtype, const float* d_rho, float* d_dmu,
                             float* d_drho, long long n_tokens, long long tokens_per_sample, long long V, int D,
                             uint64_t seed, uint32_t sample_base, uint32_t stream_id, hipStream_t stream);
+int bf_launch_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta,
+                            int param_dtype, void* d_out, int dtype, long long rows, int N, float eps,
+                            hipStream_t stream);

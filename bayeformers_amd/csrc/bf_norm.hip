@@ -1,0 +1,160 @@
+// bf_norm.hip — residual add + LayerNorm in one pass, the op that consumes a Bayesian dense layer's output in the
+// transformer blocks the reference converts (HF BertSelfOutput / BertOutput: LayerNorm(dropout(dense(h)) + input),
+// called around /root/reference/bayeformers/nn/layers/linear.py:83-104's forward).  Not a reference function: it
+// replaces two framework kernels (elementwise add, then layer_norm) that re-read the GEMM output from HBM.
+//
+// HBM-bound streaming kernel: one wave64 per row, the row lives in registers (fp32) between the load and the
+// store, statistics by the two-pass formula on those registers (mean, then sum of squared deviations), wave
+// reductions on the DPP network.  Algorithmic bytes per row: N * (2 reads + 1 write) * sizeof(T).
+#include "bf_common.h"
+
+namespace {
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true);
+    return v + __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v);
+    v = dpp_add<0x143, 0xc>(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// 8 consecutive elements <-> 8 floats
+__device__ __forceinline__ void load8(const __bf16* p, float (&v)[8]) {
+    const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+}
+__device__ __forceinline__ void load8(const _Float16* p, float (&v)[8]) {
+    const f16x8_t t = *reinterpret_cast<const f16x8_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+}
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p), b = *reinterpret_cast<const f32x4_t*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = a[i], v[4 + i] = b[i];
+}
+__device__ __forceinline__ void store8(__bf16* p, const float (&v)[8]) {
+    *reinterpret_cast<bf16x8_t*>(p) =
+        __builtin_convertvector((f32x8_t{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}), bf16x8_t);
+}
+__device__ __forceinline__ void store8(_Float16* p, const float (&v)[8]) {
+    *reinterpret_cast<f16x8_t*>(p) =
+        __builtin_convertvector((f32x8_t{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}), f16x8_t);
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4_t*>(p) = f32x4_t{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4_t*>(p + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+}
+
+constexpr int kRowsPerBlock = 4;  // one wave per row
+
+// VPL = 8-element vectors per lane: a row has N/8 <= 64*VPL of them
+template <typename T, typename GT, int VPL>
+__global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_kernel(
+    const T* __restrict__ x, const T* __restrict__ res, const GT* __restrict__ gamma, const GT* __restrict__ beta,
+    T* __restrict__ out, long long rows, int N, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = N >> 3;
+    const T* xr = x + row * N;
+    const T* rr = res ? res + row * N : nullptr;
+    float v[VPL][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) {
+        const int vi = lane + 64 * c;
+        if (vi < nvec) {
+            load8(xr + vi * 8, v[c]);
+            if (rr) {
+                float r[8];
+                load8(rr + vi * 8, r);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[c][i] += r[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += v[c][i];
+        }
+    }
+    const float inv_n = 1.0f / (float)N;
+    const float mean = wave_sum(sum) * inv_n;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) {
+        if (lane + 64 * c < nvec) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float d = v[c][i] - mean;
+                sq = fmaf(d, d, sq);
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_n + eps);
+    T* orow = out + row * N;
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) {
+        const int vi = lane + 64 * c;
+        if (vi < nvec) {
+            float g[8], b[8], o[8];
+            load8(gamma + vi * 8, g);
+            load8(beta + vi * 8, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = fmaf((v[c][i] - mean) * rstd, g[i], b[i]);
+            store8(orow + vi * 8, o);
+        }
+    }
+}
+
+template <typename T, typename GT>
+int launch_vpl(const void* x, const void* res, const void* gamma, const void* beta, void* out, long long rows, int N,
+               float eps, hipStream_t stream) {
+    const int nvec = N >> 3;
+    const dim3 grid((unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock)), block(64 * kRowsPerBlock);
+#define BF_LN_LAUNCH(VPL)                                                                                        \
+    hipLaunchKernelGGL((add_layernorm_kernel<T, GT, VPL>), grid, block, 0, stream, (const T*)x, (const T*)res,    \
+                       (const GT*)gamma, (const GT*)beta, (T*)out, rows, N, eps)
+    if (nvec <= 64) BF_LN_LAUNCH(1);
+    else if (nvec <= 128) BF_LN_LAUNCH(2);
+    else if (nvec <= 256) BF_LN_LAUNCH(4);
+    else if (nvec <= 512) BF_LN_LAUNCH(8);
+    else BF_LN_LAUNCH(16);
+#undef BF_LN_LAUNCH
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+int launch_gt(const void* x, const void* res, const void* gamma, const void* beta, int param_dtype, int dtype,
+              void* out, long long rows, int N, float eps, hipStream_t stream) {
+    if (param_dtype == BF_DT_F32) return launch_vpl<T, float>(x, res, gamma, beta, out, rows, N, eps, stream);
+    if (param_dtype == dtype) return launch_vpl<T, T>(x, res, gamma, beta, out, rows, N, eps, stream);
+    BF_FAIL("bf_add_layernorm: gamma/beta must be fp32 or have the activation dtype");
+}
+
+}  // namespace
+
+int bf_launch_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta,
+                            int param_dtype, void* d_out, int dtype, long long rows, int N, float eps,
+                            hipStream_t stream) {
+    if (rows < 0 || N <= 0) BF_FAIL("bf_add_layernorm: bad shape rows=%lld N=%d", rows, N);
+    if (rows == 0) return 0;
+    if (!d_x || !d_gamma || !d_beta || !d_out) BF_FAIL("bf_add_layernorm: null pointer");
+    if (N % 8 || N > 8192) BF_FAIL("bf_add_layernorm: N=%d must be a multiple of 8 and at most 8192", N);
+    if (rows > 0x7fffffffLL * kRowsPerBlock) BF_FAIL("bf_add_layernorm: too many rows");
+    const uintptr_t al = (uintptr_t)d_x | (uintptr_t)d_residual | (uintptr_t)d_gamma | (uintptr_t)d_beta | (uintptr_t)d_out;
+    if (al & 15) BF_FAIL("bf_add_layernorm: pointers must be 16-byte aligned");
+    switch (dtype) {
+        case BF_DT_BF16: return launch_gt<__bf16>(d_x, d_residual, d_gamma, d_beta, param_dtype, dtype, d_out, rows, N, eps, stream);
+        case BF_DT_F16: return launch_gt<_Float16>(d_x, d_residual, d_gamma, d_beta, param_dtype, dtype, d_out, rows, N, eps, stream);
+        case BF_DT_F32: return launch_gt<float>(d_x, d_residual, d_gamma, d_beta, param_dtype, dtype, d_out, rows, N, eps, stream);
+    }
+    BF_FAIL("bf_add_layernorm: unknown dtype %d", dtype);
+}

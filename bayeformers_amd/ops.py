@@ -290,3 +290,24 @@ def embedding_backward(ids: Tensor, grad: Tensor, mu: Tensor, rho: Tensor, S: in
                                            n, n // S, V, D, seed, sample_base & 0xFFFFFFFF, stream_id, _stream_ptr()),
                  "bf_embedding_bwd")
     return dmu, drho
+
+
+def add_layernorm(x: Tensor, residual: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float) -> Tensor:
+    """LayerNorm(x + residual) over the last axis in one pass (bf_add_layernorm); residual may be None."""
+    _require_device(x, "add_layernorm input")
+    N = x.shape[-1]
+    x2 = x.reshape(-1, N)
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    r2 = None
+    if residual is not None:
+        if residual.shape != x.shape or residual.dtype != x.dtype:
+            raise _C.BayeFormersAMDError("add_layernorm: residual must match the input's shape and dtype")
+        r2 = residual.reshape(-1, N)
+        r2 = r2 if r2.is_contiguous() else r2.contiguous()
+    if gamma.dtype != beta.dtype or gamma.dtype not in (torch.float32, x.dtype):
+        raise _C.BayeFormersAMDError("add_layernorm: gamma/beta must be float32 or have the input's dtype")
+    out = torch.empty_like(x2)
+    _C.check(_C.lib().bf_add_layernorm(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
+                                       beta.data_ptr(), _TORCH2BF[gamma.dtype], out.data_ptr(), _TORCH2BF[x.dtype],
+                                       x2.shape[0], N, float(eps), _stream_ptr()), "bf_add_layernorm")
+    return out.view(x.shape)

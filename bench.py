@@ -64,6 +64,7 @@ def make_bert(device, S, dtype):
     model = BertForSequenceClassification(cfg).eval()
     bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().to(device)
     n_fused = bf.fuse_activations(bmodel)  # BertIntermediate: dense + exact GELU in one GEMM epilogue
+    n_ln = bf.fuse_residual_layernorm(bmodel) if os.environ.get("BF_BENCH_NO_LN_FUSION") is None else 0
     if dtype != "fp32":
         bmodel = bmodel.to(torch.bfloat16 if dtype == "bf16" else torch.float16)
     g = torch.Generator().manual_seed(321)
@@ -96,7 +97,8 @@ def make_bert(device, S, dtype):
 
     cfgd = {"workload": "to_bayesian(BERT-base seq-cls, delta=0.05, freeze=True) fwd+ELBO", "samples_per_gpu": S,
             "batch": B, "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "bayesian_scalars": 85609730,
-            "gelu_fused_into_gemm": n_fused}
+            "gelu_fused_into_gemm": n_fused,
+            "residual_layernorm_fused": n_ln}
     return step, cpu_baseline, cfgd, bmodel
 
 
@@ -112,6 +114,7 @@ def make_bert_large_qa(device, S, dtype):
     model = BertForQuestionAnswering(cfg).eval()
     bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().to(device)
     n_fused = bf.fuse_activations(bmodel)
+    n_ln = bf.fuse_residual_layernorm(bmodel) if os.environ.get("BF_BENCH_NO_LN_FUSION") is None else 0
     if dtype != "fp32":
         bmodel = bmodel.to(torch.bfloat16 if dtype == "bf16" else torch.float16)
     g = torch.Generator().manual_seed(654)
@@ -139,7 +142,8 @@ def make_bert_large_qa(device, S, dtype):
                 "sample": f"1 MC sample (fwd + log-probs) of the same BERT-large B=16 L=384 batch, torch-CPU fp32, {dt:.1f}s"}
 
     cfgd = {"workload": "to_bayesian(BERT-large QA, delta=0.05, freeze=True) fwd+ELBO", "samples_per_gpu": S, "batch": B,
-            "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "gelu_fused_into_gemm": n_fused}
+            "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "gelu_fused_into_gemm": n_fused,
+            "residual_layernorm_fused": n_ln}
     return step, cpu_baseline, cfgd, bmodel
 
 

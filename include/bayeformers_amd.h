@@ -172,6 +172,14 @@ int bf_embedding_bwd(const int64_t* d_ids, const void* d_grad, int grad_dtype, c
                      float* d_drho, int64_t n_tokens, int64_t tokens_per_sample, int64_t V, int D, uint64_t seed,
                      uint32_t sample_base, uint32_t stream_id, void* stream);
 
+/* out = LayerNorm(x + residual) * gamma + beta over the last axis (biased variance, eps inside the square root), one
+ * pass over HBM: the consumer of a Bayesian dense layer's output in the transformer blocks the reference converts
+ * (HF BertSelfOutput/BertOutput around bnn.Linear.forward, bayeformers/nn/layers/linear.py:83-104).  x, residual
+ * (nullable: plain LayerNorm) and out are [rows, N] of `dtype`; gamma/beta are [N] of `param_dtype` (BF_DT_F32 or
+ * `dtype`).  The sum and the statistics are fp32.  N % 8 == 0, N <= 8192, 16-byte aligned pointers. */
+int bf_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, int param_dtype,
+                     void* d_out, int dtype, int64_t rows, int N, float eps, void* stream);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * While enabled, every sampling launch (kind BF_PROF_SAMPLE) and every GEMM launch (BF_PROF_GEMM) made through
  * this library is bracketed by two events; bf_profile_read() synchronises them and returns, per kind, the number

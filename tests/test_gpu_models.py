@@ -128,6 +128,51 @@ def test_fused_gelu_matches_unfused_bert():
     assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("rows,N", [(37, 768), (5, 8), (130, 1024), (9, 1544), (3, 4096), (2, 8192), (0, 768)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_add_layernorm_kernel(dtype, rows, N, with_res):
+    """bf_add_layernorm against the fp32 torch ops it replaces (add, then layer_norm), incl. ragged row/width counts."""
+    from bayeformers_amd import ops
+
+    g = torch.Generator().manual_seed(rows * 131 + N)
+    x = (torch.randn(rows, N, generator=g) * 2 + 0.5).to(dtype).cuda()
+    r = torch.randn(rows, N, generator=g).to(dtype).cuda() if with_res else None
+    for pdt in (torch.float32, dtype):
+        gamma = (1 + 0.1 * torch.randn(N, generator=g)).to(pdt).cuda()
+        beta = (0.1 * torch.randn(N, generator=g)).to(pdt).cuda()
+        out = ops.add_layernorm(x, r, gamma, beta, 1e-12)
+        assert out.shape == x.shape and out.dtype == dtype
+        z = x.float() + (r.float() if with_res else 0)
+        ref = torch.nn.functional.layer_norm(z, (N,), gamma.float(), beta.float(), 1e-12)
+        tol = {torch.float32: 2e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+        if rows:
+            assert (out.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+def test_fused_residual_layernorm_matches_unfused_bert():
+    """fuse_residual_layernorm(): same logits (bf16 rounding apart) and identical log-probs as the framework ops;
+    with gradients enabled the fused blocks run the framework ops, so training still works."""
+    cfg, model = _bert(True)
+    outs = []
+    for fuse in (False, True):
+        bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().cuda().to(torch.bfloat16)
+        if fuse:
+            assert bf.fuse_residual_layernorm(bmodel) == 2 * cfg.num_hidden_layers
+        torch.manual_seed(3)
+        ids = torch.randint(0, cfg.vocab_size, (4, 16)).cuda()
+        bf.manual_seed(SEED)
+        with torch.no_grad():
+            raw, mean, lp, lq = sample_bayesian(bmodel, {"input_ids": ids}, 3)
+        outs.append((raw[0].float(), float(lp), float(lq)))
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 2e-2
+    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+    bf.manual_seed(SEED)
+    raw, mean, lp, lq = sample_bayesian(bmodel, {"input_ids": ids}, 3)   # grad mode: framework ops inside
+    mean[0].float().sum().backward()
+    assert any(p.grad is not None and p.grad.abs().sum() > 0 for p in bmodel.parameters())
+
+
 @pytest.mark.parametrize("dtype,tol", [("fp16", 2e-2), ("bf16", 8e-2)])
 def test_bert_large_qa_c5(golden_dir, dtype, tol):
     """BASELINE config 5: to_bayesian(BERT-large QA), S=10, seq=384, batch=16, fp16 MFMA (and bf16), vs the reference."""
@@ -147,6 +192,7 @@ def test_bert_large_qa_c5(golden_dir, dtype, tol):
     tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
     bmodel = bmodel.cuda().to(tdt)
     bf.fuse_activations(bmodel)
+    bf.fuse_residual_layernorm(bmodel)
     bf.manual_seed(SEED)
     bf.set_compute_dtype(dtype)
     try:
