@@ -1,4 +1,5 @@
 // bf_api.hip — the extern "C" surface declared in include/bayeformers_amd.h.
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -315,11 +316,34 @@ int bf_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamm
 
 // workspace layout of bf_linear_bwd
 struct BwdLayout {
-    size_t w, wt, dyt, xt, dw, db, lp, part, total;
+    size_t w, wt, dyt, xt, dw, db, dbp, lp, part, total;
+    int splits;
 };
+
+// Split-K factor of the weight-gradient GEMM dW_s = dy[s]^T x[s] (reduction over the M rows of the batch): with
+// S * ceil(N/256) * ceil(K/256) output tiles a layer like 768x768 fills 90 of the 256 CUs, so the M axis is cut into
+// `splits` chunks that run as extra batch entries and leave fp32 partial products for param_grad to add up.  Picks
+// the factor minimising rounds * (k-steps per tile + fixed tile cost) + the partials' extra HBM traffic.
+static int bwd_splits(int S, int M, int N, int K, int dtype) {
+    if (dtype == BF_DT_F32) return 1;
+    const double tiles = (double)S * ((N + 255) / 256) * ((K + 255) / 256);
+    int best = 1;
+    double best_cost = 1e30;
+    for (int sp = 1; sp <= 16; sp *= 2) {
+        if (M % (64 * sp) || M / sp < 256) break;
+        const double rounds = ceil(tiles * sp / 256.0);
+        const double ksteps = (double)M / sp / 64.0;
+        const double traffic_us = sp > 1 ? (double)sp * S * N * K * 8.0 / 3.0e6 : 0.0;  // write + read at ~3 TB/s
+        const double cost = rounds * (ksteps + 6.0) * 2.0 + traffic_us;                  // ~2 us per 256x256x64 k-step
+        if (cost < best_cost) best_cost = cost, best = sp;
+    }
+    return best;
+}
+
 static BwdLayout bwd_layout(int S, int M, int N, int K, int has_bias, int dtype) {
     const size_t es = bf_dtype_size(dtype);
     BwdLayout L;
+    L.splits = bwd_splits(S, M, N, K, dtype);
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t o = off;
@@ -330,8 +354,9 @@ static BwdLayout bwd_layout(int S, int M, int N, int K, int has_bias, int dtype)
     L.wt = take((size_t)S * N * K * es);
     L.dyt = take((size_t)S * N * M * es);
     L.xt = take((size_t)S * K * M * es);
-    L.dw = take((size_t)S * N * K * sizeof(float));
+    L.dw = take((size_t)L.splits * S * N * K * sizeof(float));
     L.db = take(has_bias ? (size_t)S * N * sizeof(float) : 0);
+    L.dbp = take(has_bias ? bf_colsum_workspace_bytes(S, M, N) : 0);
     L.lp = take((size_t)S * 2 * sizeof(double));
     bf_tensor_t t;
     memset(&t, 0, sizeof(t));
@@ -377,27 +402,32 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
         if ((rc = bf_launch_gemm_nt(d_dy, dtype, (int64_t)M * N, ws + L.wt, dtype, nullptr, d_dx, dtype, S, M, K, N, stream)))
             return rc;
     }
-    // 3. dW_s = dy[s]^T x[s] = (dy^T [N][M]) x (x^T [K][M])^T, fp32 out
-    if ((rc = bf_launch_transpose(d_dy, ws + L.dyt, es, S, M, N, stream))) return rc;
-    const int xs_batch = x_sample_stride == 0 ? 1 : S;
-    if ((rc = bf_launch_transpose(d_x, ws + L.xt, es, xs_batch, M, K, stream))) return rc;
+    // 3. dW_s = dy[s]^T x[s] = (dy^T [N][M]) x (x^T [K][M])^T, fp32 out.  With split-K the M axis is cut into `sp`
+    //    chunks that are transposed (and multiplied) as sp * S batch entries of M / sp rows each.
+    const int sp = x_sample_stride == 0 ? 1 : L.splits;
+    const int Mc = M / sp;
+    if ((rc = bf_launch_transpose(d_dy, ws + L.dyt, es, S * sp, Mc, N, stream))) return rc;
+    const int xs_batch = x_sample_stride == 0 ? 1 : S * sp;
+    if ((rc = bf_launch_transpose(d_x, ws + L.xt, es, xs_batch, Mc, K, stream))) return rc;
     // operands: "x" = dy^T [S][N][M] (stride N*M), "w" = x^T [S][K][M]; a shared x is broadcast by passing it S times
     if (x_sample_stride == 0) {
         for (int s = 0; s < S; ++s)
             if ((rc = bf_launch_gemm_nt(ws + L.dyt + (size_t)s * N * M * es, dtype, 0, ws + L.xt, dtype, nullptr,
                                         ws + L.dw + (size_t)s * N * K * sizeof(float), BF_DT_F32, 1, N, K, M, stream)))
                 return rc;
-    } else if ((rc = bf_launch_gemm_nt(ws + L.dyt, dtype, (int64_t)N * M, ws + L.xt, dtype, nullptr, ws + L.dw, BF_DT_F32,
-                                       S, N, K, M, stream))) {
+    } else if ((rc = bf_launch_gemm_nt(ws + L.dyt, dtype, (int64_t)N * Mc, ws + L.xt, dtype, nullptr, ws + L.dw, BF_DT_F32,
+                                       S * sp, N, K, Mc, stream))) {
         return rc;
     }
-    // 4. reduce over samples with eps regenerated
-    if ((rc = bf_launch_param_grad(reinterpret_cast<const float*>(ws + L.dw), weight->d_rho, weight->n, S, seed,
+    // 4. reduce over samples (and split-K partials) with eps regenerated
+    if ((rc = bf_launch_param_grad(reinterpret_cast<const float*>(ws + L.dw), weight->d_rho, weight->n, S, sp, seed,
                                    sample_base, weight->stream_id, d_dmu_w, d_drho_w, stream)))
         return rc;
     if (bias) {
-        if ((rc = bf_launch_colsum(d_dy, dtype, reinterpret_cast<float*>(ws + L.db), S, M, N, stream))) return rc;
-        if ((rc = bf_launch_param_grad(reinterpret_cast<const float*>(ws + L.db), bias->d_rho, bias->n, S, seed,
+        if ((rc = bf_launch_colsum(d_dy, dtype, reinterpret_cast<float*>(ws + L.db), S, M, N,
+                                   reinterpret_cast<float*>(ws + L.dbp), stream)))
+            return rc;
+        if ((rc = bf_launch_param_grad(reinterpret_cast<const float*>(ws + L.db), bias->d_rho, bias->n, S, 1, seed,
                                        sample_base, bias->stream_id, d_dmu_b, d_drho_b, stream)))
             return rc;
     }

@@ -55,9 +55,82 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, f
     if (lane_r == 0 && n < N) out[(long long)s * N + n] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
+// 16-bit transpose, 64x64 tile, 16-byte global accesses on both sides.  Rows are packed in pairs into dwords on the
+// way into LDS, so that the transposed image tileT[c][r/2] is read back as 16-byte vectors of 8 consecutive r.
+// The 4-dword chunks of a tileT row are XOR-swizzled with (c >> 3): conflict-free 4-byte writes and 16-byte reads.
+// Requires rows % 64 == 0, cols % 64 == 0 and 16-byte aligned bases.
+__global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                          int rows, int cols) {
+    __shared__ __attribute__((aligned(16))) uint32_t tileT[64][32];
+    const long long b = blockIdx.z;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    in += b * (long long)rows * cols;
+    out += b * (long long)rows * cols;
+    const int t = threadIdx.x;
+    {
+        const int rp = t >> 3, cv = t & 7;  // row pair 0..31, 8-column vector 0..7
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        const u32x4 a = *reinterpret_cast<const u32x4*>(in + (long long)(r0 + 2 * rp) * cols + c0 + cv * 8);
+        const u32x4 bq = *reinterpret_cast<const u32x4*>(in + (long long)(r0 + 2 * rp + 1) * cols + c0 + cv * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t ea = (j & 1) ? (a[j >> 1] >> 16) : (a[j >> 1] & 0xffffu);
+            const uint32_t eb = (j & 1) ? (bq[j >> 1] >> 16) : (bq[j >> 1] & 0xffffu);
+            const int c = cv * 8 + j;
+            tileT[c][(((rp >> 2) ^ cv) << 2) | (rp & 3)] = ea | (eb << 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int c = pass * 32 + (t >> 3), rv = t & 7;  // output row c, 8 consecutive r = 4 dwords
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&tileT[c][(rv ^ ((c >> 3) & 7)) << 2]);
+        *reinterpret_cast<u32x4*>(out + (long long)(c0 + c) * rows + r0 + rv * 8) = v;
+    }
+}
+
+// column sums of dy[s] ([M][N], 16-bit), 16-byte loads: block = 64 column-vectors (512 columns) x 4 row lanes over a
+// chunk of kColsumRows rows; partial[s][chunk][n] is reduced by colsum_finish_kernel (deterministic order).
+constexpr int kColsumRows = 256;
+template <typename T, typename V8>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ dy, float* __restrict__ partial,
+                                                             int M, int N, int chunks) {
+    __shared__ float sh[4][64][8];
+    const int s = blockIdx.z, ch = blockIdx.y, cv = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const T* p = dy + (long long)s * M * N;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int m1 = min(M, (ch + 1) * kColsumRows);
+    if (cv * 8 < N) {
+        for (int m = ch * kColsumRows + rl; m < m1; m += 4) {
+            const V8 v = *reinterpret_cast<const V8*>(p + (long long)m * N + cv * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sh[rl][threadIdx.x & 63][i] = acc[i];
+    __syncthreads();
+    if (rl == 0 && cv * 8 < N) {
+        float* o = partial + ((long long)s * chunks + ch) * N + cv * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            o[i] = (sh[0][threadIdx.x][i] + sh[1][threadIdx.x][i]) + (sh[2][threadIdx.x][i] + sh[3][threadIdx.x][i]);
+    }
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            int N, int chunks) {
+    const int s = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int c = 0; c < chunks; ++c) acc += partial[((long long)s * chunks + c) * N + n];
+    out[(long long)s * N + n] = acc;
+}
+
 // dmu[e] = sum_s dw[s][e];  drho[e] = (sum_s dw[s][e] * eps(s, e)) * softplus'(rho[e]).  thread = 4 scalars.
+// dw is [S][splits][n]: the split-K partial products of one sample are summed first.
 __global__ __launch_bounds__(256) void param_grad_kernel(const float* __restrict__ dw, const float* __restrict__ rho,
-                                                         unsigned long long n, int S, uint32_t k0, uint32_t k1,
+                                                         unsigned long long n, int S, int splits, uint32_t k0, uint32_t k1,
                                                          uint32_t sample_base, const uint32_t* __restrict__ counter,
                                                          uint32_t stream, float* __restrict__ dmu,
                                                          float* __restrict__ drho) {
@@ -70,12 +143,16 @@ __global__ __launch_bounds__(256) void param_grad_kernel(const float* __restrict
     for (int s = 0; s < S; ++s) {
         float z[4];
         bf_normal4_dev((uint32_t)g, (uint32_t)(g >> 32), sample_base + (uint32_t)s, stream, k0, k1, z);
-        const float* p = dw + (unsigned long long)s * n + e0;
+        const float* p = dw + (unsigned long long)s * splits * n + e0;
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < splits; ++j, p += n) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i] += i < nv ? p[i] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float d = i < nv ? p[i] : 0.f;
-            sm[i] += d;
-            se[i] = fmaf(d, z[i], se[i]);
+            sm[i] += d[i];
+            se[i] = fmaf(d[i], z[i], se[i]);
         }
     }
     for (int i = 0; i < nv; ++i) {
@@ -304,7 +381,9 @@ int bf_launch_transpose(const void* d_in, void* d_out, int elem_size, int batch,
     if (!d_in || !d_out) BF_FAIL("bf_transpose: NULL argument");
     if (batch < 1 || rows < 1 || cols < 1 || batch > 65535) BF_FAIL("bf_transpose: bad shape %d x %d x %d", batch, rows, cols);
     dim3 grid((cols + 63) / 64, (rows + 63) / 64, batch);
-    if (elem_size == 2)
+    if (elem_size == 2 && rows % 64 == 0 && cols % 64 == 0 && (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0)
+        hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, stream, (const uint16_t*)d_in, (uint16_t*)d_out, rows, cols);
+    else if (elem_size == 2)
         hipLaunchKernelGGL(transpose_kernel<uint16_t>, grid, dim3(256), 0, stream, (const uint16_t*)d_in, (uint16_t*)d_out, rows, cols);
     else if (elem_size == 4)
         hipLaunchKernelGGL(transpose_kernel<uint32_t>, grid, dim3(256), 0, stream, (const uint32_t*)d_in, (uint32_t*)d_out, rows, cols);
@@ -314,8 +393,26 @@ int bf_launch_transpose(const void* d_in, void* d_out, int elem_size, int batch,
     return 0;
 }
 
-int bf_launch_colsum(const void* d_dy, int dtype, float* d_out, int S, int M, int N, hipStream_t stream) {
+size_t bf_colsum_workspace_bytes(int S, int M, int N) {
+    return (size_t)S * ((M + kColsumRows - 1) / kColsumRows) * N * sizeof(float);
+}
+
+int bf_launch_colsum(const void* d_dy, int dtype, float* d_out, int S, int M, int N, float* d_partial,
+                     hipStream_t stream) {
     if (!d_dy || !d_out) BF_FAIL("bf_colsum: NULL argument");
+    if (dtype != BF_DT_F32 && N % 8 == 0 && d_partial && ((uintptr_t)d_dy & 15) == 0 && S <= 65535) {
+        const int chunks = (M + kColsumRows - 1) / kColsumRows;
+        dim3 pgrid((N / 8 + 63) / 64, chunks, S);
+        if (dtype == BF_DT_BF16)
+            hipLaunchKernelGGL((colsum_partial_kernel<__bf16, bf16x8_t>), pgrid, dim3(256), 0, stream, (const __bf16*)d_dy,
+                               d_partial, M, N, chunks);
+        else
+            hipLaunchKernelGGL((colsum_partial_kernel<_Float16, f16x8_t>), pgrid, dim3(256), 0, stream,
+                               (const _Float16*)d_dy, d_partial, M, N, chunks);
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256, S), dim3(256), 0, stream, d_partial, d_out, N, chunks);
+        BF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     dim3 grid((N + 63) / 64, S);
     if (dtype == BF_DT_BF16)
         hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(256), 0, stream, (const __bf16*)d_dy, d_out, M, N);
@@ -327,13 +424,13 @@ int bf_launch_colsum(const void* d_dy, int dtype, float* d_out, int S, int M, in
     return 0;
 }
 
-int bf_launch_param_grad(const float* d_dw, const float* d_rho, uint64_t n, int S, uint64_t seed, uint32_t sample_base,
-                         uint32_t stream_id, float* d_dmu, float* d_drho, hipStream_t stream) {
+int bf_launch_param_grad(const float* d_dw, const float* d_rho, uint64_t n, int S, int splits, uint64_t seed,
+                         uint32_t sample_base, uint32_t stream_id, float* d_dmu, float* d_drho, hipStream_t stream) {
     if (!d_dw || !d_rho || !d_drho) BF_FAIL("bf_param_grad: NULL argument");
-    if (n == 0 || S < 1) BF_FAIL("bf_param_grad: empty");
+    if (n == 0 || S < 1 || splits < 1) BF_FAIL("bf_param_grad: empty");
     const uint64_t groups = (n + 3) / 4;
     hipLaunchKernelGGL(param_grad_kernel, dim3((uint32_t)((groups + 255) / 256)), dim3(256), 0, stream, d_dw, d_rho,
-                       (unsigned long long)n, S, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, bf_sample_counter(), stream_id, d_dmu,
+                       (unsigned long long)n, S, splits, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, bf_sample_counter(), stream_id, d_dmu,
                        d_drho);
     BF_HIP_CHECK(hipGetLastError());
     return 0;

@@ -74,9 +74,11 @@ __device__ __forceinline__ f32x4_t bf_apply_act(f32x4_t v, int act) {
     return v;
 }
 int bf_launch_transpose(const void* d_in, void* d_out, int elem_size, int batch, int rows, int cols, hipStream_t stream);
-int bf_launch_colsum(const void* d_dy, int dtype, float* d_out, int S, int M, int N, hipStream_t stream);
-int bf_launch_param_grad(const float* d_dw, const float* d_rho, uint64_t n, int S, uint64_t seed, uint32_t sample_base,
-                         uint32_t stream_id, float* d_dmu, float* d_drho, hipStream_t stream);
+size_t bf_colsum_workspace_bytes(int S, int M, int N);
+int bf_launch_colsum(const void* d_dy, int dtype, float* d_out, int S, int M, int N, float* d_partial,
+                     hipStream_t stream);
+int bf_launch_param_grad(const float* d_dw, const float* d_rho, uint64_t n, int S, int splits, uint64_t seed,
+                         uint32_t sample_base, uint32_t stream_id, float* d_dmu, float* d_drho, hipStream_t stream);
 int bf_launch_reduce_partials(const double* d_partials, uint32_t nrows, int S, double* d_out, hipStream_t stream);
 bool bf_fused_small_supported(int x_dtype, int y_dtype, int compute_dtype, int64_t x_sample_stride, const void* d_x,
                               const bf_tensor_t* weight, const bf_tensor_t* bias, int S, int M, int N, int K);

@@ -70,6 +70,49 @@ def test_gradients_match_reference(golden_dir, name, dtype, rtol, planned):
     assert not model.log_prior().requires_grad
 
 
+@pytest.mark.parametrize("M,N,K,S", [(1024, 320, 192, 3), (512, 200, 136, 2), (2048, 768, 768, 2)])
+@pytest.mark.parametrize("planned", [False, True])
+def test_gradients_large_shapes_fast_paths(M, N, K, S, planned):
+    """Shapes that take the backward's fast paths (16-byte transposes, split-K weight-gradient GEMM, vectorised
+    column sums) against fp64 autograd of the oracle's restatement of linear.py:97,104 with the same epsilon."""
+    from oracle import bayes_oracle as bo
+
+    g = torch.Generator().manual_seed(M + N)
+    layer = bnn.Linear(K, N)
+    layer.weight.mu.data = torch.randn(N, K, generator=g) * 0.05
+    layer.weight.rho.data = -3.0 + 0.3 * torch.randn(N, K, generator=g)
+    layer.bias.mu.data = torch.randn(N, generator=g) * 0.05
+    layer.bias.rho.data = -3.0 + 0.3 * torch.randn(N, generator=g)
+    layer.layer_id = 0
+    layer = layer.cuda()
+    model = bnn.Model(layer)
+    model.cross_layer_sampling = planned
+    x = torch.randn(S * M, K, generator=g)
+    gy = torch.randn(S * M, N, generator=g)
+    xd = x.cuda().bfloat16().requires_grad_(True)
+    base = 9
+    bf.manual_seed(SEED, next_sample=base)
+    with model.monte_carlo(S):
+        y = model(xd)
+    y.backward(gy.cuda().bfloat16())
+
+    xr = x.bfloat16().double().requires_grad_(True)
+    gyr = gy.bfloat16().double()
+    ps = [p.detach().cpu().double().requires_grad_(True)
+          for p in (layer.weight.mu, layer.weight.rho, layer.bias.mu, layer.bias.rho)]
+    loss = 0
+    for s in range(S):
+        w = ps[0] + torch.nn.functional.softplus(ps[1]) * bo.eps_tensor((N, K), SEED, base + s, 0, 0).double()
+        b = ps[2] + torch.nn.functional.softplus(ps[3]) * bo.eps_tensor((N,), SEED, base + s, 0, 1).double()
+        loss = loss + (torch.nn.functional.linear(xr[s * M:(s + 1) * M], w, b) * gyr[s * M:(s + 1) * M]).sum()
+    loss.backward()
+    got = [xd.grad, layer.weight.mu.grad, layer.weight.rho.grad, layer.bias.mu.grad, layer.bias.rho.grad]
+    ref = [xr.grad] + [p.grad for p in ps]
+    for a, r, what in zip(got, ref, ("dx", "dmu_w", "drho_w", "dmu_b", "drho_b")):
+        err = (a.double().cpu() - r).abs().max().item()
+        assert err <= 3e-2 * r.abs().max().item(), (what, err, r.abs().max().item())
+
+
 def test_backward_through_a_small_mlp_is_finite_and_deterministic():
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.ReLU(), torch.nn.Linear(128, 10))
