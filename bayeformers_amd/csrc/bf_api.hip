@@ -406,7 +406,14 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
     //    chunks that are transposed (and multiplied) as sp * S batch entries of M / sp rows each.
     const int sp = x_sample_stride == 0 ? 1 : L.splits;
     const int Mc = M / sp;
-    if ((rc = bf_launch_transpose(d_dy, ws + L.dyt, es, S * sp, Mc, N, stream))) return rc;
+    const bool fused_colsum = bias && bf_transpose_colsum_supported(dtype, S * sp, Mc, N, d_dy, ws + L.dyt);
+    if (fused_colsum) {  // the bias gradient's column sums ride along with the transpose of dy
+        if ((rc = bf_launch_transpose_colsum(d_dy, ws + L.dyt, dtype, S * sp, Mc, N, sp, reinterpret_cast<float*>(ws + L.dbp),
+                                             reinterpret_cast<float*>(ws + L.db), stream)))
+            return rc;
+    } else if ((rc = bf_launch_transpose(d_dy, ws + L.dyt, es, S * sp, Mc, N, stream))) {
+        return rc;
+    }
     const int xs_batch = x_sample_stride == 0 ? 1 : S * sp;
     if ((rc = bf_launch_transpose(d_x, ws + L.xt, es, xs_batch, Mc, K, stream))) return rc;
     // operands: "x" = dy^T [S][N][M] (stride N*M), "w" = x^T [S][K][M]; a shared x is broadcast by passing it S times
@@ -424,8 +431,8 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
                                    sample_base, weight->stream_id, d_dmu_w, d_drho_w, stream)))
         return rc;
     if (bias) {
-        if ((rc = bf_launch_colsum(d_dy, dtype, reinterpret_cast<float*>(ws + L.db), S, M, N,
-                                   reinterpret_cast<float*>(ws + L.dbp), stream)))
+        if (!fused_colsum && (rc = bf_launch_colsum(d_dy, dtype, reinterpret_cast<float*>(ws + L.db), S, M, N,
+                                                    reinterpret_cast<float*>(ws + L.dbp), stream)))
             return rc;
         if ((rc = bf_launch_param_grad(reinterpret_cast<const float*>(ws + L.db), bias->d_rho, bias->n, S, 1, seed,
                                        sample_base, bias->stream_id, d_dmu_b, d_drho_b, stream)))

@@ -59,8 +59,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, f
 // way into LDS, so that the transposed image tileT[c][r/2] is read back as 16-byte vectors of 8 consecutive r.
 // The 4-dword chunks of a tileT row are XOR-swizzled with (c >> 3): conflict-free 4-byte writes and 16-byte reads.
 // Requires rows % 64 == 0, cols % 64 == 0 and 16-byte aligned bases.
+//
+// SUM_DT != 0 (BF_DT_BF16 / BF_DT_F16): the block also leaves the column sums of its 64 rows, in fp32, at
+// colpart[(b * gridDim.y + blockIdx.y) * cols + c] — the bias gradient's partial sums for free while dy is transposed.
+template <int SUM_DT>
 __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                          int rows, int cols) {
+                                                          int rows, int cols, float* __restrict__ colpart) {
     __shared__ __attribute__((aligned(16))) uint32_t tileT[64][32];
     const long long b = blockIdx.z;
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -87,6 +91,22 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __rest
         typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
         const u32x4 v = *reinterpret_cast<const u32x4*>(&tileT[c][(rv ^ ((c >> 3) & 7)) << 2]);
         *reinterpret_cast<u32x4*>(out + (long long)(c0 + c) * rows + r0 + rv * 8) = v;
+        if constexpr (SUM_DT != 0) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (SUM_DT == BF_DT_BF16) {
+                    acc += __builtin_bit_cast(float, v[j] << 16) + __builtin_bit_cast(float, v[j] & 0xffff0000u);
+                } else {
+                    const auto h = __builtin_bit_cast(__attribute__((ext_vector_type(2))) _Float16, v[j]);
+                    acc += (float)h[0] + (float)h[1];
+                }
+            }
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            acc += __shfl_xor(acc, 4);
+            if (rv == 0) colpart[((long long)b * gridDim.y + blockIdx.y) * cols + c0 + c] = acc;
+        }
     }
 }
 
@@ -382,7 +402,8 @@ int bf_launch_transpose(const void* d_in, void* d_out, int elem_size, int batch,
     if (batch < 1 || rows < 1 || cols < 1 || batch > 65535) BF_FAIL("bf_transpose: bad shape %d x %d x %d", batch, rows, cols);
     dim3 grid((cols + 63) / 64, (rows + 63) / 64, batch);
     if (elem_size == 2 && rows % 64 == 0 && cols % 64 == 0 && (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0)
-        hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, stream, (const uint16_t*)d_in, (uint16_t*)d_out, rows, cols);
+        hipLaunchKernelGGL(transpose16_kernel<0>, grid, dim3(256), 0, stream, (const uint16_t*)d_in, (uint16_t*)d_out, rows,
+                           cols, (float*)nullptr);
     else if (elem_size == 2)
         hipLaunchKernelGGL(transpose_kernel<uint16_t>, grid, dim3(256), 0, stream, (const uint16_t*)d_in, (uint16_t*)d_out, rows, cols);
     else if (elem_size == 4)
@@ -394,7 +415,34 @@ int bf_launch_transpose(const void* d_in, void* d_out, int elem_size, int batch,
 }
 
 size_t bf_colsum_workspace_bytes(int S, int M, int N) {
-    return (size_t)S * ((M + kColsumRows - 1) / kColsumRows) * N * sizeof(float);
+    // the larger of the two partial layouts: 64-row chunks (fused into the transpose) / kColsumRows-row chunks
+    return (size_t)S * ((M + 63) / 64) * N * sizeof(float);
+}
+
+bool bf_transpose_colsum_supported(int dtype, int batch, int rows, int cols, const void* d_in, const void* d_out) {
+    return dtype != BF_DT_F32 && rows % 64 == 0 && cols % 64 == 0 && batch >= 1 && batch <= 65535 &&
+           (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0;
+}
+
+// transpose of a 16-bit [batch][rows][cols] tensor that also yields out_sums[g][c] = sum of the rows of each group of
+// `batch_per_group` consecutive batch entries (d_partial: batch * rows / 64 * cols floats of scratch)
+int bf_launch_transpose_colsum(const void* d_in, void* d_out, int dtype, int batch, int rows, int cols,
+                               int batch_per_group, float* d_partial, float* d_out_sums, hipStream_t stream) {
+    if (!d_in || !d_out || !d_partial || !d_out_sums) BF_FAIL("bf_transpose_colsum: NULL argument");
+    if (!bf_transpose_colsum_supported(dtype, batch, rows, cols, d_in, d_out) || batch % batch_per_group)
+        BF_FAIL("bf_transpose_colsum: unsupported shape %d x %d x %d", batch, rows, cols);
+    dim3 grid(cols / 64, rows / 64, batch);
+    if (dtype == BF_DT_BF16)
+        hipLaunchKernelGGL(transpose16_kernel<BF_DT_BF16>, grid, dim3(256), 0, stream, (const uint16_t*)d_in, (uint16_t*)d_out,
+                           rows, cols, d_partial);
+    else
+        hipLaunchKernelGGL(transpose16_kernel<BF_DT_F16>, grid, dim3(256), 0, stream, (const uint16_t*)d_in, (uint16_t*)d_out,
+                           rows, cols, d_partial);
+    const int groups = batch / batch_per_group, chunks = batch_per_group * (rows / 64);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 255) / 256, groups), dim3(256), 0, stream, d_partial, d_out_sums,
+                       cols, chunks);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int bf_launch_colsum(const void* d_dy, int dtype, float* d_out, int S, int M, int N, float* d_partial,

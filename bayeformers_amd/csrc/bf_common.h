@@ -75,6 +75,9 @@ __device__ __forceinline__ f32x4_t bf_apply_act(f32x4_t v, int act) {
 }
 int bf_launch_transpose(const void* d_in, void* d_out, int elem_size, int batch, int rows, int cols, hipStream_t stream);
 size_t bf_colsum_workspace_bytes(int S, int M, int N);
+bool bf_transpose_colsum_supported(int dtype, int batch, int rows, int cols, const void* d_in, const void* d_out);
+int bf_launch_transpose_colsum(const void* d_in, void* d_out, int dtype, int batch, int rows, int cols,
+                               int batch_per_group, float* d_partial, float* d_out_sums, hipStream_t stream);
 int bf_launch_colsum(const void* d_dy, int dtype, float* d_out, int S, int M, int N, float* d_partial,
                      hipStream_t stream);
 int bf_launch_param_grad(const float* d_dw, const float* d_rho, uint64_t n, int S, int splits, uint64_t seed,
