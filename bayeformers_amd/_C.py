@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbayeformers_amd.so")
+LIB_PATH = os.environ.get("BF_LIB_PATH") or os.path.join(_HERE, "lib", "libbayeformers_amd.so")  # BF_LIB_PATH: developer A/B of kernel variants
 
 BF_DT_F32, BF_DT_BF16, BF_DT_F16 = 0, 1, 2
 BF_PRIOR_MIXTURE, BF_PRIOR_GAUSSIAN, BF_PRIOR_NONE = 0, 1, 2
