@@ -41,17 +41,24 @@ __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = a[i], v[4 + i] = b[i];
 }
+#ifndef BF_LN_NT_STORES
+#define BF_LN_NT_STORES 1
+#endif
+__device__ __forceinline__ void st16(f32x4_t* p, f32x4_t v) {
+    if (BF_LN_NT_STORES) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 __device__ __forceinline__ void store8(__bf16* p, const float (&v)[8]) {
-    *reinterpret_cast<bf16x8_t*>(p) =
-        __builtin_convertvector((f32x8_t{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}), bf16x8_t);
+    const bf16x8_t t = __builtin_convertvector((f32x8_t{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}), bf16x8_t);
+    st16(reinterpret_cast<f32x4_t*>(p), __builtin_bit_cast(f32x4_t, t));
 }
 __device__ __forceinline__ void store8(_Float16* p, const float (&v)[8]) {
-    *reinterpret_cast<f16x8_t*>(p) =
-        __builtin_convertvector((f32x8_t{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}), f16x8_t);
+    const f16x8_t t = __builtin_convertvector((f32x8_t{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}), f16x8_t);
+    st16(reinterpret_cast<f32x4_t*>(p), __builtin_bit_cast(f32x4_t, t));
 }
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
-    *reinterpret_cast<f32x4_t*>(p) = f32x4_t{v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4_t*>(p + 4) = f32x4_t{v[4], v[5], v[6], v[7]};
+    st16(reinterpret_cast<f32x4_t*>(p), f32x4_t{v[0], v[1], v[2], v[3]});
+    st16(reinterpret_cast<f32x4_t*>(p + 4), f32x4_t{v[4], v[5], v[6], v[7]});
 }
 
 constexpr int kRowsPerBlock = 4;  // one wave per row

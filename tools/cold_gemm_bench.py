@@ -17,6 +17,9 @@ gam, bet = torch.ones(K, device="cuda").bfloat16(), torch.zeros(K, device="cuda"
 ws = [torch.randn(S, N, K, device="cuda").bfloat16() for _ in range(3)]
 b = torch.randn(S, N, device="cuda")
 big = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+tiny = torch.zeros(64, device="cuda")
+ma, mb = torch.randn(2048, 2048, device="cuda").bfloat16(), torch.randn(2048, 2048, device="cuda").bfloat16()
+mc = torch.empty(2048, 2048, device="cuda", dtype=torch.bfloat16)
 
 
 def run(mode, iters=40):
@@ -28,9 +31,15 @@ def run(mode, iters=40):
             xin = ops.add_layernorm(x, r, gam, bet, 1e-12)
         elif mode == "ln_elsewhere":
             other.copy_(ops.add_layernorm(other, r, gam, bet, 1e-12))
+        elif mode == "ln_then_tiny":
+            xin = ops.add_layernorm(x, r, gam, bet, 1e-12)
+            tiny.add_(1)
+        elif mode == "ln_then_20us":
+            xin = ops.add_layernorm(x, r, gam, bet, 1e-12)
+            torch.mm(ma, mb, out=mc)
         elif mode == "flush":
             big.zero_()
-        src = xin if mode == "ln_inplace_out" else x
+        src = xin if mode in ("ln_inplace_out", "ln_then_tiny", "ln_then_20us") else x
         for j in range(3):
             ev[it][j].record()
             ops.gemm_nt(src, ws[j], b, S, M, N, K, M * K, torch.bfloat16)
@@ -40,5 +49,5 @@ def run(mode, iters=40):
     print(f"{mode:16s}: GEMM1 {t[0]:6.1f} us  GEMM2 {t[1]:6.1f} us  GEMM3 {t[2]:6.1f} us")
 
 
-for mode in ("none", "ln_elsewhere", "ln_rewrites_x", "ln_inplace_out", "flush", "none"):
+for mode in ("none", "ln_rewrites_x", "ln_inplace_out", "ln_then_tiny", "ln_then_20us", "flush", "none"):
     run(mode)
