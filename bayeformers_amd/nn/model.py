@@ -134,6 +134,8 @@ class Model(Module):
         try:
             return super(Model, self).__call__(*args, **kwargs)
         finally:
+            if plan is not None:
+                plan.finish(self._lp_buf)  # one log-prob reduction for all the groups this forward sampled
             bfr.STATE.ctx = None
             bfr.commit_samples(S * world)
 

@@ -9,8 +9,8 @@ many layers can be done by ONE launch (bf_sample_logprob_table) ahead of the GEM
     (S x n x 2 B) total about GROUP_BYTES; a group is sampled when its first layer is about to run;
   * groups alternate between two arenas, so the weights a GEMM reads were written a few hundred microseconds
     earlier and are still in the 256 MiB Infinity Cache, and the footprint is 2 groups, not the whole model;
-  * each block leaves one [S][2] fp64 row of partial log-prob sums; one bf_reduce_logprob launch per group turns
-    them into the per-layer {log_prior, log_q}[S] the Model sums — instead of 2 launches per layer.
+  * each block leaves one [S][2] fp64 row of partial log-prob sums; ONE bf_reduce_logprob launch at the end of the
+    forward turns them into the per-layer {log_prior, log_q}[S] the Model sums — instead of 2 launches per layer.
 
 If a layer runs while its arena holds another group (unusual execution order) the group is simply sampled again:
 same counters, same values.
@@ -74,6 +74,7 @@ class SamplePlan:
         arena_bytes = max(group_bytes)
         self.arenas = [torch.empty(arena_bytes, dtype=torch.uint8, device=device) for _ in range(min(2, len(groups)))]
         self.arena_owner = [None] * len(self.arenas)
+        self.pending = set()  # groups sampled in the running forward whose block partials are not reduced yet
 
         # table: entries in layer order (weight, then bias)
         n_entries = sum(1 + (self.slices[id(l)][2] is not None) for l in layers)
@@ -162,7 +163,26 @@ class SamplePlan:
             _C.check(lib.bf_sample_logprob_table(self.blob.data_ptr(), self.n_entries, b0, b1, self.S, seed,
                                                  sample_base & 0xFFFFFFFF, self.partials.data_ptr(), stream),
                      "bf_sample_logprob_table")
-            _C.check(lib.bf_reduce_logprob(self.partials.data_ptr(), self.layer_rows.data_ptr() + 4 * l0, nl, self.S,
-                                           lp_buf.data_ptr() + row0 * self.S * 2 * 8, stream), "bf_reduce_logprob")
+            self.pending.add(gi)
             self.arena_owner[a] = (gi, token)
         return self.views[id(layer)]
+
+    def finish(self, lp_buf: torch.Tensor) -> None:
+        """Reduce the block partials of every group sampled since the last call into the model's [L, S, 2] buffer:
+        one bf_reduce_logprob launch per run of groups whose layers are consecutive rows (normally one per forward)."""
+        if not self.pending:
+            return
+        lib = _C.lib()
+        stream = ops._stream_ptr()
+        run = None  # (first plan-layer, number of layers, first row)
+        for gi in sorted(self.pending) + [None]:
+            span = self.group_span[gi] if gi is not None else None
+            if run is not None and span is not None and span[0] == run[0] + run[1] and span[4] == run[2] + run[1]:
+                run = (run[0], run[1] + span[1], run[2])
+                continue
+            if run is not None:
+                _C.check(lib.bf_reduce_logprob(self.partials.data_ptr(), self.layer_rows.data_ptr() + 4 * run[0], run[1],
+                                               self.S, lp_buf.data_ptr() + run[2] * self.S * 2 * 8, stream),
+                         "bf_reduce_logprob")
+            run = (span[0], span[1], span[4]) if span is not None else None
+        self.pending.clear()
