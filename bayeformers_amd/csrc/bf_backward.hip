@@ -369,9 +369,6 @@ int bf_launch_embedding_bwd(const long long* d_ids, const void* d_grad, int grad
     return 0;
 }
 
-namespace {
-}  // namespace
-
 int bf_launch_kl_grad(const bf_tensor_t* t, int S, uint64_t seed, uint32_t sample_base, const double* d_g,
                       float* d_dmu, float* d_drho, hipStream_t stream) {
     if (!t || !t->d_mu || !t->d_rho || !d_g || !d_drho) BF_FAIL("bf_kl_grad: NULL argument");

@@ -276,3 +276,24 @@ def test_rccl_single_rank_collective_path():
         dist.destroy_process_group()
     assert torch.equal(got[0][0], ref[0][0]) and torch.equal(got[1][0], ref[1][0])
     assert float(got[2]) == float(ref[2]) and float(got[3]) == float(ref[3])
+
+
+def test_sample_sharding_is_invariant_to_the_number_of_ranks():
+    """Row (e): rank r of G runs global samples [base + r*S/G, base + (r+1)*S/G) — its per-sample outputs and
+    log-probs are bit-identical to the same samples of a single-rank run (BASELINE config 4's 8 x 8 split, scaled down)."""
+    cfg, model = _bert(True)
+    bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().cuda().to(torch.bfloat16)
+    torch.manual_seed(5)
+    ids = torch.randint(0, cfg.vocab_size, (3, 16)).cuda()
+    S, G = 8, 4
+    bf.manual_seed(SEED, next_sample=100)
+    with torch.no_grad(), bmodel.monte_carlo(S):
+        full = bmodel(input_ids=ids.repeat(S, 1)).logits.view(S, 3, -1).clone()
+    lp_full = bmodel.log_prob_samples().clone()
+    for r in range(G):
+        bf.manual_seed(SEED, next_sample=100)
+        with torch.no_grad(), bmodel.monte_carlo(S // G, shard=(r, G)):
+            part = bmodel(input_ids=ids.repeat(S // G, 1)).logits.view(S // G, 3, -1)
+        sl = slice(r * S // G, (r + 1) * S // G)
+        assert torch.equal(part, full[sl])
+        assert torch.equal(bmodel.log_prob_samples(), lp_full[sl])
