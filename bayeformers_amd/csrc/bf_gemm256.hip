@@ -302,7 +302,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
         if (wm == 1) __builtin_amdgcn_s_barrier();  // G1 runs one slot behind G0
         init_acc(acc, p.bias ? p.bias + (long long)s * N : nullptr, n0, N, wn, lane);
 
-        for (int kt = 0; kt + 1 < nk; ++kt) kstep([&] { if (!(p.flags & 1)) stage(cur, kt + 1, (g & 1) ^ 1); });
+        for (int kt = 0; kt + 1 < nk; ++kt)
+            kstep([&] { if (!(p.flags & 1)) stage(cur, (p.flags & 64) ? 0 : kt + 1, (g & 1) ^ 1); });
         // last k-step: its DMA slot fetches k-step 0 of this workgroup's next tile
         unsigned vbn = vb + gridDim.x;
         asm volatile("" : "+s"(vbn));  // keep the next tile's address arithmetic out of the k-loop's live ranges

@@ -13,7 +13,8 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int act;      // BF_ACT_* applied to y in the epilogue
     int stagger;  // unused (kept for ABI stability of the kernel argument block)
-    int flags;  // developer ablation bits (BF_GEMM_ABLATE): 1 = no DMA in the k-loop, 2 = no MFMA, 4 = no fragment reads, 8 = no stores
+    int flags;  // developer ablation bits (BF_GEMM_ABLATE): 1 = no DMA in the k-loop, 8 = no stores, 16 = no row mask,
+                // 64 = every k-step's DMA re-reads k-step 0 (operands always L2-hot)
 };
 
 // fast 256x256x64 LDS-DMA kernel (bf_gemm256.hip)
