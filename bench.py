@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="bert_base", choices=["bert_base", "bert_large_qa", "linear768", "linear768_m32", "mlp"])
+    ap.add_argument("--workload", default="bert_base", choices=["bert_base", "bert_large_qa", "linear768", "linear768_m32", "mlp", "bert_base_train"])
     ap.add_argument("--samples", type=int, default=None, help="MC samples per GPU per step (default: workload's)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -53,7 +53,7 @@ class Workload:
     """name, S (per GPU), dtype, step() -> python float (the ELBO), config dict, cpu_baseline() -> dict."""
 
 
-def make_bert(device, S, dtype):
+def make_bert(device, S, dtype, train=False):
     import bayeformers_amd as bf
     from bayeformers_amd.sampling import elbo, sample_bayesian
     from transformers import BertConfig, BertForSequenceClassification
@@ -79,9 +79,24 @@ def make_bert(device, S, dtype):
             nll = torch.nn.functional.cross_entropy(mean[0].float(), labels_d)
             return elbo(lp, lq, nll.double(), n_batches)
 
+    if train:
+        # the reference's training step (examples/bert_glue.py:227-241) — forward, ELBO, backward through
+        # every sampled-weight layer (eps regenerated from the Philox counter), Adam on the unfrozen parameters
+        opt = torch.optim.Adam([p for p in bmodel.parameters() if p.requires_grad], lr=1e-5)
+
+        def step():  # noqa: F811
+            opt.zero_grad(set_to_none=True)
+            raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S)
+            loss = elbo(lp, lq, torch.nn.functional.cross_entropy(mean[0].float(), labels_d).double(), n_batches)
+            loss.backward()
+            opt.step()
+            return loss.detach()
+
     def cpu_baseline():
         from oracle.model_oracle import log_probs, to_oracle
 
+        if train:
+            return None
         omodel = to_oracle(model, delta=0.05).eval()
         n = 2
         with torch.no_grad():
@@ -95,7 +110,8 @@ def make_bert(device, S, dtype):
                 "sample": f"{n} serial MC samples (fwd + log-probs) of the same BERT-base B=32 L=128 batch, "
                           f"torch-CPU fp32, {dt:.1f}s"}
 
-    cfgd = {"workload": "to_bayesian(BERT-base seq-cls, delta=0.05, freeze=True) fwd+ELBO", "samples_per_gpu": S,
+    cfgd = {"workload": "to_bayesian(BERT-base seq-cls, delta=0.05, freeze=True) " +
+                        ("training step: fwd+ELBO+backward+Adam" if train else "fwd+ELBO"), "samples_per_gpu": S,
             "batch": B, "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "bayesian_scalars": 85609730,
             "gelu_fused_into_gemm": n_fused,
             "residual_layernorm_fused": n_ln}
@@ -300,13 +316,17 @@ def main():
     import bayeformers_amd as bf
     from bayeformers_amd import _C
 
-    defaults = {"bert_base": (10, "bf16"), "bert_large_qa": (10, "fp16"), "linear768": (10, "bf16"), "linear768_m32": (10, "bf16"), "mlp": (5, "bf16")}
+    defaults = {"bert_base": (10, "bf16"), "bert_base_train": (10, "bf16"), "bert_large_qa": (10, "fp16"), "linear768": (10, "bf16"), "linear768_m32": (10, "bf16"), "mlp": (5, "bf16")}
     S = args.samples or defaults[args.workload][0]
     dtype = args.dtype or defaults[args.workload][1]
     bf.set_compute_dtype(dtype)
     bf.manual_seed(0x5EED)
     if args.workload == "bert_base":
         step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype)
+    elif args.workload == "bert_base_train":
+        if world > 1:
+            raise SystemExit("bert_base_train is a single-GPU workload (no gradient all-reduce in this bench)")
+        step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype, train=True)
     elif args.workload == "bert_large_qa":
         step, cpu_baseline, cfgd, bmodel = make_bert_large_qa(device, S, dtype)
     elif args.workload == "linear768":
@@ -400,7 +420,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
-        if world == 1 and not args.no_traffic and gn > 0:
+        if world == 1 and not args.no_traffic and gn > 0 and not args.workload.endswith("_train"):
             tr = measure_traffic(args)
             if tr is not None:
                 roofline["traffic"] = round(tr["bytes_per_launch"])
@@ -409,7 +429,8 @@ def main():
                                               "algorithmic": alg_gemm_bytes(bmodel, cfgd, S, dtype)}
         total_samples = S * world * args.steps
         cfgd.update({"parallelism": f"mc-sample-shard x{world}", "last_elbo": last, "hip_graph": bool(use_graph)})
-        out = {"metric": "MC-samples/sec (fwd+ELBO)", "value": round(total_samples / dt, 3), "unit": "MC-samples/s",
+        metric = "MC-samples/sec (fwd+ELBO+backward+Adam)" if args.workload.endswith("_train") else "MC-samples/sec (fwd+ELBO)"
+        out = {"metric": metric, "value": round(total_samples / dt, 3), "unit": "MC-samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": cfgd, "roofline": roofline, "cpu_baseline": cpu}

@@ -124,3 +124,30 @@ def test_error_reporting_without_gpu():
     rc = lib.bf_sample_logprob(None, 1, 1, 0, 0, None, None, 0, None)
     assert rc != 0 and b"tensors is NULL" in lib.bf_last_error()
     assert lib.bf_linear_fwd_workspace_bytes(10, 32, 768, 768, 1, _C.BF_DT_BF16, _C.BF_DT_F32) > 10 * 768 * 768 * 2
+
+
+def test_header_is_plain_c_and_every_entry_links_from_c(tmp_path):
+    """The boundary is a C ABI: include/bayeformers_amd.h compiles as C99 with gcc and a C translation unit that takes
+    the address of every declared entry point links against the shared library (no compute call: no GPU here)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = os.path.join(root, "include", "bayeformers_amd.h")
+    names = sorted(set(re.findall(r"\b(bf_[a-z0-9_]+)\s*\(", open(header).read())) & set(_C.SYMBOLS))
+    assert len(names) == len(_C.SYMBOLS)
+    src = tmp_path / "link_check.c"
+    body = "\n".join(f"    p[{i}] = (fn)&{n};" for i, n in enumerate(names))
+    src.write_text('#include "bayeformers_amd.h"\n#include <stdio.h>\ntypedef void (*fn)(void);\nint main(void) {\n'
+                   f"    fn p[{len(names)}];\n    int i, n = 0;\n{body}\n"
+                   f"    for (i = 0; i < {len(names)}; ++i) n += p[i] != 0;\n"
+                   '    printf("%d %d\\n", bf_version(), n);\n    return 0;\n}\n')
+    exe = tmp_path / "link_check"
+    libdir = os.path.dirname(_C.LIB_PATH)
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src),
+                    "-L", libdir, "-lbayeformers_amd", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out[-1] == str(len(names)) and int(out[0]) == _C.lib().bf_version()
