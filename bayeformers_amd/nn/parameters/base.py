@@ -1,56 +1,50 @@
 # -*- coding: utf-8 -*-
-"""bayeformers_amd.nn.parameters.base
+"""The parameter protocol of the Bayesian layers.
 
-Parameter protocol of the Bayesian layers — same surface as the reference's
-/root/reference/bayeformers/nn/parameters/base.py (parameter :17-32, Parameter :35-52, NoneParameter :55-69).
+API parity with /root/reference/bayeformers/nn/parameters/base.py: `parameter(size)` (:17-32), the abstract
+`Parameter` module with `sample()` / `log_prob(input)` (:35-52) and `NoneParameter`, the stand-in for a missing bias
+(:55-69).
 """
 from typing import Optional
 
 import torch
-import torch.nn as nn
-from torch import Size, Tensor
-from torch.nn import Module
+from torch import Size, Tensor, nn
 
 
 def parameter(size: Size, dtype: Optional[torch.dtype] = torch.float32) -> nn.Parameter:
-    """Zero fp32 parameter of the given size.  Like the reference (base.py:32) the dtype argument is ignored:
-    the variational parameters are fp32 masters whatever precision the matmul runs in."""
+    """A zero-filled float32 nn.Parameter.  `dtype` is accepted and ignored, as in the reference (base.py:32):
+    mu and rho are fp32 masters whatever precision the matrix cores run in."""
+    del dtype
     return nn.Parameter(torch.zeros(size, dtype=torch.float32))
 
 
-class Parameter(Module):
-    """Base class of Bayesian parameters: ``sample()`` and ``log_prob(input)`` (base.py:48-52)."""
-
-    def __init__(self) -> None:
-        super(Parameter, self).__init__()
+class Parameter(nn.Module):
+    """What a layer needs from a posterior or a prior: a draw and a summed log-density."""
 
     def sample(self) -> Tensor:
-        raise NotImplementedError("Sample not implemented yet")
+        raise NotImplementedError(f"{type(self).__name__}.sample is not defined")
 
     def log_prob(self, input: Tensor) -> Tensor:
-        raise NotImplementedError("Log_prob not implemented yet")
+        raise NotImplementedError(f"{type(self).__name__}.log_prob is not defined")
 
     def _apply(self, fn, recurse=True):
-        # Device moves are honoured, precision changes are not: `model.to(torch.bfloat16)` / `.half()` must leave
-        # mu/rho (and the prior's constants) in fp32 — the HIP kernels read fp32 masters and choose the MFMA
-        # operand precision themselves.
-        def keep_fp32(t):
-            out = fn(t)
-            if t.is_floating_point() and out.dtype != t.dtype:
-                out = t.to(device=out.device)
-            return out
+        """`.cuda()` / `.to(device)` move the tensors; `.to(torch.bfloat16)` / `.half()` do NOT change their
+        precision: the HIP kernels read fp32 masters and pick the MFMA operand type themselves."""
 
-        return super(Parameter, self)._apply(keep_fp32, recurse)
+        def device_only(t):
+            moved = fn(t)
+            if t.is_floating_point() and moved.dtype != t.dtype:
+                moved = t.to(device=moved.device)
+            return moved
+
+        return super()._apply(device_only, recurse)
 
 
 class NoneParameter(Parameter):
-    """Proxy for an absent bias: ``sample() -> None``, ``log_prob() -> 0.0`` (base.py:55-69)."""
+    """Absent parameter (a layer built with bias=False): nothing to draw, contributes 0 to every log-density."""
 
-    def __init__(self) -> None:
-        super(NoneParameter, self).__init__()
-
-    def sample(self) -> Tensor:
+    def sample(self) -> None:
         return None
 
-    def log_prob(self, input: Tensor) -> Tensor:
+    def log_prob(self, input: Tensor) -> float:
         return 0.0

@@ -22,6 +22,12 @@ from .initializations import DEFAULT_UNIFORM, Initialization
 LOG_SQRT_2PI = float(np.log(np.sqrt(2 * np.pi)))
 
 
+def _frozen_scalar(value: float) -> nn.Parameter:
+    """0-d fp32 constant kept as a frozen nn.Parameter, so that it appears in the state dict under the reference's
+    key and follows the module across devices."""
+    return nn.Parameter(torch.tensor(float(value), dtype=torch.float32), requires_grad=False)
+
+
 class Gaussian(Parameter):
     """Mean-field Gaussian parametrised by mu and rho, sigma = softplus(rho) = log(1 + exp(rho)).
 
@@ -33,13 +39,12 @@ class Gaussian(Parameter):
     def __init__(self, size: Size, initialization: Optional[Initialization] = DEFAULT_UNIFORM,
                  dtype: Optional[torch.dtype] = torch.float32) -> None:
         super(Gaussian, self).__init__()
-        self.size, self.dtype = size, dtype
+        self.size = size
+        self.dtype = dtype
         self.initialization = initialization
-        self.mu = parameter(self.size, dtype=self.dtype)
-        self.rho = parameter(self.size, dtype=self.dtype)
-
-        self.register_parameter("zero", nn.Parameter(torch.tensor(0.).float(), requires_grad=False))
-        self.register_parameter("one", nn.Parameter(torch.tensor(1.).float(), requires_grad=False))
+        self.mu, self.rho = parameter(size), parameter(size)
+        for name, value in (("zero", 0.0), ("one", 1.0)):  # the reference's N(0, 1) constants: state-dict keys only
+            self.register_parameter(name, _frozen_scalar(value))
 
         # Philox stream of a stand-alone sample(); a bnn.Linear uses 2*layer_id + {0,1} instead.
         self.stream_id = 2 * _bfr.new_layer_id()
@@ -68,7 +73,8 @@ class Gaussian(Parameter):
     def log_prob(self, input: Tensor) -> Tensor:
         """sum[-log sqrt(2 pi) - log sigma - (input - mu)^2 / (2 sigma^2)]  (gaussian.py:103-116)."""
         sigma = self.sigma
-        return (-LOG_SQRT_2PI - torch.log(sigma) - ((input - self.mu) ** 2) / (2 * sigma ** 2)).sum()
+        z = (input - self.mu) / sigma
+        return -(LOG_SQRT_2PI + torch.log(sigma) + 0.5 * z * z).sum()
 
 
 class ScaledGaussianMixture(Parameter):
@@ -78,10 +84,8 @@ class ScaledGaussianMixture(Parameter):
 
     def __init__(self, pi: float, sigma1: float, sigma2: float) -> None:
         super(ScaledGaussianMixture, self).__init__()
-        self.register_parameter("pi", nn.Parameter(torch.tensor(pi).float(), requires_grad=False))
-        self.register_parameter("sigma1", nn.Parameter(torch.tensor(sigma1).float(), requires_grad=False))
-        self.register_parameter("sigma2", nn.Parameter(torch.tensor(sigma2).float(), requires_grad=False))
-        self.register_parameter("zero", nn.Parameter(torch.tensor(0.).float(), requires_grad=False))
+        for name, value in (("pi", pi), ("sigma1", sigma1), ("sigma2", sigma2), ("zero", 0.0)):
+            self.register_parameter(name, _frozen_scalar(value))
         self._consts = None
 
     def constants(self):

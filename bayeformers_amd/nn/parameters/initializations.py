@@ -1,38 +1,45 @@
 # -*- coding: utf-8 -*-
-"""bayeformers_amd.nn.parameters.initializations
+"""Initialisers of a Gaussian's (mu, rho) pair.
 
-Initialisation callbacks for (mu, rho) — same surface as
-/root/reference/bayeformers/nn/parameters/initializations.py (Initialization :14-22, Uniform :25-56, default :60).
-One-off host work, not on the per-step path.
+API parity with /root/reference/bayeformers/nn/parameters/initializations.py: an `Initialization` is a callable
+`(mu, rho) -> (mu, rho)` (:14-22), `Uniform(mu_range, rho_range)` draws both uniformly (:25-56) and
+`DEFAULT_UNIFORM` is U(-0.2, 0.2) for mu, U(-5, -4) for rho (:60).  Construction-time host work only; nothing here
+is on the per-step path.
 """
-from typing import Tuple
+from typing import Sequence, Tuple
 
+import torch
 from torch.nn import Parameter
 
-TwoParameters = Tuple[Parameter, Parameter]
 Range = Tuple[float, float]
+TwoParameters = Tuple[Parameter, Parameter]
 
 
 class Initialization:
-    """Callback that initialises mu and rho in place and returns them."""
+    """Abstract initialiser: subclasses fill mu and rho in place and hand both back."""
 
     def __call__(self, mu: Parameter, rho: Parameter) -> TwoParameters:
-        raise NotImplementedError("Initialization not implemented yet")
+        raise NotImplementedError(f"{type(self).__name__} does not define how to initialise (mu, rho)")
 
 
 class Uniform(Initialization):
-    """mu ~ U(mu_range), rho ~ U(rho_range), drawn from torch's global generator in that order — the same two
-    ``uniform_`` calls as the reference (initializations.py:54-55), so a seeded construction reproduces it."""
+    """mu ~ U(mu_range) first, then rho ~ U(rho_range), both from torch's global generator.
 
-    def __init__(self, mu_range: Range, rho_range: Range) -> None:
-        super(Uniform, self).__init__()
-        self.mu_range, self.rho_range = mu_range, rho_range
+    The draw order and the in-place `uniform_` are what make a seeded construction reproduce the reference's values
+    bit for bit (initializations.py:54-55; checked in tests/test_host_api.py)."""
+
+    def __init__(self, mu_range: Sequence[float], rho_range: Sequence[float]) -> None:
+        self.mu_range = mu_range
+        self.rho_range = rho_range
 
     def __call__(self, mu: Parameter, rho: Parameter) -> TwoParameters:
-        mu.data = mu.data.uniform_(*self.mu_range)
-        rho.data = rho.data.uniform_(*self.rho_range)
+        with torch.no_grad():
+            for tensor, (low, high) in ((mu, self.mu_range), (rho, self.rho_range)):
+                tensor.uniform_(low, high)
         return mu, rho
 
+    def __repr__(self) -> str:
+        return f"Uniform(mu_range={tuple(self.mu_range)}, rho_range={tuple(self.rho_range)})"
 
-"""Default Uniform initialization (initializations.py:60)"""
-DEFAULT_UNIFORM = Uniform((-0.2, 0.2), (-5, -4))
+
+DEFAULT_UNIFORM = Uniform(mu_range=(-0.2, 0.2), rho_range=(-5, -4))
