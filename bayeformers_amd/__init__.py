@@ -21,7 +21,7 @@ from .nn.parameters.initializations import DEFAULT_UNIFORM, Initialization
 from .random import (get_compute_dtype, manual_seed, set_compute_dtype, set_kl_gradient,  # noqa: F401
                      use_device_counter)
 
-__all__ = ["to_bayesian", "fuse_activations", "fuse_residual_layernorm", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
+__all__ = ["to_bayesian", "fuse_activations", "fuse_residual_layernorm", "fuse_shared_inputs", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
            "use_device_counter", "set_kl_gradient"]
 
 
@@ -120,4 +120,23 @@ def fuse_residual_layernorm(model: torch.nn.Module) -> int:
                 and dense.out_features <= 8192 and m.__class__.__name__.endswith("Output")):
             m.forward = types.MethodType(_dense_residual_norm_forward, m)
             fused += 1
+    return fused
+
+
+def fuse_shared_inputs(model: torch.nn.Module, names=("query", "key", "value")) -> int:
+    """Multiply the activations of an attention block by its query / key / value weights in ONE launch
+    (bf_gemm_nt_layers): marks modules that hold `names` as bnn.Linear children of one shape (HF BertSelfAttention
+    and its relatives, which call them on the same hidden states).  The sampling plan then lays their sampled
+    weights out back to back, and whichever of the layers runs first computes all outputs; a layer that is handed a
+    different input simply runs on its own.  Inference-time optimisation: with gradients enabled every layer runs
+    separately.  Returns the number of fused blocks."""
+    fused = 0
+    for m in model.modules():
+        group = tuple(getattr(m, n, None) for n in names)
+        if all(isinstance(l, nn.Linear) for l in group) and len({(l.in_features, l.out_features) for l in group}) == 1:
+            for l in group:
+                l._shared_input = group
+            fused += 1
+    if isinstance(model, Model):
+        model.refresh()
     return fused

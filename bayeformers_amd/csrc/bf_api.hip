@@ -206,6 +206,16 @@ int bf_gemm_nt_act(const void* d_x, int x_dtype, int64_t x_sample_stride, const 
                              (hipStream_t)stream, act);
 }
 
+int bf_gemm_nt_layers(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
+                      const float* d_bias, void* d_y, int y_dtype, int L, int S, int M, int N, int K, int act,
+                      void* stream) {
+    if (act != BF_ACT_NONE && act != BF_ACT_GELU) BF_FAIL("bf_gemm_nt_layers: unknown activation %d", act);
+    if (L < 1) BF_FAIL("bf_gemm_nt_layers: L must be >= 1 (got %d)", L);
+    ProfScope prof(BF_PROF_GEMM, 2.0 * L * S * M * (double)N * K, (hipStream_t)stream);
+    return bf_launch_gemm_nt(d_x, x_dtype, x_sample_stride, d_w, w_dtype, d_bias, d_y, y_dtype, S, M, N, K,
+                             (hipStream_t)stream, act, L);
+}
+
 // workspace layout of bf_linear_fwd: [W_s : S*N*K compute_dtype][b_s : S*N fp32][log-prob partials]
 static void linear_ws_layout(int S, int N, int K, int has_bias, int compute_dtype, size_t* off_w, size_t* off_b,
                              size_t* off_p, size_t* total) {

@@ -50,7 +50,7 @@ int bf_launch_reduce_groups(const double* d_partials, const uint32_t* d_rows, in
                             hipStream_t stream);
 int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
                       const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, hipStream_t stream,
-                      int act = BF_ACT_NONE);
+                      int act = BF_ACT_NONE, int layers = 1);
 
 // erf-GELU x/2 (1 + erf(x / sqrt 2)), the activation of HF BERT's intermediate layer, on the fp32 accumulators.
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32-exact for a bf16/fp16 or fp32 epilogue) on the

@@ -278,7 +278,25 @@ int launch_16_xy(const GemmParams& p, int x_dtype, int y_dtype, int t_dtype, boo
 
 int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
                       const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, hipStream_t stream,
-                      int act) {
+                      int act, int layers) {
+    if (layers < 1) BF_FAIL("bf_gemm_nt: layers must be >= 1 (got %d)", layers);
+    if (layers > 1) {
+        // L layers sharing x: one launch of the 256x256 kernel when it applies, else one launch per layer
+        const bool fast = gemm_variant() != 0 && w_dtype != BF_DT_F32 && (long long)M * N >= 128 * 128 &&
+                          ((uintptr_t)d_bias & 15) == 0 && (long long)layers * S <= 65535 &&
+                          bf_gemm256_supported(x_dtype, w_dtype, y_dtype, layers * S, M, N, K, d_x, d_w, x_sample_stride);
+        if (!fast) {
+            const size_t ws = bf_dtype_size(w_dtype), ys = bf_dtype_size(y_dtype);
+            for (int l = 0; l < layers; ++l) {
+                const int rc = bf_launch_gemm_nt(
+                    d_x, x_dtype, x_sample_stride, (const char*)d_w + (size_t)l * S * N * K * ws, w_dtype,
+                    d_bias ? d_bias + (size_t)l * S * N : nullptr, (char*)d_y + (size_t)l * S * M * N * ys, y_dtype, S,
+                    M, N, K, stream, act, 1);
+                if (rc) return rc;
+            }
+            return 0;
+        }
+    }
     if (!d_x || !d_w || !d_y) BF_FAIL("bf_gemm_nt: NULL operand");
     if (S < 1 || M < 1 || N < 1 || K < 1) BF_FAIL("bf_gemm_nt: bad shape S=%d M=%d N=%d K=%d", S, M, N, K);
     if (S > 65535) BF_FAIL("bf_gemm_nt: S=%d exceeds gridDim.y", S);
@@ -293,6 +311,7 @@ int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, con
     p.N = N;
     p.K = K;
     p.act = act;
+    p.layers = layers;
     if (w_dtype == BF_DT_F32) {
         if (x_dtype != BF_DT_F32 || y_dtype != BF_DT_F32) BF_FAIL("bf_gemm_nt: fp32 weights need fp32 x and y");
         p.tiles_m = (M + FM - 1) / FM;
@@ -305,7 +324,7 @@ int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, con
     // large aligned problems: the 256x256x64 LDS-DMA kernel; everything else: the generic 128x128x32 kernel
     const int variant = gemm_variant();
     if (variant != 0 && (long long)M * N >= 128 * 128 && ((uintptr_t)d_bias & 15) == 0 &&
-        bf_gemm256_supported(x_dtype, w_dtype, y_dtype, S, M, N, K, d_x, d_w, x_sample_stride))
+        bf_gemm256_supported(x_dtype, w_dtype, y_dtype, layers * S, M, N, K, d_x, d_w, x_sample_stride))
         return bf_launch_gemm256(p, w_dtype, y_dtype, stream);
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
     const int M = p.M, N = p.N, K = p.K;
-    const unsigned total = (unsigned)(p.tiles_m * p.tiles_n * p.S);
+    const int tiles_nl = p.tiles_n * p.layers;  // the L layers sharing x form one wide row of n-tiles per m-panel
+    const unsigned total = (unsigned)(p.tiles_m * tiles_nl * p.S);
 
     const int prow = lane >> 3;
     const int kc8 = ((lane & 7) ^ ((((wid & 1) << 2) + (lane >> 4)) & 7)) * 8;
@@ -211,12 +212,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
         const T* wb;
         unsigned xo[4], wo[4];
     };
+    // s = index of the (layer, sample) pair in w / bias / y; the activations only depend on the sample
     auto tile_setup = [&](unsigned vb, Src& t, int& s, int& m0, int& n0) {
-        int tm, tn;
-        tile_coords(xcd_remap(vb, total), p.tiles_m, p.tiles_n, s, tm, tn);
+        int tm, tn, xs;
+        tile_coords(xcd_remap(vb, total), p.tiles_m, tiles_nl, xs, tm, tn);
+        const int layer = tn / p.tiles_n;
+        tn -= layer * p.tiles_n;
+        s = layer * p.S + xs;
         m0 = tm * TM;
         n0 = tn * TN;
-        t.xb = reinterpret_cast<const T*>(p.x) + (long long)s * p.x_sstride;
+        t.xb = reinterpret_cast<const T*>(p.x) + (long long)xs * p.x_sstride;
         t.wb = reinterpret_cast<const T*>(p.w) + (long long)s * N * K;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
 
 template <typename T>
 int launch256(const GemmParams& p, int y_dtype, hipStream_t stream) {
-    const uint32_t tiles = (uint32_t)(p.tiles_m * p.tiles_n * p.S);
+    const uint32_t tiles = (uint32_t)(p.tiles_m * p.tiles_n * p.S * p.layers);
     // persistent: one workgroup per CU (a grid that is a multiple of 8 keeps a workgroup's tiles on one XCD)
     static int n_cu = 0;
     if (!n_cu) {
@@ -362,7 +367,7 @@ bool bf_gemm256_supported(int x_dtype, int w_dtype, int y_dtype, int S, int M, i
     if (((uintptr_t)d_x | (uintptr_t)d_w) & 15) return false;
     if (((size_t)x_sample_stride * 2) % 16 != 0) return false;
     if ((long long)M * K >= (1ll << 32) || (long long)N * K >= (1ll << 32) || (long long)M * N >= (1ll << 31)) return false;
-    const long long tiles = (long long)((M + TM - 1) / TM) * ((N + TN - 1) / TN) * S;
+    const long long tiles = (long long)((M + TM - 1) / TM) * ((N + TN - 1) / TN) * S;  // S counts (layer, sample) pairs
     if (tiles > 0x7FFFFFFFll) return false;
     (void)S;
     return true;
@@ -372,7 +377,7 @@ int bf_launch_gemm256(const GemmParams& p0, int w_dtype, int y_dtype, hipStream_
     GemmParams p = p0;
     const char* ab = getenv("BF_GEMM_ABLATE");
     p.flags = ab ? atoi(ab) : 0;
-    p.stagger = 0;
+    if (p.layers < 1) p.layers = 1;
     p.tiles_m = (p.M + TM - 1) / TM;
     p.tiles_n = (p.N + TN - 1) / TN;
     if (w_dtype == BF_DT_BF16) return launch256<__bf16>(p, y_dtype, stream);

@@ -12,7 +12,7 @@ struct GemmParams {
     int S, M, N, K;
     int tiles_m, tiles_n;
     int act;      // BF_ACT_* applied to y in the epilogue
-    int stagger;  // unused (kept for ABI stability of the kernel argument block)
+    int layers;   // L >= 1 layers that share x: w is [L][S][N][K], bias [L][S][N], y [L][S][M][N] (bf_gemm_nt_layers)
     int flags;  // developer ablation bits (BF_GEMM_ABLATE): 1 = no DMA in the k-loop, 8 = no stores, 16 = no row mask,
                 // 64 = every k-step's DMA re-reads k-step 0 (operands always L2-hot)
 };

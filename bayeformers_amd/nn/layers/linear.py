@@ -99,6 +99,7 @@ class Linear(KernelLayer):
         self._init_kernel_layer()
         self._small_m = False   # seen with <= 64 rows per sample: single fused kernel, left out of the sampling plan
         self.activation = None  # "gelu": exact GELU fused into the GEMM epilogue (bayeformers_amd.fuse_activations)
+        self._shared_input = None  # tuple of layers fed the same activations (bayeformers_amd.fuse_shared_inputs)
         self._plan = ops.LinearPlan()
 
     def forward(self, input: Tensor) -> Tensor:
@@ -129,6 +130,11 @@ class Linear(KernelLayer):
             self._small_m = small  # the model rebuilds its sampling plan without / with this layer next forward
         if ctx is not None and ctx.plan is not None and not small and id(self) in ctx.plan.group_of:
             w_s, b_s = ctx.plan.ensure(self, ctx.token, bfr.STATE.seed, base, ctx.lp_buf)
+            if self._shared_input is not None and not need_grad and not want_act:
+                y = self._stacked_forward(ctx, x2, S)
+                if y is not None:
+                    self._lp_view, self._lp_dirty = slot, True
+                    return y.view(*input.shape[:-1], self.out_features)
             fused = want_act and not need_grad
             y = _PlannedLinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, w_s, b_s, self, S,
                                        bfr.STATE.seed, base, 1 if fused else 0)
@@ -141,6 +147,26 @@ class Linear(KernelLayer):
             y = torch.nn.functional.gelu(y)
         self._end(ctx, slot)
         return y.view(*input.shape[:-1], self.out_features)
+
+    def _stacked_forward(self, ctx, x2: Tensor, S: int) -> Optional[Tensor]:
+        """Layers that read the same activations (query / key / value): whichever of them runs first multiplies x by
+        the stacked sampled weights of all of them in ONE launch (bf_gemm_nt_layers); the others pick their slab up.
+        Returns None when the run is not stacked in this plan or the input is not the one the outputs came from."""
+        run = self._shared_input
+        entry = ctx.plan.stacked.get(id(run[0]))
+        if entry is None or entry[0] != run or ctx.plan.group_of[id(run[0])] != ctx.plan.group_of[id(self)]:
+            return None
+        ident = (x2.data_ptr(), tuple(x2.shape), x2.dtype, x2._version)
+        cached = ctx.shared_out.get(id(run[0]))
+        if cached is None or cached[0] != ident:
+            if x2.dtype != entry[1].dtype or not x2.is_contiguous():
+                return None
+            M = x2.shape[0] // S
+            y = ops.gemm_nt_layers(x2, entry[1], entry[2], len(run), S, M, self.out_features, self.in_features,
+                                   M * self.in_features, x2.dtype)
+            cached = (ident, y)
+            ctx.shared_out[id(run[0])] = cached
+        return cached[1][run.index(self)].view(-1, self.out_features)
 
     @classmethod
     def from_frequentist(cls, linear: Module, initialization: Optional[Initialization] = DEFAULT_UNIFORM,

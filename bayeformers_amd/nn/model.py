@@ -44,6 +44,7 @@ class _ForwardContext:
         self.sample_base, self.S, self._slots = sample_base, S, slots
         self.plan, self.lp_buf = plan, lp_buf
         self.token = next(_TOKENS)
+        self.shared_out = {}  # id(first layer of a stacked run) -> (input identity, [L, S, M, N] outputs)
 
     def slot(self, layer) -> Optional[Tensor]:
         return self._slots.get(id(layer))
@@ -121,9 +122,12 @@ class Model(Module):
             if planned:
                 cdt = bfr.get_compute_dtype()
                 pl = [l for _, l in planned]
-                key = SamplePlan.make_key(pl, S, cdt)
+                shared = tuple(sorted({id(l._shared_input): l._shared_input for l in pl
+                                       if l._shared_input is not None}.values(), key=lambda t: t[0].layer_id))
+                key = SamplePlan.make_key(pl, S, cdt, shared)
                 if self._plan is None or self._plan.key != key:
-                    self._plan = SamplePlan(pl, S, cdt, layers[0].weight.mu.device, index=[i for i, _ in planned])
+                    self._plan = SamplePlan(pl, S, cdt, layers[0].weight.mu.device, index=[i for i, _ in planned],
+                                            shared=shared)
                 plan = self._plan
         rank, world = self._mc_shard
         # every rank reserves the GLOBAL S*world indices and runs its own contiguous slice of them

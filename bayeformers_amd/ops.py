@@ -127,6 +127,18 @@ def gemm_nt(x: Tensor, w: Tensor, bias: Optional[Tensor], S: int, M: int, N: int
     return y
 
 
+def gemm_nt_layers(x: Tensor, w: Tensor, bias: Optional[Tensor], L: int, S: int, M: int, N: int, K: int,
+                   x_sample_stride: int, y_dtype: torch.dtype, act: int = 0) -> Tensor:
+    """y[l][s] = act(x[s] w[l][s]^T + bias[l][s]) for L layers sharing x, one launch (bf_gemm_nt_layers).
+    w: [L,S,N,K]; bias: [L,S,N] fp32 or None; returns [L,S,M,N]."""
+    y = torch.empty((L, S, M, N), dtype=y_dtype, device=x.device)
+    _C.check(_C.lib().bf_gemm_nt_layers(x.data_ptr(), _TORCH2BF[x.dtype], x_sample_stride, w.data_ptr(),
+                                        _TORCH2BF[w.dtype], bias.data_ptr() if bias is not None else None,
+                                        y.data_ptr(), _TORCH2BF[y_dtype], L, S, M, N, K, act, _stream_ptr()),
+             "bf_gemm_nt_layers")
+    return y
+
+
 class LinearPlan:
     """Cached ctypes descriptors of one bnn.Linear (pointers are refreshed per call; structs are reused)."""
 

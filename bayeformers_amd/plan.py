@@ -28,24 +28,44 @@ GROUP_BYTES = 96 << 20
 
 
 class SamplePlan:
-    def __init__(self, layers, S: int, cdt: torch.dtype, device: torch.device, index=None):
+    def __init__(self, layers, S: int, cdt: torch.dtype, device: torch.device, index=None, shared=()):
         """layers: the planned bnn.Linear modules; index[i] = row of layers[i] in the model's [L, S, 2] log-prob
-        buffer (layers that take the single-kernel small-M path are left out, so rows may have gaps)."""
+        buffer (layers that take the single-kernel small-M path are left out, so rows may have gaps).
+        shared: tuples of layers that read the same activations (query/key/value): when such a tuple is a run of
+        consecutive planned layers of one shape its sampled weights are laid out back to back ([L][S][N][K], then
+        [L][S][N] biases) so that ONE bf_gemm_nt_layers launch can multiply them all (self.stacked)."""
         from .nn.parameters.base import NoneParameter
 
         self.S, self.cdt, self.device = S, cdt, device
         self.layers = layers
         self.index = list(index) if index is not None else list(range(len(layers)))
-        self.key = self.make_key(layers, S, cdt)
+        self.key = self.make_key(layers, S, cdt, shared)
         lib = _C.lib()
         esz = 4 if cdt == torch.float32 else 2
 
-        # groups of consecutive layers
+        # runs of layers that share their input and can be stacked: consecutive in the plan, one shape, all with bias
+        pos = {id(l): i for i, l in enumerate(layers)}
+        run_of = {}
+        for tup in shared:
+            idx = [pos.get(id(l)) for l in tup]
+            l0 = tup[0]
+            ok = (None not in idx and idx == list(range(idx[0], idx[0] + len(tup))) and
+                  all(self.index[i] == self.index[idx[0]] + k for k, i in enumerate(idx)) and
+                  all(l.out_features == l0.out_features and l.in_features == l0.in_features and
+                      not isinstance(l.bias, NoneParameter) for l in tup) and
+                  (S * l0.weight.mu.numel() * esz) % 256 == 0 and (S * l0.out_features * 4) % 256 == 0)
+            if ok:
+                for l in tup:
+                    run_of[id(l)] = tuple(tup)
+
+        # groups of consecutive layers (a stackable run is never split)
         self.group_of, groups, cur, cur_bytes = {}, [], [], 0
         prev_row = None
         for l, row in zip(layers, self.index):
             b = S * l.weight.mu.numel() * esz
-            if cur and (cur_bytes + b > GROUP_BYTES or row != prev_row + 1):
+            run = run_of.get(id(l))
+            inside_run = run is not None and run[0] is not l
+            if cur and not inside_run and (cur_bytes + b > GROUP_BYTES or row != prev_row + 1):
                 groups.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(l)
@@ -60,15 +80,26 @@ class SamplePlan:
             return (x + 255) // 256 * 256
 
         self.slices = {}
+        self.stacked = {}  # id(first layer of a run) -> (run, W [L,S,N,K] view, b [L,S,N] view); filled below
+        stacked_off = {}
         group_bytes = []
         for gi, g in enumerate(groups):
             off = 0
             for l in g:
+                self.group_of[id(l)] = gi
+                run = run_of.get(id(l))
+                if run is not None:
+                    if run[0] is l:  # lay the whole run out: all W back to back, then all b
+                        wb, bb = S * l.weight.mu.numel() * esz, S * l.out_features * 4
+                        for k, m in enumerate(run):
+                            self.slices[id(m)] = (gi, off + k * wb, off + len(run) * wb + k * bb)
+                        stacked_off[id(l)] = (gi, off, off + len(run) * wb)
+                        off += len(run) * (wb + bb)
+                    continue
                 wb = align(S * l.weight.mu.numel() * esz)
                 has_bias = not isinstance(l.bias, NoneParameter)
                 bb = align(S * l.out_features * 4) if has_bias else 0
                 self.slices[id(l)] = (gi, off, off + wb if has_bias else None)
-                self.group_of[id(l)] = gi
                 off += wb + bb
             group_bytes.append(off)
         arena_bytes = max(group_bytes)
@@ -100,6 +131,12 @@ class SamplePlan:
                 arr[e].d_sample_out, arr[e].out_dtype = bv.data_ptr(), _C.BF_DT_F32
                 e += 1
             self.views[id(l)] = (wv, bv)
+        for tup in {id(r[0]): r for r in run_of.values()}.values():
+            gi, woff, boff = stacked_off[id(tup[0])]
+            arena = self.arenas[gi % len(self.arenas)]
+            L, N, K = len(tup), tup[0].out_features, tup[0].in_features
+            self.stacked[id(tup[0])] = (tup, arena[woff:woff + L * S * N * K * esz].view(cdt).view(L, S, N, K),
+                                        arena[boff:boff + L * S * N * 4].view(torch.float32).view(L, S, N))
         total = ctypes.c_uint32()
         nbytes = lib.bf_sample_table_bytes(arr, n_entries, ctypes.byref(total))
         blob = torch.empty(nbytes, dtype=torch.uint8, pin_memory=False)
@@ -122,10 +159,10 @@ class SamplePlan:
         self.scalars = sum(l.weight.mu.numel() + (l.out_features if self.slices[id(l)][2] is not None else 0) for l in layers)
 
     @staticmethod
-    def make_key(layers, S, cdt):
+    def make_key(layers, S, cdt, shared=()):
         from .nn.parameters.gaussian import Gaussian
 
-        key = [S, cdt, len(layers)]
+        key = [S, cdt, len(layers), tuple(tuple(l.layer_id for l in t) for t in shared)]
         for l in layers:
             key.append(l.layer_id)
             for g in (l.weight, l.bias, l.weight_prior, l.bias_prior):

@@ -123,6 +123,15 @@ enum { BF_ACT_NONE = 0, BF_ACT_GELU = 1 };
 int bf_gemm_nt_act(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
                    const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, int act, void* stream);
 
+/* L layers that consume the SAME activations (the query / key / value projections of an attention block,
+ * HF BertSelfAttention around bnn.Linear.forward, bayeformers/nn/layers/linear.py:83-104) in ONE launch:
+ *   y[l][s] = act(x[s] W_{l,s}^T + b_{l,s}),  d_w [L][S][N][K], d_bias [L][S][N] (nullable), d_y [L][S][M][N].
+ * An m-panel of x is then shared by the n-tiles of all L layers while it sits in L2.  Falls back to one launch per
+ * layer for shapes the 256x256 kernel does not take. */
+int bf_gemm_nt_layers(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
+                      const float* d_bias, void* d_y, int y_dtype, int L, int S, int M, int N, int K, int act,
+                      void* stream);
+
 /* The whole of Linear.forward (layers/linear.py:83-104) for S Monte-Carlo samples in one call:
  * sample W_s and b_s, accumulate both log-probs, y[s] = x[s] W_s^T + b_s.
  *   weight.n must be N*K (row-major [N][K], as nn.Linear), bias may be NULL (NoneParameter, base.py:55-69);

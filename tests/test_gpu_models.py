@@ -297,3 +297,45 @@ def test_sample_sharding_is_invariant_to_the_number_of_ranks():
         sl = slice(r * S // G, (r + 1) * S // G)
         assert torch.equal(part, full[sl])
         assert torch.equal(bmodel.log_prob_samples(), lp_full[sl])
+
+
+def test_fused_qkv_is_bit_identical_to_separate_launches():
+    """fuse_shared_inputs(): query/key/value of each attention block in one bf_gemm_nt_layers launch — the same
+    tile arithmetic, so logits and log-probs are bit-identical to three launches; also at the C-ABI level against
+    three bf_gemm_nt calls on ragged shapes (fallback path) and 256-tile shapes (single launch)."""
+    from bayeformers_amd import ops
+    from transformers import BertConfig, BertForSequenceClassification
+
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                     vocab_size=1000, max_position_embeddings=128)
+    torch.manual_seed(0)
+    model = BertForSequenceClassification(cfg).eval()
+    torch.manual_seed(3)
+    ids = torch.randint(0, cfg.vocab_size, (4, 64)).cuda()       # 256 rows per sample: the planned GEMM path
+    outs = []
+    for fuse in (False, True):
+        bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().cuda().to(torch.bfloat16)
+        if fuse:
+            assert bf.fuse_shared_inputs(bmodel) == cfg.num_hidden_layers
+        bf.manual_seed(SEED)
+        with torch.no_grad():
+            raw, mean, lp, lq = sample_bayesian(bmodel, {"input_ids": ids}, 3)
+        if fuse:
+            assert len(bmodel._plan.stacked) == cfg.num_hidden_layers
+        outs.append((raw[0].clone(), float(lp), float(lq)))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+    # gradients enabled: every layer runs on its own and autograd works
+    bf.manual_seed(SEED)
+    raw, mean, lp, lq = sample_bayesian(bmodel, {"input_ids": ids}, 3)
+    mean[0].float().sum().backward()
+
+    g = torch.Generator().manual_seed(1)
+    for (L, S, M, N, K) in [(3, 2, 256, 256, 128), (3, 2, 300, 264, 192), (2, 3, 40, 24, 64), (3, 1, 512, 512, 64)]:
+        x = torch.randn(S * M, K, generator=g).cuda().bfloat16()
+        w = torch.randn(L, S, N, K, generator=g).cuda().bfloat16()
+        b = torch.randn(L, S, N, generator=g).cuda()
+        y = ops.gemm_nt_layers(x, w, b, L, S, M, N, K, M * K, torch.bfloat16)
+        for l in range(L):
+            ref = ops.gemm_nt(x, w[l], b[l], S, M, N, K, M * K, torch.bfloat16)
+            assert torch.equal(y[l], ref), (L, S, M, N, K, l)
