@@ -193,6 +193,7 @@ def test_bert_large_qa_c5(golden_dir, dtype, tol):
     bmodel = bmodel.cuda().to(tdt)
     bf.fuse_activations(bmodel)
     bf.fuse_residual_layernorm(bmodel)
+    assert bf.fuse_shared_inputs(bmodel) == cfg.num_hidden_layers
     bf.manual_seed(SEED)
     bf.set_compute_dtype(dtype)
     try:
