@@ -243,14 +243,24 @@ def make_mlp(device, S, dtype):
 
 
 def alg_gemm_bytes(bmodel, cfgd, S, dtype):
-    """Algorithmic HBM bytes per 256x256-tile GEMM launch: S*(M*K + N*K + M*N)*elem, averaged over the Bayesian
-    linears that take that kernel (M = rows per sample >= 128)."""
+    """Algorithmic HBM bytes per 256x256-tile GEMM launch, averaged over the step's launches of that kernel
+    (M = rows per sample >= 128): S*(M*K + N*K + M*N)*elem for a single layer, S*(M*K + L*(N*K + M*N))*elem for L
+    layers that share x in one launch (query/key/value)."""
     es = 4 if dtype == "fp32" else 2
     M = cfgd.get("batch", 1) * cfgd.get("seq_len", 1)
     if M < 128:
         return None
-    tot = [S * (M * l.in_features + l.out_features * l.in_features + M * l.out_features) * es
-           for l in bmodel.fused_children() if not l._small_m]
+    stacked = getattr(getattr(bmodel, "_plan", None), "stacked", {}) or {}
+    tot = []
+    for l in bmodel.fused_children():
+        if getattr(l, "_small_m", True):
+            continue
+        run = getattr(l, "_shared_input", None)
+        if run is not None and id(run[0]) in stacked:
+            if run[0] is l:
+                tot.append(S * (M * l.in_features + len(run) * (l.out_features * l.in_features + M * l.out_features)) * es)
+            continue
+        tot.append(S * (M * l.in_features + l.out_features * l.in_features + M * l.out_features) * es)
     return round(sum(tot) / len(tot)) if tot else None
 
 
