@@ -222,3 +222,36 @@ def test_many_samples_in_one_call(cases):
     _, _, _, lp64, lq64, (mag_p, mag_q) = oracle_layer(c, 1063)
     assert float(lp[63, 0]) == pytest.approx(lp64, abs=LOGPROB_RTOL * mag_p)
     assert float(lp[63, 1]) == pytest.approx(lq64, abs=LOGPROB_RTOL * mag_q)
+
+
+def test_sample_counter_wraps_modulo_2_32():
+    """Monte-Carlo sample indices are 32-bit Philox counter words: a forward that straddles 2^32 uses
+    ..., 2^32 - 1, 0, 1, ... — checked against the oracle's epsilon at the wrapped indices."""
+    from oracle import bayes_oracle as bo
+
+    layer = bnn.Linear(64, 48).cuda()
+    layer.layer_id = 0
+    model = bnn.Model(layer)
+    S, B = 8, 4
+    x = torch.randn(S * B, 64, device="cuda")
+    base = 2 ** 32 - 3
+    bf.manual_seed(SEED, next_sample=base)
+    bf.set_compute_dtype("fp32")
+    try:
+        with torch.no_grad(), model.monte_carlo(S):
+            y = model(x)
+    finally:
+        bf.set_compute_dtype("bf16")
+    lp = model.log_prob_samples().cpu().numpy()
+    mu, rho = layer.weight.mu.detach().cpu(), layer.weight.rho.detach().cpu()
+    bmu, brho = layer.bias.mu.detach().cpu(), layer.bias.rho.detach().cpu()
+    for s in range(S):
+        idx = (base + s) & 0xFFFFFFFF
+        ew, eb = bo.eps_tensor(mu.shape, SEED, idx, 0, 0), bo.eps_tensor(bmu.shape, SEED, idx, 0, 1)
+        w = mu + torch.nn.functional.softplus(rho) * ew
+        b = bmu + torch.nn.functional.softplus(brho) * eb
+        ref = torch.nn.functional.linear(x[s * B:(s + 1) * B].cpu(), w, b)
+        assert (y[s * B:(s + 1) * B].cpu() - ref).abs().max().item() < 1e-4
+        lq = bo.gaussian_log_prob_f64(ew, mu, rho) + bo.gaussian_log_prob_f64(eb, bmu, brho)
+        assert abs(lp[s, 1] / lq - 1) < 1e-6
+    assert bf.random.get_state()[1] == (base + S) & 0xFFFFFFFF
