@@ -6,9 +6,12 @@ The reference samples every layer's weights inside that layer's forward
 many layers can be done by ONE launch (bf_sample_logprob_table) ahead of the GEMMs that consume it:
 
   * the model's bnn.Linear layers are cut, in registration order, into groups whose sampled weights
-    (S x n x 2 B) total about GROUP_BYTES; a group is sampled when its first layer is about to run;
-  * groups alternate between two arenas, so the weights a GEMM reads were written a few hundred microseconds
-    earlier and are still in the 256 MiB Infinity Cache, and the footprint is 2 groups, not the whole model;
+    (S x n x 2 B) total about GROUP_BYTES; group g lives in arena g % R of a ring of R arenas;
+  * when a layer runs whose group is not sampled yet, that group AND as many of the following ones as the ring
+    holds are sampled by one launch — everything that read the arenas being overwritten was enqueued before that
+    point.  The ring is as long as ARENA_BYTES allows: on a 288 GB MI355X BERT-base (1.7 GB of bf16 samples at
+    S = 10) and BERT-large (6 GB) fit whole, i.e. one sampling launch per forward.  Large launches matter: the
+    VALU-bound kernel runs at 0.65 T eps/s in 96 MB launches and at 1.0 T eps/s over the whole model;
   * each block leaves one [S][2] fp64 row of partial log-prob sums; ONE bf_reduce_logprob launch at the end of the
     forward turns them into the per-layer {log_prior, log_q}[S] the Model sums — instead of 2 launches per layer.
 
@@ -24,7 +27,12 @@ from . import _C
 from . import ops
 from . import random as bfr
 
+import os
+
 GROUP_BYTES = 96 << 20
+# Sampled weights held at once: group g lives in arena g % R, R = as many arenas as fit in ARENA_BYTES.  MI355X has
+# 288 GB: BERT-base (S = 10: 1.7 GB of bf16 weights) and BERT-large (6 GB) fit whole, so ONE launch samples the model.
+ARENA_BYTES = int(os.environ.get("BF_PLAN_ARENA_BYTES", str(16 << 30)))
 
 
 class SamplePlan:
@@ -103,8 +111,10 @@ class SamplePlan:
                 off += wb + bb
             group_bytes.append(off)
         arena_bytes = max(group_bytes)
-        self.arenas = [torch.empty(arena_bytes, dtype=torch.uint8, device=device) for _ in range(min(2, len(groups)))]
+        # ring of arenas: group g lives in arena g % R; a launch samples as many consecutive groups as the ring holds
+        self.arenas = [torch.empty(arena_bytes, dtype=torch.uint8, device=device) for _ in range(max(1, min(len(groups), ARENA_BYTES // max(arena_bytes, 1))))]
         self.arena_owner = [None] * len(self.arenas)
+
         self.pending = set()  # groups sampled in the running forward whose block partials are not reduced yet
 
         # table: entries in layer order (weight, then bias)
@@ -189,19 +199,26 @@ class SamplePlan:
             isinstance(l.weight_prior, ok) and isinstance(l.bias_prior, ok) and l.weight.mu.device == dev and
             l.compute_dtype is None for l in layers)
 
+    def _sample_groups(self, first: int, last: int, token, seed: int, sample_base: int):
+        """ONE launch over the (contiguous) blocks of groups first..last; they must map to distinct arenas."""
+        b0, b1 = self.group_span[first][2], self.group_span[last][3]
+        _C.check(_C.lib().bf_sample_logprob_table(self.blob.data_ptr(), self.n_entries, b0, b1, self.S, seed,
+                                                  sample_base & 0xFFFFFFFF, self.partials.data_ptr(),
+                                                  ops._stream_ptr()), "bf_sample_logprob_table")
+        for gi in range(first, last + 1):
+            self.pending.add(gi)
+            self.arena_owner[gi % len(self.arenas)] = (gi, token)
+
     def ensure(self, layer, token, seed: int, sample_base: int, lp_buf: torch.Tensor):
         """Make sure `layer`'s group has been sampled for the forward identified by `token`; returns (W_s, b_s)."""
         gi = self.group_of[id(layer)]
-        a = gi % len(self.arenas)
-        if self.arena_owner[a] != (gi, token):
-            l0, nl, b0, b1, row0 = self.group_span[gi]
-            lib = _C.lib()
-            stream = ops._stream_ptr()
-            _C.check(lib.bf_sample_logprob_table(self.blob.data_ptr(), self.n_entries, b0, b1, self.S, seed,
-                                                 sample_base & 0xFFFFFFFF, self.partials.data_ptr(), stream),
-                     "bf_sample_logprob_table")
-            self.pending.add(gi)
-            self.arena_owner[a] = (gi, token)
+        if self.arena_owner[gi % len(self.arenas)] != (gi, token):
+            # this group and as many of the following ones as the arena ring holds, in one launch: everything that
+            # read the arenas being overwritten was enqueued before this point
+            last = min(len(self.groups), gi + len(self.arenas)) - 1
+            while last > gi and self.arena_owner[last % len(self.arenas)] == (last, token):
+                last -= 1
+            self._sample_groups(gi, last, token, seed, sample_base)
         return self.views[id(layer)]
 
     def finish(self, lp_buf: torch.Tensor) -> None:

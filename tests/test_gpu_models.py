@@ -340,3 +340,34 @@ def test_fused_qkv_is_bit_identical_to_separate_launches():
         for l in range(L):
             ref = ops.gemm_nt(x, w[l], b[l], S, M, N, K, M * K, torch.bfloat16)
             assert torch.equal(y[l], ref), (L, S, M, N, K, l)
+
+
+def test_sampling_launch_granularity_does_not_change_results(monkeypatch):
+    """The plan samples as many groups per launch as its arena ring holds (the whole model on a 288 GB GPU); with a
+    ring of two small arenas the same forward takes many launches and re-uses arenas — outputs and log-probs are
+    bit-identical, also over repeated forwards."""
+    from bayeformers_amd import plan as plan_mod
+    from transformers import BertConfig, BertForSequenceClassification
+
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024,
+                     vocab_size=1000, max_position_embeddings=128)
+    torch.manual_seed(0)
+    model = BertForSequenceClassification(cfg).eval()
+    torch.manual_seed(3)
+    ids = torch.randint(0, cfg.vocab_size, (4, 64)).cuda()
+    outs = []
+    for group_bytes, arena_bytes in ((96 << 20, 16 << 30), (2 << 20, 8 << 20)):
+        monkeypatch.setattr(plan_mod, "GROUP_BYTES", group_bytes)
+        monkeypatch.setattr(plan_mod, "ARENA_BYTES", arena_bytes)
+        bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().cuda().to(torch.bfloat16)
+        bf.fuse_shared_inputs(bmodel)
+        bf.manual_seed(SEED)
+        res = []
+        with torch.no_grad():
+            for _ in range(3):
+                raw, mean, lp, lq = sample_bayesian(bmodel, {"input_ids": ids}, 3)
+                res.append((raw[0].clone(), bmodel.log_prob_samples().clone()))
+        outs.append((res, len(bmodel._plan.groups), len(bmodel._plan.arenas)))
+    assert outs[0][1] == outs[0][2] == 1 and 2 <= outs[1][2] < outs[1][1], outs
+    for (ya, la), (yb, lb) in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(ya, yb) and torch.equal(la, lb)
