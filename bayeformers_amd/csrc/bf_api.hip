@@ -398,17 +398,24 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
     char* ws = reinterpret_cast<char*>(d_workspace);
     const int es = (int)bf_dtype_size(dtype);
 
-    // 1. W_s again (same counters as the forward); no prior term needed
-    bf_tensor_t t = *weight;
-    t.prior.kind = BF_PRIOR_NONE;
-    t.d_sample_out = ws + L.w;
-    t.out_dtype = dtype;
-    int rc = bf_launch_sample_logprob(&t, 1, S, seed, sample_base, reinterpret_cast<double*>(ws + L.lp), ws + L.part,
+    // 1. W_s: the forward's own samples if the caller still holds them (weight->d_sample_out, same dtype), else
+    //    regenerated from the same counters; no prior term needed
+    int rc = 0;
+    const char* w_s = ws + L.w;
+    if (weight->d_sample_out && weight->out_dtype == dtype) {
+        w_s = reinterpret_cast<const char*>(weight->d_sample_out);
+    } else if (d_dx) {
+        bf_tensor_t t = *weight;
+        t.prior.kind = BF_PRIOR_NONE;
+        t.d_sample_out = ws + L.w;
+        t.out_dtype = dtype;
+        rc = bf_launch_sample_logprob(&t, 1, S, seed, sample_base, reinterpret_cast<double*>(ws + L.lp), ws + L.part,
                                       L.total - L.part, stream);
-    if (rc) return rc;
+        if (rc) return rc;
+    }
     if (d_dx) {
         // 2. dx[s] = dy[s] [M][N] x (W_s^T [K][N])^T : the NT kernel wants the reduction axis (n) contiguous in both
-        if ((rc = bf_launch_transpose(ws + L.w, ws + L.wt, es, S, N, K, stream))) return rc;
+        if ((rc = bf_launch_transpose(w_s, ws + L.wt, es, S, N, K, stream))) return rc;
         if ((rc = bf_launch_gemm_nt(d_dy, dtype, (int64_t)M * N, ws + L.wt, dtype, nullptr, d_dx, dtype, S, M, K, N, stream)))
             return rc;
     }

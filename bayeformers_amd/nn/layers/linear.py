@@ -29,8 +29,14 @@ def _backward(ctx, grad):
     (x,) = ctx.saved_tensors
     layer, S, seed, base, cdt = ctx.layer, ctx.S, ctx.seed, ctx.base, ctx.cdt
     need_x, need_mu_w, _, need_mu_b, _ = ctx.needs_input_grad[:5]
+    w_samples = None
+    kept = getattr(ctx, "kept", None)
+    if kept is not None:
+        plan, gi, token, w_s = kept
+        if plan.arena_owner[gi % len(plan.arenas)] == (gi, token):  # no later forward has overwritten the arena
+            w_samples = w_s
     with bfr.counter_override(ctx.counter):
-        return ops.linear_backward(layer, x, grad, S, seed, base, cdt, need_x, need_mu_w, need_mu_b)
+        return ops.linear_backward(layer, x, grad, S, seed, base, cdt, need_x, need_mu_w, need_mu_b, w_samples)
 
 
 class _LinearFn(torch.autograd.Function):
@@ -58,6 +64,9 @@ class _PlannedLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, w_s, b_s, layer, S, seed, base, act):
         ctx.layer, ctx.S, ctx.seed, ctx.base = layer, S, seed, base
+        fwd = bfr.STATE.ctx
+        if fwd is not None and fwd.plan is not None and id(layer) in fwd.plan.group_of:
+            ctx.kept = (fwd.plan, fwd.plan.group_of[id(layer)], fwd.token, w_s)  # see _backward
         ctx.counter = bfr.counter_snapshot()
         ctx.cdt = w_s.dtype
         ctx.save_for_backward(x)

@@ -223,7 +223,7 @@ def planned_linear_forward(x: Tensor, w_s: Tensor, b_s: Optional[Tensor], S: int
 
 
 def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_base: int, cdt: torch.dtype,
-                    need_x: bool, need_mu_w: bool, need_mu_b: bool):
+                    need_x: bool, need_mu_w: bool, need_mu_b: bool, w_samples: Optional[Tensor] = None):
     """Gradients of the sampled-weight linear layer (bf_linear_bwd).  Returns (dx, dmu_w, drho_w, dmu_b, drho_b);
     entries that are not needed are None.  x: [S*M, K] as saved by the forward; grad_y: [S*M, N]."""
     from .nn.parameters.base import NoneParameter
@@ -237,6 +237,9 @@ def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_
     dev = x.device
     w, b = _C.bf_tensor_t(), _C.bf_tensor_t()
     fill_tensor(w, layer.weight, NoneParameter(), 2 * layer.layer_id)
+    if w_samples is not None and w_samples.dtype == cdt:
+        # the forward's W_s are still resident (sampling plan): read instead of regenerated
+        w.d_sample_out, w.out_dtype = w_samples.data_ptr(), _TORCH2BF[cdt]
     if has_bias:
         fill_tensor(b, layer.bias, NoneParameter(), 2 * layer.layer_id + 1)
     dx = torch.empty((S * M, K), dtype=cdt, device=dev) if need_x else None

@@ -148,7 +148,9 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
  * F.linear(input, mu + eps*softplus(rho), ...) (layers/linear.py:97,104, gaussian.py:100-101) with eps a constant and
  * the two log-prob scalars detached (linear.py:99-102: the KL terms carry no gradient in the reference).
  *   dx[s] = dy[s] W_s;  dW_s = dy[s]^T x[s];  dmu = sum_s dW_s;  drho = (sum_s dW_s*eps_s) * softplus'(rho); same for b.
- * eps is regenerated from (seed, sample_base + s, stream) — the same values the forward used.  x, dy and dx share
+ * eps is regenerated from (seed, sample_base + s, stream) — the same values the forward used; W_s is regenerated
+ * too unless weight->d_sample_out still holds the forward's samples ([S][N][K] of `dtype`, weight->out_dtype ==
+ * dtype), in which case they are read from there.  x, dy and dx share
  * one dtype, which is also the MFMA operand type (BF16 | F16 | F32).  Any of d_dx, d_dmu_w, d_dmu_b may be NULL
  * (not needed); d_drho_b/d_dmu_b are ignored when bias is NULL.  Gradients are written, not accumulated. */
 size_t bf_linear_bwd_workspace_bytes(int S, int M, int N, int K, int has_bias, int dtype);

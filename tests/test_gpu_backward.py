@@ -215,3 +215,29 @@ def test_training_loop_reduces_the_elbo():
         bf.set_kl_gradient(False)
     assert all(np.isfinite(losses))
     assert losses[-1] < 0.85 * losses[0], (losses[0], losses[-1])
+
+
+def test_backward_after_a_later_forward_regenerates_the_samples():
+    """The backward reads the forward's sampled weights while the sampling plan still holds them; if another forward
+    has overwritten them in between (fwd 1, fwd 2, bwd 1) it regenerates them from the Philox counter — same grads."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(256, 512), torch.nn.ReLU(), torch.nn.Linear(512, 256))
+    bmodel = bf.to_bayesian(net, delta=0.05).cuda()
+    S = 2
+    x = torch.randn(S * 256, 256, device="cuda").bfloat16()
+    gy = torch.randn(S * 256, 256, device="cuda").bfloat16()
+
+    def grads(interleave):
+        bmodel.zero_grad()
+        bf.manual_seed(SEED)
+        with bmodel.monte_carlo(S):
+            y = bmodel(x)
+            if interleave:
+                with torch.no_grad():
+                    bmodel(x)  # draws the next sample indices into the same arenas
+        assert bmodel._plan is not None
+        y.backward(gy)
+        return [p.grad.clone() for p in bmodel.parameters() if p.grad is not None]
+
+    for a, b in zip(grads(False), grads(True)):
+        assert torch.equal(a, b)
