@@ -140,11 +140,17 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 }
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                             int N, int chunks) {
-    const int s = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    // block = 64 columns x 4 chunk lanes (the chunk axis is 64-128 long: one serial thread per column was
+    // latency-bound at 18 us per call); fixed summation order -> deterministic
+    __shared__ float sh[4][64];
+    const int s = blockIdx.y, n = blockIdx.x * 64 + (threadIdx.x & 63), cl = threadIdx.x >> 6;
     float acc = 0.f;
-    for (int c = 0; c < chunks; ++c) acc += partial[((long long)s * chunks + c) * N + n];
-    out[(long long)s * N + n] = acc;
+    if (n < N)
+        for (int c = cl; c < chunks; c += 4) acc += partial[((long long)s * chunks + c) * N + n];
+    sh[cl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (cl == 0 && n < N)
+        out[(long long)s * N + n] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
 // dmu[e] = sum_s dw[s][e];  drho[e] = (sum_s dw[s][e] * eps(s, e)) * softplus'(rho[e]).  thread = 4 scalars.
@@ -436,7 +442,7 @@ int bf_launch_transpose_colsum(const void* d_in, void* d_out, int dtype, int bat
         hipLaunchKernelGGL(transpose16_kernel<BF_DT_F16>, grid, dim3(256), 0, stream, (const uint16_t*)d_in, (uint16_t*)d_out,
                            rows, cols, d_partial);
     const int groups = batch / batch_per_group, chunks = batch_per_group * (rows / 64);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 255) / 256, groups), dim3(256), 0, stream, d_partial, d_out_sums,
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 63) / 64, groups), dim3(256), 0, stream, d_partial, d_out_sums,
                        cols, chunks);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
@@ -454,7 +460,7 @@ int bf_launch_colsum(const void* d_dy, int dtype, float* d_out, int S, int M, in
         else
             hipLaunchKernelGGL((colsum_partial_kernel<_Float16, f16x8_t>), pgrid, dim3(256), 0, stream,
                                (const _Float16*)d_dy, d_partial, M, N, chunks);
-        hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256, S), dim3(256), 0, stream, d_partial, d_out, N, chunks);
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64, S), dim3(256), 0, stream, d_partial, d_out, N, chunks);
         BF_HIP_CHECK(hipGetLastError());
         return 0;
     }
