@@ -21,7 +21,7 @@ from .nn.parameters.initializations import DEFAULT_UNIFORM, Initialization
 from .random import (get_compute_dtype, manual_seed, set_compute_dtype, set_kl_gradient,  # noqa: F401
                      use_device_counter)
 
-__all__ = ["to_bayesian", "fuse_activations", "fuse_residual_layernorm", "fuse_shared_inputs", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
+__all__ = ["to_bayesian", "fuse_activations", "fuse_residual_layernorm", "fuse_shared_inputs", "fuse_attention", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
            "use_device_counter", "set_kl_gradient"]
 
 
@@ -140,3 +140,59 @@ def fuse_shared_inputs(model: torch.nn.Module, names=("query", "key", "value")) 
     if isinstance(model, Model):
         model.refresh()
     return fused
+
+
+_ATTENTION_NAME = "bayeformers_amd"
+
+
+def _attention_interface(module, query, key, value, attention_mask, dropout: float = 0.0, scaling=None, **kwargs):
+    """Attention function in the HuggingFace `AttentionInterface` convention: query/key/value [B, H, T, D], returns
+    ([B, T, H, D], None).  Runs bf_attention_fwd when it applies (inference, no dropout, head size 64, T a multiple of
+    128, no mask or a key-padding mask); anything else goes to the framework's scaled-dot-product attention."""
+    from transformers.integrations.sdpa_attention import sdpa_attention_forward
+
+    from . import ops
+
+    usable = (dropout == 0.0 and not (torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or
+                                                                    value.requires_grad))
+              and not kwargs.get("is_causal", False) and ops.attention_supported(query, key, value))
+    key_mask = None
+    if usable and attention_mask is not None:
+        m = attention_mask
+        B, H, T, _ = query.shape
+        # a padding mask: [B, 1, 1 or T (broadcast), T]; per-query structure is not handled here
+        if m.dim() == 4 and m.shape[0] == B and m.shape[1] == 1 and m.shape[3] == T and (m.shape[2] == 1 or m.stride(2) == 0):
+            row = m[:, 0, 0, :]
+            if row.dtype == torch.bool:
+                key_mask = torch.zeros(row.shape, dtype=torch.float32, device=row.device).masked_fill_(~row, float("-inf"))
+            else:
+                key_mask = row.to(torch.float32).contiguous()
+        else:
+            usable = False
+    if not usable:
+        return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
+    scale = scaling if scaling is not None else query.shape[-1] ** -0.5
+    return ops.attention_forward(query, key, value, key_mask, scale), None
+
+
+def fuse_attention(model: torch.nn.Module) -> bool:
+    """Route the wrapped HuggingFace model's attention through bf_attention_fwd: registers an attention function in
+    transformers' AttentionInterface (mask format: the scaled-dot-product one) and selects it in the model's config.
+    The function falls back to the framework's attention for anything it does not take.  Returns False (and changes
+    nothing) when the model has no HuggingFace config or transformers lacks the interface."""
+    try:
+        from transformers import AttentionInterface
+        from transformers.masking_utils import AttentionMaskInterface, sdpa_mask
+    except ImportError:
+        return False
+    inner = model.model if isinstance(model, Model) and model.model is not None else model
+    config = getattr(inner, "config", None)
+    if config is None or not hasattr(config, "_attn_implementation"):
+        return False
+    AttentionInterface.register(_ATTENTION_NAME, _attention_interface)
+    AttentionMaskInterface.register(_ATTENTION_NAME, sdpa_mask)
+    for m in inner.modules():
+        c = getattr(m, "config", None)
+        if c is not None and hasattr(c, "_attn_implementation"):
+            c._attn_implementation = _ATTENTION_NAME
+    return True

@@ -324,6 +324,12 @@ int bf_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamm
                                    (hipStream_t)stream);
 }
 
+int bf_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, void* d_out, int dtype,
+                     int B, int T, int H, int head_dim, int64_t token_stride, float scaling, void* stream) {
+    return bf_launch_attention_fwd(d_q, d_k, d_v, d_mask, d_out, dtype, B, T, H, head_dim, token_stride, scaling,
+                                   (hipStream_t)stream);
+}
+
 // workspace layout of bf_linear_bwd
 struct BwdLayout {
     size_t w, wt, dyt, xt, dw, db, dbp, lp, part, total;

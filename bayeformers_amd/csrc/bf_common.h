@@ -100,3 +100,6 @@ int bf_launch_embedding_bwd(const long long* d_ids, const void* d_grad, int grad
 int bf_launch_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta,
                             int param_dtype, void* d_out, int dtype, long long rows, int N, float eps,
                             hipStream_t stream);
+int bf_launch_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, void* d_out, int dtype,
+                            int B, int T, int H, int head_dim, long long token_stride, float scaling,
+                            hipStream_t stream);

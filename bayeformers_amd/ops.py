@@ -326,3 +326,28 @@ def add_layernorm(x: Tensor, residual: Optional[Tensor], gamma: Tensor, beta: Te
                                        beta.data_ptr(), _TORCH2BF[gamma.dtype], out.data_ptr(), _TORCH2BF[x.dtype],
                                        x2.shape[0], N, float(eps), _stream_ptr()), "bf_add_layernorm")
     return out.view(x.shape)
+
+
+def attention_supported(q: Tensor, k: Tensor, v: Tensor) -> bool:
+    """q, k, v as the attention hook gets them: [B, H, T, 64] views of the projections' [B*T, H*64] outputs."""
+    if not (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and k.dtype == q.dtype and v.dtype == q.dtype):
+        return False
+    if q.dim() != 4 or q.shape != k.shape or q.shape != v.shape:
+        return False
+    B, H, T, D = q.shape
+    if D != 64 or T < 128 or T % 128 or B > 65535 or H > 65535:
+        return False
+    st = (T * H * D, D, H * D, 1)  # BHTD view of a contiguous [B, T, H, D] tensor
+    return all(t.stride() == st and t.data_ptr() % 16 == 0 for t in (q, k, v))
+
+
+def attention_forward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tensor], scaling: float) -> Tensor:
+    """softmax(q k^T * scaling + key_mask) v (bf_attention_fwd).  q, k, v: [B, H, T, 64] views as described by
+    attention_supported; key_mask: additive fp32 [B, T] or None.  Returns [B, T, H, 64] contiguous."""
+    B, H, T, D = q.shape
+    out = torch.empty((B, T, H, D), dtype=q.dtype, device=q.device)
+    _C.check(_C.lib().bf_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                       key_mask.data_ptr() if key_mask is not None else None, out.data_ptr(),
+                                       _TORCH2BF[q.dtype], B, T, H, D, H * D, float(scaling), _stream_ptr()),
+             "bf_attention_fwd")
+    return out

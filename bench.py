@@ -66,6 +66,7 @@ def make_bert(device, S, dtype, train=False):
     n_fused = bf.fuse_activations(bmodel)  # BertIntermediate: dense + exact GELU in one GEMM epilogue
     n_ln = bf.fuse_residual_layernorm(bmodel) if os.environ.get("BF_BENCH_NO_LN_FUSION") is None else 0
     n_qkv = bf.fuse_shared_inputs(bmodel) if os.environ.get("BF_BENCH_NO_QKV_FUSION") is None else 0
+    attn = bf.fuse_attention(bmodel) if os.environ.get("BF_BENCH_NO_ATTENTION") is None else False
     if dtype != "fp32":
         bmodel = bmodel.to(torch.bfloat16 if dtype == "bf16" else torch.float16)
     g = torch.Generator().manual_seed(321)
@@ -115,7 +116,8 @@ def make_bert(device, S, dtype, train=False):
                         ("training step: fwd+ELBO+backward+Adam" if train else "fwd+ELBO"), "samples_per_gpu": S,
             "batch": B, "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "bayesian_scalars": 85609730,
             "gelu_fused_into_gemm": n_fused,
-            "residual_layernorm_fused": n_ln, "qkv_in_one_launch": n_qkv}
+            "residual_layernorm_fused": n_ln, "qkv_in_one_launch": n_qkv,
+            "attention_kernel": bool(attn)}
     return step, cpu_baseline, cfgd, bmodel
 
 
@@ -133,6 +135,7 @@ def make_bert_large_qa(device, S, dtype):
     n_fused = bf.fuse_activations(bmodel)
     n_ln = bf.fuse_residual_layernorm(bmodel) if os.environ.get("BF_BENCH_NO_LN_FUSION") is None else 0
     n_qkv = bf.fuse_shared_inputs(bmodel) if os.environ.get("BF_BENCH_NO_QKV_FUSION") is None else 0
+    attn = bf.fuse_attention(bmodel) if os.environ.get("BF_BENCH_NO_ATTENTION") is None else False
     if dtype != "fp32":
         bmodel = bmodel.to(torch.bfloat16 if dtype == "bf16" else torch.float16)
     g = torch.Generator().manual_seed(654)
@@ -161,7 +164,8 @@ def make_bert_large_qa(device, S, dtype):
 
     cfgd = {"workload": "to_bayesian(BERT-large QA, delta=0.05, freeze=True) fwd+ELBO", "samples_per_gpu": S, "batch": B,
             "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "gelu_fused_into_gemm": n_fused,
-            "residual_layernorm_fused": n_ln, "qkv_in_one_launch": n_qkv}
+            "residual_layernorm_fused": n_ln, "qkv_in_one_launch": n_qkv,
+            "attention_kernel": bool(attn)}
     return step, cpu_baseline, cfgd, bmodel
 
 

@@ -191,6 +191,16 @@ int bf_embedding_bwd(const int64_t* d_ids, const void* d_grad, int grad_dtype, c
 int bf_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, int param_dtype,
                      void* d_out, int dtype, int64_t rows, int N, float eps, void* stream);
 
+/* out[b][t][h][:] = softmax_keys(q[b][t][h] . k[b][:][h] * scaling + mask[b][:]) v[b][:][h] — the attention that sits
+ * between the Bayesian query/key/value projections and the Bayesian output projection of the transformers the
+ * reference converts (HF BertSelfAttention around bnn.Linear.forward, bayeformers/nn/layers/linear.py:83-104; the
+ * reference runs whatever the wrapped model runs there).  Inference-time forward.  q, k, v: element (b, t, h, d) at
+ * ((b*T + t) * token_stride + h*head_dim + d) of `dtype` (BF16 | F16) — i.e. the [B*T, H*head_dim] outputs of the
+ * projections as they are; d_mask: additive fp32 [B][T] over the keys (-inf = masked), nullable; d_out: [B][T][H][head_dim]
+ * contiguous.  head_dim == 64, T a multiple of 128, 16-byte aligned pointers; anything else is refused (status 1). */
+int bf_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, void* d_out, int dtype,
+                     int B, int T, int H, int head_dim, int64_t token_stride, float scaling, void* stream);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * While enabled, every sampling launch (kind BF_PROF_SAMPLE) and every GEMM launch (BF_PROF_GEMM) made through
  * this library is bracketed by two events; bf_profile_read() synchronises them and returns, per kind, the number

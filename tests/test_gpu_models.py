@@ -371,3 +371,62 @@ def test_sampling_launch_granularity_does_not_change_results(monkeypatch):
     assert outs[0][1] == outs[0][2] == 1 and 2 <= outs[1][2] < outs[1][1], outs
     for (ya, la), (yb, lb) in zip(outs[0][0], outs[1][0]):
         assert torch.equal(ya, yb) and torch.equal(la, lb)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float16, 3e-3)])
+@pytest.mark.parametrize("B,T,H", [(3, 128, 2), (2, 384, 3), (1, 256, 12)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attention_kernel_matches_sdpa(dtype, tol, B, T, H, masked):
+    """bf_attention_fwd against torch scaled_dot_product_attention in fp32 (same inputs), with and without a
+    key-padding mask (incl. a fully padded tail), on the [B, H, T, 64] views the HuggingFace hook passes."""
+    from bayeformers_amd import ops
+
+    g = torch.Generator().manual_seed(B * 1000 + T + H)
+    q, k, v = (torch.randn(B, T, H * 64, generator=g).cuda().to(dtype).view(B, T, H, 64).transpose(1, 2) for _ in range(3))
+    assert ops.attention_supported(q, k, v)
+    key_mask = None
+    if masked:
+        lens = torch.randint(T // 3, T, (B,), generator=g)
+        lens[0] = T - 1
+        keep = torch.arange(T)[None, :] < lens[:, None]
+        key_mask = torch.zeros(B, T).masked_fill_(~keep, float("-inf")).cuda()
+    out = ops.attention_forward(q, k, v, key_mask, 0.125)
+    assert out.shape == (B, T, H, 64) and out.is_contiguous()
+    am = key_mask[:, None, None, :] if masked else None
+    ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float(), attn_mask=am, scale=0.125)
+    err = (out.float() - ref.transpose(1, 2)).abs().max().item()
+    assert err <= tol, err
+
+
+def test_fused_attention_in_bert_matches_framework_attention():
+    """fuse_attention(): the HuggingFace attention hook — same logits as the framework's attention up to bf16
+    rounding, identical log-probs, with an all-ones mask and with real padding; gradients still flow (fallback)."""
+    from transformers import BertConfig, BertForSequenceClassification
+
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                     vocab_size=1000, max_position_embeddings=128)
+    torch.manual_seed(0)
+    model = BertForSequenceClassification(cfg).eval()
+    torch.manual_seed(3)
+    ids = torch.randint(0, cfg.vocab_size, (4, 128)).cuda()
+    pad = torch.ones(4, 128, dtype=torch.long, device="cuda")
+    pad[1, 100:] = 0
+    pad[3, 64:] = 0
+    outs = []
+    for fuse in (False, True):
+        bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().cuda().to(torch.bfloat16)
+        if fuse:
+            assert bf.fuse_attention(bmodel)
+        res = []
+        for mask in (torch.ones_like(pad), pad):
+            bf.manual_seed(SEED)
+            with torch.no_grad():
+                raw, mean, lp, lq = sample_bayesian(bmodel, {"input_ids": ids, "attention_mask": mask}, 2)
+            res.append((raw[0].float(), float(lp), float(lq)))
+        outs.append(res)
+    for (ya, pa, qa), (yb, pb, qb) in zip(*outs):
+        assert (ya - yb).abs().max().item() < 2e-2
+        assert pa == pb and qa == qb
+    bf.manual_seed(SEED)
+    raw, mean, lp, lq = sample_bayesian(bmodel, {"input_ids": ids, "attention_mask": pad}, 2)
+    mean[0].float().sum().backward()

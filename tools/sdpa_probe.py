@@ -24,3 +24,12 @@ qq=torch.randn(320,128,12,64,device='cuda',dtype=torch.bfloat16).transpose(1,2);
 print("strided BTHD views", t(lambda: F.scaled_dot_product_attention(qq,kk,vv)))
 m=torch.zeros(320,1,1,128,device='cuda',dtype=torch.bfloat16)
 print("with additive mask", t(lambda: F.scaled_dot_product_attention(qq,kk,vv,attn_mask=m)))
+
+import os, sys
+sys.path.insert(0, os.getcwd())
+from bayeformers_amd import ops
+print("bf_attention_fwd (BTHD views)", t(lambda: ops.attention_forward(qq, kk, vv, None, 0.125)))
+mk = torch.zeros(320, 128, device='cuda')
+print("bf_attention_fwd + key mask  ", t(lambda: ops.attention_forward(qq, kk, vv, mk, 0.125)))
+q3=torch.randn(160,384,16,64,device='cuda',dtype=torch.float16).transpose(1,2); k3=torch.randn(160,384,16,64,device='cuda',dtype=torch.float16).transpose(1,2); v3=torch.randn(160,384,16,64,device='cuda',dtype=torch.float16).transpose(1,2)
+print("BERT-large shape sdpa", t(lambda: F.scaled_dot_product_attention(q3,k3,v3)), " bf", t(lambda: ops.attention_forward(q3,k3,v3,None,0.125)))
