@@ -68,9 +68,10 @@ template <typename T>
 __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams p) {
     using frag = typename Mfma<T>::frag;
     using half4 = typename Mfma<T>::half4;
-    __shared__ __attribute__((aligned(16))) char smem[K_BYTES + V_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[K_BYTES + V_BYTES + TKEY * 4];
     char* const ks = smem;
     char* const vs = smem + K_BYTES;
+    float* const ms = reinterpret_cast<float*>(smem + K_BYTES + V_BYTES);  // this tile's key mask, in log2 units
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
@@ -106,6 +107,9 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams 
             const f32x4_t vv = *reinterpret_cast<const f32x4_t*>(vb + (long long)(key0 + row) * p.tok_stride + c8 * 8);
             *reinterpret_cast<f32x4_t*>(vs + row * V_ROW + (c8 << 4)) = vv;
         }
+        if (p.mask && tid < TKEY / 4)
+            *reinterpret_cast<f32x4_t*>(ms + tid * 4) =
+                *reinterpret_cast<const f32x4_t*>(p.mask + (long long)b * p.T + key0 + tid * 4) * 1.4426950408889634f;
         __syncthreads();
 
         // One block of 16 queries at a time (keeps the live scores at 32 registers, 4 waves per SIMD fit).
@@ -123,14 +127,12 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams 
                     s[kbk] = Mfma<T>::run(kf, qf[qi][dh], s[kbk]);
                 }
             }
-            // scale (+ additive key mask: a lane's 4 keys of a block are one 16-byte load), in log2 units
+            // scale (+ additive key mask: a lane's 4 keys of a block are one 16-byte LDS read), in log2 units
             float mx = -INFINITY;
 #pragma unroll
             for (int kbk = 0; kbk < 8; ++kbk) {
                 f32x4_t mk = {0.f, 0.f, 0.f, 0.f};
-                if (p.mask)
-                    mk = *reinterpret_cast<const f32x4_t*>(p.mask + (long long)b * p.T + key0 + kbk * 16 + lg * 4) *
-                         1.4426950408889634f;
+                if (p.mask) mk = *reinterpret_cast<const f32x4_t*>(ms + kbk * 16 + lg * 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     s[kbk][j] = fmaf(s[kbk][j], p.scale_log2e, mk[j]);
