@@ -106,6 +106,19 @@ def _dense_residual_norm_forward(self, hidden_states, input_tensor):
     return ops.add_layernorm(hidden_states, input_tensor, ln.weight, ln.bias, ln.eps)
 
 
+def _layernorm_forward(self, input):
+    """nn.LayerNorm.forward on bf_add_layernorm (no residual) when no gradient is needed and the shape qualifies."""
+    from . import ops
+
+    n = self.normalized_shape[0]
+    plain = (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad)) or not input.is_cuda or \
+        input.dtype not in (torch.bfloat16, torch.float16, torch.float32) or input.shape[-1] != n or \
+        self.weight.dtype not in (torch.float32, input.dtype)
+    if plain:
+        return torch.nn.functional.layer_norm(input, self.normalized_shape, self.weight, self.bias, self.eps)
+    return ops.add_layernorm(input, None, self.weight, self.bias, self.eps)
+
+
 def fuse_residual_layernorm(model: torch.nn.Module) -> int:
     """Fuse `LayerNorm(dropout(dense(h)) + input)` blocks whose dense layer is a bnn.Linear (HF BertSelfOutput,
     BertOutput and their relatives: attributes `dense`, `dropout`, `LayerNorm`, forward(hidden_states,
@@ -119,7 +132,15 @@ def fuse_residual_layernorm(model: torch.nn.Module) -> int:
                 and ln.normalized_shape[0] == dense.out_features and dense.out_features % 8 == 0
                 and dense.out_features <= 8192 and m.__class__.__name__.endswith("Output")):
             m.forward = types.MethodType(_dense_residual_norm_forward, m)
+            ln._bf_fused = True
             fused += 1
+    # the remaining stand-alone LayerNorms (the embedding block's) run on the same kernel without a residual
+    for m in model.modules():
+        if (isinstance(m, torch.nn.LayerNorm) and not getattr(m, "_bf_fused", False) and m.elementwise_affine
+                and m.bias is not None and len(m.normalized_shape) == 1 and m.normalized_shape[0] % 8 == 0
+                and m.normalized_shape[0] <= 8192):
+            m.forward = types.MethodType(_layernorm_forward, m)
+            m._bf_fused = True
     return fused
 
 
