@@ -91,31 +91,29 @@ def fuse_activations(model: torch.nn.Module) -> int:
 
 def _dense_residual_norm_forward(self, hidden_states, input_tensor):
     """forward of an HF `*Output` block — LayerNorm(dropout(dense(h)) + input) — with the residual add and the
-    normalisation done by one HBM pass (bf_add_layernorm) behind the Bayesian dense layer's GEMM.  Whenever a
-    gradient may be needed or dropout is active, the framework ops run instead, so autograd stays intact."""
+    normalisation done by one HBM pass (bf_add_layernorm) behind the Bayesian dense layer's GEMM; with gradients
+    enabled the same kernel runs inside an autograd function whose backward is bf_add_layernorm_bwd."""
     from . import ops
 
     hidden_states = self.dense(hidden_states)
     ln = self.LayerNorm
-    plain = (torch.is_grad_enabled() and (hidden_states.requires_grad or input_tensor.requires_grad or
-                                          ln.weight.requires_grad)) or \
-        (self.training and self.dropout.p > 0) or not hidden_states.is_cuda or \
-        hidden_states.dtype != input_tensor.dtype or hidden_states.shape != input_tensor.shape
-    if plain:
-        return ln(self.dropout(hidden_states) + input_tensor)
+    if self.training and self.dropout.p > 0:
+        hidden_states = self.dropout(hidden_states)
+    if not ops.layernorm_supported(hidden_states, input_tensor, ln):
+        return ln(hidden_states + input_tensor)
+    if torch.is_grad_enabled() and (hidden_states.requires_grad or input_tensor.requires_grad or ln.weight.requires_grad):
+        return ops.AddLayerNormFn.apply(hidden_states, input_tensor, ln.weight, ln.bias, ln.eps)
     return ops.add_layernorm(hidden_states, input_tensor, ln.weight, ln.bias, ln.eps)
 
 
 def _layernorm_forward(self, input):
-    """nn.LayerNorm.forward on bf_add_layernorm (no residual) when no gradient is needed and the shape qualifies."""
+    """nn.LayerNorm.forward on bf_add_layernorm (no residual), differentiable through bf_add_layernorm_bwd."""
     from . import ops
 
-    n = self.normalized_shape[0]
-    plain = (torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad)) or not input.is_cuda or \
-        input.dtype not in (torch.bfloat16, torch.float16, torch.float32) or input.shape[-1] != n or \
-        self.weight.dtype not in (torch.float32, input.dtype)
-    if plain:
+    if input.shape[-1] != self.normalized_shape[0] or not ops.layernorm_supported(input, None, self):
         return torch.nn.functional.layer_norm(input, self.normalized_shape, self.weight, self.bias, self.eps)
+    if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad):
+        return ops.AddLayerNormFn.apply(input, None, self.weight, self.bias, self.eps)
     return ops.add_layernorm(input, None, self.weight, self.bias, self.eps)
 
 
@@ -130,7 +128,7 @@ def fuse_residual_layernorm(model: torch.nn.Module) -> int:
         if (isinstance(dense, nn.Linear) and isinstance(ln, torch.nn.LayerNorm) and isinstance(drop, torch.nn.Dropout)
                 and ln.elementwise_affine and ln.bias is not None and len(ln.normalized_shape) == 1
                 and ln.normalized_shape[0] == dense.out_features and dense.out_features % 8 == 0
-                and dense.out_features <= 8192 and m.__class__.__name__.endswith("Output")):
+                and dense.out_features <= 4096 and m.__class__.__name__.endswith("Output")):
             m.forward = types.MethodType(_dense_residual_norm_forward, m)
             ln._bf_fused = True
             fused += 1
@@ -138,7 +136,7 @@ def fuse_residual_layernorm(model: torch.nn.Module) -> int:
     for m in model.modules():
         if (isinstance(m, torch.nn.LayerNorm) and not getattr(m, "_bf_fused", False) and m.elementwise_affine
                 and m.bias is not None and len(m.normalized_shape) == 1 and m.normalized_shape[0] % 8 == 0
-                and m.normalized_shape[0] <= 8192):
+                and m.normalized_shape[0] <= 4096):
             m.forward = types.MethodType(_layernorm_forward, m)
             m._bf_fused = True
     return fused

@@ -330,6 +330,15 @@ int bf_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const fl
                                    (hipStream_t)stream);
 }
 
+size_t bf_add_layernorm_bwd_workspace_bytes(int64_t rows, int N) { return bf_add_layernorm_bwd_ws_bytes(rows, N); }
+
+int bf_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,
+                         void* d_dz, float* d_dgamma, float* d_dbeta, void* d_workspace, size_t workspace_bytes, int dtype,
+                         int64_t rows, int N, float eps, void* stream) {
+    return bf_launch_add_layernorm_bwd(d_x, d_residual, d_gamma, param_dtype, d_dy, d_dz, d_dgamma, d_dbeta, d_workspace,
+                                       workspace_bytes, dtype, rows, N, eps, (hipStream_t)stream);
+}
+
 // workspace layout of bf_linear_bwd
 struct BwdLayout {
     size_t w, wt, dyt, xt, dw, db, dbp, lp, part, total;

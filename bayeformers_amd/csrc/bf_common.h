@@ -103,3 +103,7 @@ int bf_launch_add_layernorm(const void* d_x, const void* d_residual, const void*
 int bf_launch_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, void* d_out, int dtype,
                             int B, int T, int H, int head_dim, long long token_stride, float scaling,
                             hipStream_t stream);
+size_t bf_add_layernorm_bwd_ws_bytes(long long rows, int N);
+int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
+                                const void* d_dy, void* d_dz, float* d_dgamma, float* d_dbeta, void* d_workspace,
+                                size_t workspace_bytes, int dtype, long long rows, int N, float eps, hipStream_t stream);

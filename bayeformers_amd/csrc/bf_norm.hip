@@ -120,6 +120,139 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_kernel(
     }
 }
 
+// Backward of out = LayerNorm(x + residual) * gamma + beta.  z = x + residual and its row statistics are recomputed
+// (nothing but the forward's inputs is kept), then with zh = (z - mean) * rstd and a = dy * gamma:
+//     dz = rstd * (a - mean_row(a) - zh * mean_row(a * zh))      (= dx = dresidual)
+//     dgamma = sum_rows dy * zh,   dbeta = sum_rows dy
+// One wave per row, a workgroup walks rows blockIdx, blockIdx + gridDim, ...; every lane keeps the dgamma / dbeta
+// partial sums of its own columns in registers, the 4 waves of a workgroup are combined through LDS and leave one
+// [2][N] fp32 row per workgroup, reduced in a fixed order by layernorm_param_grad_kernel (deterministic).
+template <typename T, typename GT, int VPL>
+__global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_bwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ res, const GT* __restrict__ gamma, const T* __restrict__ dy,
+    T* __restrict__ dz, float* __restrict__ partial, long long rows, int N, float eps) {
+    extern __shared__ float sh[];  // [kRowsPerBlock][2][N]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nvec = N >> 3;
+    float gm[VPL][8], dgam[VPL][8], dbet[VPL][8];
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) {
+        const int vi = lane + 64 * c;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gm[c][i] = dgam[c][i] = dbet[c][i] = 0.f;
+        if (vi < nvec) load8(gamma + vi * 8, gm[c]);
+    }
+    const float inv_n = 1.0f / (float)N;
+    for (long long row = (long long)blockIdx.x * kRowsPerBlock + wave; row < rows; row += (long long)gridDim.x * kRowsPerBlock) {
+        float v[VPL][8], g[VPL][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < VPL; ++c) {
+            const int vi = lane + 64 * c;
+            if (vi < nvec) {
+                load8(x + row * N + vi * 8, v[c]);
+                if (res) {
+                    float r[8];
+                    load8(res + row * N + vi * 8, r);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[c][i] += r[i];
+                }
+                load8(dy + row * N + vi * 8, g[c]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sum += v[c][i];
+            }
+        }
+        const float mean = wave_sum(sum) * inv_n;
+        float sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < VPL; ++c)
+            if (lane + 64 * c < nvec)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[c][i] -= mean;
+                    sq = fmaf(v[c][i], v[c][i], sq);
+                }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_n + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < VPL; ++c)
+            if (lane + 64 * c < nvec)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    v[c][i] *= rstd;  // zh
+                    dbet[c][i] += g[c][i];
+                    dgam[c][i] = fmaf(g[c][i], v[c][i], dgam[c][i]);
+                    g[c][i] *= gm[c][i];  // a
+                    s1 += g[c][i];
+                    s2 = fmaf(g[c][i], v[c][i], s2);
+                }
+        s1 = wave_sum(s1) * inv_n;
+        s2 = wave_sum(s2) * inv_n;
+#pragma unroll
+        for (int c = 0; c < VPL; ++c) {
+            const int vi = lane + 64 * c;
+            if (vi < nvec) {
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = rstd * (g[c][i] - s1 - v[c][i] * s2);
+                store8(dz + row * N + vi * 8, o);
+            }
+        }
+    }
+    // combine the workgroup's 4 waves
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) {
+        const int vi = lane + 64 * c;
+        if (vi < nvec)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                sh[(wave * 2 + 0) * N + vi * 8 + i] = dgam[c][i];
+                sh[(wave * 2 + 1) * N + vi * 8 + i] = dbet[c][i];
+            }
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < 2 * N; n += blockDim.x) {
+        const int which = n / N, col = n - which * N;
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < kRowsPerBlock; ++w) acc += sh[(w * 2 + which) * N + col];
+        partial[((long long)blockIdx.x * 2 + which) * N + col] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_param_grad_kernel(const float* __restrict__ partial, int nblocks, int N,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float sh[4][64];
+    const int which = blockIdx.y, n = blockIdx.x * 64 + (threadIdx.x & 63), cl = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (n < N)
+        for (int b = cl; b < nblocks; b += 4) acc += partial[((long long)b * 2 + which) * N + n];
+    sh[cl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (cl == 0 && n < N)
+        (which ? dbeta : dgamma)[n] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+constexpr int kBwdBlocks = 1024;
+
+template <typename T, typename GT>
+int launch_bwd_vpl(const void* x, const void* res, const void* gamma, const void* dy, void* dz, float* partial,
+                   int nblocks, long long rows, int N, float eps, hipStream_t stream) {
+    const int nvec = N >> 3;
+    const size_t lds = (size_t)kRowsPerBlock * 2 * N * sizeof(float);
+    const dim3 grid((unsigned)nblocks), block(64 * kRowsPerBlock);
+#define BF_LNB_LAUNCH(VPL)                                                                                            \
+    hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, GT, VPL>), grid, block, lds, stream, (const T*)x, (const T*)res,   \
+                       (const GT*)gamma, (const T*)dy, (T*)dz, partial, rows, N, eps)
+    if (nvec <= 64) BF_LNB_LAUNCH(1);
+    else if (nvec <= 128) BF_LNB_LAUNCH(2);
+    else if (nvec <= 256) BF_LNB_LAUNCH(4);
+    else BF_LNB_LAUNCH(8);
+#undef BF_LNB_LAUNCH
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 template <typename T, typename GT>
 int launch_vpl(const void* x, const void* res, const void* gamma, const void* beta, void* out, long long rows, int N,
                float eps, hipStream_t stream) {
@@ -164,4 +297,51 @@ int bf_launch_add_layernorm(const void* d_x, const void* d_residual, const void*
         case BF_DT_F32: return launch_gt<float>(d_x, d_residual, d_gamma, d_beta, param_dtype, dtype, d_out, rows, N, eps, stream);
     }
     BF_FAIL("bf_add_layernorm: unknown dtype %d", dtype);
+}
+
+static int bwd_blocks(long long rows) {
+    const long long need = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
+    return (int)(need < kBwdBlocks ? (need < 1 ? 1 : need) : kBwdBlocks);
+}
+
+size_t bf_add_layernorm_bwd_ws_bytes(long long rows, int N) {
+    if (rows < 1 || N < 1) return 0;
+    return (size_t)bwd_blocks(rows) * 2 * N * sizeof(float);
+}
+
+int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
+                                const void* d_dy, void* d_dz, float* d_dgamma, float* d_dbeta, void* d_workspace,
+                                size_t workspace_bytes, int dtype, long long rows, int N, float eps, hipStream_t stream) {
+    if (rows < 0 || N <= 0) BF_FAIL("bf_add_layernorm_bwd: bad shape rows=%lld N=%d", rows, N);
+    if (N % 8 || N > 4096) BF_FAIL("bf_add_layernorm_bwd: N=%d must be a multiple of 8 and at most 4096", N);
+    if (!d_dgamma || !d_dbeta) BF_FAIL("bf_add_layernorm_bwd: null parameter gradient");
+    if (rows == 0) {
+        BF_HIP_CHECK(hipMemsetAsync(d_dgamma, 0, (size_t)N * sizeof(float), stream));
+        BF_HIP_CHECK(hipMemsetAsync(d_dbeta, 0, (size_t)N * sizeof(float), stream));
+        return 0;
+    }
+    if (!d_x || !d_gamma || !d_dy || !d_dz) BF_FAIL("bf_add_layernorm_bwd: null pointer");
+    const uintptr_t al = (uintptr_t)d_x | (uintptr_t)d_residual | (uintptr_t)d_gamma | (uintptr_t)d_dy | (uintptr_t)d_dz;
+    if (al & 15) BF_FAIL("bf_add_layernorm_bwd: pointers must be 16-byte aligned");
+    const size_t need = bf_add_layernorm_bwd_ws_bytes(rows, N);
+    if (!d_workspace || workspace_bytes < need) BF_FAIL("bf_add_layernorm_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+    const int nb = bwd_blocks(rows);
+    float* partial = reinterpret_cast<float*>(d_workspace);
+    int rc = 1;
+#define BF_LNB_DISPATCH(T)                                                                                              \
+    rc = param_dtype == BF_DT_F32 ? launch_bwd_vpl<T, float>(d_x, d_residual, d_gamma, d_dy, d_dz, partial, nb, rows, N, eps, stream) \
+         : param_dtype == dtype   ? launch_bwd_vpl<T, T>(d_x, d_residual, d_gamma, d_dy, d_dz, partial, nb, rows, N, eps, stream)     \
+                                  : (bf_set_error("bf_add_layernorm_bwd: gamma must be fp32 or have the activation dtype"), 1)
+    switch (dtype) {
+        case BF_DT_BF16: BF_LNB_DISPATCH(__bf16); break;
+        case BF_DT_F16: BF_LNB_DISPATCH(_Float16); break;
+        case BF_DT_F32: BF_LNB_DISPATCH(float); break;
+        default: BF_FAIL("bf_add_layernorm_bwd: unknown dtype %d", dtype);
+    }
+#undef BF_LNB_DISPATCH
+    if (rc) return rc;
+    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((N + 63) / 64, 2), dim3(256), 0, stream, partial, nb, N, d_dgamma,
+                       d_dbeta);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
 }

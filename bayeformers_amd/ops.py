@@ -351,3 +351,53 @@ def attention_forward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tensor
                                        _TORCH2BF[q.dtype], B, T, H, D, H * D, float(scaling), _stream_ptr()),
              "bf_attention_fwd")
     return out
+
+
+def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor, grad_out: Tensor, eps: float):
+    """Gradients of add_layernorm (bf_add_layernorm_bwd): returns (dz, dgamma, dbeta); dz is the gradient of both x
+    and residual, dgamma / dbeta are fp32."""
+    N = x.shape[-1]
+    x2 = x.reshape(-1, N)
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, N)
+        r2 = r2 if r2.is_contiguous() else r2.contiguous()
+    g2 = grad_out.reshape(-1, N)
+    g2 = (g2 if g2.dtype == x.dtype else g2.to(x.dtype)).contiguous()
+    dz = torch.empty_like(x2)
+    dgamma = torch.empty(N, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(N, dtype=torch.float32, device=x.device)
+    lib = _C.lib()
+    need = lib.bf_add_layernorm_bwd_workspace_bytes(x2.shape[0], N)
+    ws = workspace(x.device, need)
+    _C.check(lib.bf_add_layernorm_bwd(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
+                                      _TORCH2BF[gamma.dtype], g2.data_ptr(), dz.data_ptr(), dgamma.data_ptr(),
+                                      dbeta.data_ptr(), ws.data_ptr(), ws.numel(), _TORCH2BF[x.dtype], x2.shape[0], N,
+                                      float(eps), _stream_ptr()), "bf_add_layernorm_bwd")
+    return dz.view(x.shape), dgamma, dbeta
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """LayerNorm(x + residual) * gamma + beta with both directions in the HIP kernels; nothing but the inputs is saved."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, eps):
+        ctx.eps, ctx.has_res = eps, residual is not None
+        ctx.save_for_backward(x, residual if residual is not None else x, gamma)
+        return add_layernorm(x, residual, gamma, beta, eps)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, residual, gamma = ctx.saved_tensors
+        dz, dgamma, dbeta = add_layernorm_backward(x, residual if ctx.has_res else None, gamma, grad_out, ctx.eps)
+        need = ctx.needs_input_grad
+        return (dz if need[0] else None, dz if (ctx.has_res and need[1]) else None,
+                dgamma.to(gamma.dtype) if need[2] else None, dbeta.to(gamma.dtype) if need[3] else None, None)
+
+
+def layernorm_supported(x: Tensor, residual: Optional[Tensor], ln) -> bool:
+    n = x.shape[-1]
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16, torch.float32) and n % 8 == 0 and n <= 4096 and
+            (residual is None or (residual.shape == x.shape and residual.dtype == x.dtype)) and
+            ln.weight.dtype in (torch.float32, x.dtype) and ln.bias is not None and ln.bias.dtype == ln.weight.dtype)

@@ -191,6 +191,14 @@ int bf_embedding_bwd(const int64_t* d_ids, const void* d_grad, int grad_dtype, c
 int bf_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, int param_dtype,
                      void* d_out, int dtype, int64_t rows, int N, float eps, void* stream);
 
+/* Backward of bf_add_layernorm.  z = x + residual and its row statistics are recomputed from the forward's inputs;
+ * d_dz [rows, N] of `dtype` is the gradient of BOTH x and residual; d_dgamma / d_dbeta are fp32 [N], written (not
+ * accumulated) in a fixed summation order.  N % 8 == 0, N <= 4096. */
+size_t bf_add_layernorm_bwd_workspace_bytes(int64_t rows, int N);
+int bf_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,
+                         void* d_dz, float* d_dgamma, float* d_dbeta, void* d_workspace, size_t workspace_bytes, int dtype,
+                         int64_t rows, int N, float eps, void* stream);
+
 /* out[b][t][h][:] = softmax_keys(q[b][t][h] . k[b][:][h] * scaling + mask[b][:]) v[b][:][h] — the attention that sits
  * between the Bayesian query/key/value projections and the Bayesian output projection of the transformers the
  * reference converts (HF BertSelfAttention around bnn.Linear.forward, bayeformers/nn/layers/linear.py:83-104; the

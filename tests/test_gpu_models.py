@@ -430,3 +430,29 @@ def test_fused_attention_in_bert_matches_framework_attention():
     bf.manual_seed(SEED)
     raw, mean, lp, lq = sample_bayesian(bmodel, {"input_ids": ids, "attention_mask": pad}, 2)
     mean[0].float().sum().backward()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("rows,N", [(37, 768), (4100, 1024), (5, 8), (3, 4096)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_add_layernorm_backward_matches_autograd(dtype, tol, rows, N, with_res):
+    """bf_add_layernorm_bwd (through the autograd function) against torch autograd of the fp32 ops it replaces."""
+    from bayeformers_amd import ops
+
+    g = torch.Generator().manual_seed(rows + N)
+    x = torch.randn(rows, N, generator=g).to(dtype).cuda().requires_grad_(True)
+    r = torch.randn(rows, N, generator=g).to(dtype).cuda().requires_grad_(True) if with_res else None
+    gamma = (1 + 0.1 * torch.randn(N, generator=g)).cuda().requires_grad_(True)
+    beta = (0.1 * torch.randn(N, generator=g)).cuda().requires_grad_(True)
+    gy = torch.randn(rows, N, generator=g).to(dtype).cuda()
+    out = ops.AddLayerNormFn.apply(x, r, gamma, beta, 1e-12)
+    out.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    rr = r.detach().float().requires_grad_(True) if with_res else None
+    gr, br = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr + rr if with_res else xr, (N,), gr, br, 1e-12)
+    ref.backward(gy.float())
+    pairs = [(x.grad, xr.grad), (gamma.grad, gr.grad), (beta.grad, br.grad)] + ([(r.grad, rr.grad)] if with_res else [])
+    for got, want in pairs:
+        scale = want.abs().max().item() + 1e-30
+        assert (got.float() - want).abs().max().item() <= tol * scale
