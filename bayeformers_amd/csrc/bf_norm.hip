@@ -220,20 +220,25 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_bwd_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void layernorm_param_grad_kernel(const float* __restrict__ partial, int nblocks, int N,
-                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float sh[4][64];
+__global__ __launch_bounds__(1024) void layernorm_param_grad_kernel(const float* __restrict__ partial, int nblocks, int N,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    // block = 64 columns x 16 lanes over the workgroup axis; fixed order -> deterministic
+    __shared__ float sh[16][64];
     const int which = blockIdx.y, n = blockIdx.x * 64 + (threadIdx.x & 63), cl = threadIdx.x >> 6;
     float acc = 0.f;
     if (n < N)
-        for (int b = cl; b < nblocks; b += 4) acc += partial[((long long)b * 2 + which) * N + n];
+        for (int b = cl; b < nblocks; b += 16) acc += partial[((long long)b * 2 + which) * N + n];
     sh[cl][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (cl == 0 && n < N)
-        (which ? dbeta : dgamma)[n] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (cl == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sh[i][threadIdx.x];
+        (which ? dbeta : dgamma)[n] = t;
+    }
 }
 
-constexpr int kBwdBlocks = 1024;
+constexpr int kBwdBlocks = 512;  // 2 workgroups per CU; each leaves one [2][N] partial row
 
 template <typename T, typename GT>
 int launch_bwd_vpl(const void* x, const void* res, const void* gamma, const void* dy, void* dz, float* partial,
@@ -340,7 +345,7 @@ int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const v
     }
 #undef BF_LNB_DISPATCH
     if (rc) return rc;
-    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((N + 63) / 64, 2), dim3(256), 0, stream, partial, nb, N, d_dgamma,
+    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((N + 63) / 64, 2), dim3(1024), 0, stream, partial, nb, N, d_dgamma,
                        d_dbeta);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
