@@ -1,0 +1,74 @@
+// Probe for the next GEMM design: ONE wave per SIMD, 128x128 output per wave (256 fp32 accumulators per lane, the
+// unified VGPR/AGPR file), fragments read from LDS, no global traffic in the loop.  What MFMA rate does the HIP
+// compiler's schedule of (16 ds_read_b128 + 64 v_mfma_f32_16x16x32_bf16) per 32-deep k-half sustain?
+// Compare with the current kernel's DMA-free ablation (8 waves, 128x64 per wave): 1800-1900 TFLOP/s.
+//   hipcc -O3 --offload-arch=gfx950 tools/wave128_probe.cpp -o tools/wave128_probe && ./tools/wave128_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int ROW = 128;  // bytes per LDS row (64 bf16)
+
+template <int DOUBLE_BUFFER>
+__global__ __launch_bounds__(256) void probe(float* out, int ksteps) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 256 * ROW];  // A rows 0..255 | B rows 0..255 (64 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < 2 * 256 * ROW / 4; i += 256) reinterpret_cast<float*>(smem)[i] = 0.001f * (i & 127);
+    __syncthreads();
+    const int wm = wid >> 1, wn = wid & 1;  // 2 x 2 waves, 128 x 128 each
+    const int fsw = (lane >> 1) & 7;
+    const char* abase = smem + (wm * 128 + (lane & 15)) * ROW;
+    const char* bbase = smem + 256 * ROW + (wn * 128 + (lane & 15)) * ROW;
+    f32x4_t acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < ksteps; ++kt) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int off = (((h * 4 + (lane >> 4)) ^ fsw) << 4);
+            bf16x8_t af[8], bfr[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(abase + i * 16 * ROW + off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bfr[j] = *reinterpret_cast<const bf16x8_t*>(bbase + j * 16 * ROW + off);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (DOUBLE_BUFFER) __builtin_amdgcn_s_barrier();  // stands in for the stage swap of a real kernel
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+int main() {
+    float* out;
+    hipMalloc(&out, 256 * 256 * sizeof(float));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int ksteps = 2048;
+    for (int variant = 0; variant < 2; ++variant) {
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0);
+            if (variant) hipLaunchKernelGGL(probe<1>, dim3(256), dim3(256), 0, 0, out, ksteps);
+            else hipLaunchKernelGGL(probe<0>, dim3(256), dim3(256), 0, 0, out, ksteps);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+        }
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flops = 256.0 * 2.0 * 256 * 256 * 64 * ksteps;
+        printf("4 waves x 128x128, LDS fragment reads + MFMA only%s: %.0f TFLOP/s (%.1f %% of 2500)\n",
+               variant ? ", one barrier per k-step" : "", flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 2.5e15 * 100);
+    }
+    return 0;
+}
