@@ -42,7 +42,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+# Developer build (tools/ micro-benchmarks only): -DBF_DEV keeps the ablation / A-B environment switches
+# (BF_GEMM_VARIANT, BF_GEMM_ABLATE, BF_GEMM_SCHED, BF_ATTN_ABLATE) and the round-1 GEMM kernel that the product
+# library compiles out.  Select it with BF_LIB_PATH=bayeformers_amd/lib/libbayeformers_amd_dev.so.
+DEV_LIB = os.path.join(LIBDIR, "libbayeformers_amd_dev.so")
+DEV_SOURCES = ["bf_gemm256_r1.hip"]
+
+
+def build(force=False, verbose=True, dev=False):
     """Compile every HIP source for gfx950 and link the shared library.  Returns the library path."""
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
@@ -50,12 +57,13 @@ def build(force=False, verbose=True):
     headers = _headers()
     objs = []
     procs = []
-    for src in SOURCES:
+    lib = DEV_LIB if dev else LIB
+    for src in SOURCES + (DEV_SOURCES if dev else []):
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(OBJ, src.replace(".hip", ".dev.o" if dev else ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + (["-DBF_DEV"] if dev else []) + ["-c", s, "-o", o]
             if verbose:
                 print("[bayeformers_amd.build]", " ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -69,13 +77,13 @@ def build(force=False, verbose=True):
             failed = True
     if failed:
         raise RuntimeError("hipcc failed")
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib] + objs
         if verbose:
             print("[bayeformers_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, dev="--dev" in sys.argv))

@@ -19,10 +19,14 @@
 
 namespace {
 
-// developer knob: BF_GEMM_VARIANT=0 forces the generic kernel (read on every call; a getenv is ~50 ns)
+// Kernel choice: 2 = the scheduled 256-wide persistent kernel (bf_gemm256.hip).  Developer builds (-DBF_DEV, tools/)
+// can override it with BF_GEMM_VARIANT: 0 = force the generic kernel, 1 = the round-1 fixed-tile kernel (A/B baseline).
 int gemm_variant() {
+#ifdef BF_DEV
     const char* v = getenv("BF_GEMM_VARIANT");
-    return v ? atoi(v) : 1;  // 0 = force the generic kernel, anything else = the 256x256x64 persistent ping-pong kernel
+    if (v) return atoi(v);
+#endif
+    return 2;
 }
 
 template <typename T>
@@ -324,8 +328,12 @@ int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, con
     // large aligned problems: the 256x256x64 LDS-DMA kernel; everything else: the generic 128x128x32 kernel
     const int variant = gemm_variant();
     if (variant != 0 && (long long)M * N >= 128 * 128 && ((uintptr_t)d_bias & 15) == 0 &&
-        bf_gemm256_supported(x_dtype, w_dtype, y_dtype, layers * S, M, N, K, d_x, d_w, x_sample_stride))
+        bf_gemm256_supported(x_dtype, w_dtype, y_dtype, layers * S, M, N, K, d_x, d_w, x_sample_stride)) {
+#ifdef BF_DEV
+        if (variant == 1) return bf_launch_gemm256_r1(p, w_dtype, y_dtype, stream);
+#endif
         return bf_launch_gemm256(p, w_dtype, y_dtype, stream);
+    }
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
     const size_t xs = bf_dtype_size(x_dtype);

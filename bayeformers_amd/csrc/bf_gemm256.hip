@@ -2,8 +2,9 @@
 // (F.linear at /root/reference/bayeformers/nn/layers/linear.py:104, all S samples in one launch).
 //
 // Shape of the kernel (MI355X: 256 CUs, 160 KiB LDS/CU, wave64, v_mfma_f32_16x16x32_{bf16,f16}):
-//   * one 256(m) x 256(n) output tile per 512-thread workgroup (8 waves = 2(m) x 4(n), 128 x 64 per wave,
-//     128 fp32 accumulator registers per lane), K walked in steps of 64;
+//   * one (32 h)(m) x 256(n) output tile per 512-thread workgroup, h = 4..8 (128..256 rows), 8 waves = 2(m) x 4(n);
+//     the two wave groups take the 16-row blocks of the tile alternately (group g owns blocks g, g+2, ...), so a wave
+//     holds 16 h x 64 outputs = 16 h fp32 accumulator registers per lane; K walked in steps of 64;
 //   * both operands are K-contiguous ([M][K] activations, [N][K] sampled weights) and are DMA'd straight into LDS
 //     with global_load_lds_dwordx4 (no VGPR round trip), double-buffered: 2 x (256+256) rows x 128 B = 128 KiB;
 //   * LDS rows are 128 B; the 16-byte chunk c of row r is stored at chunk position c ^ ((r >> 1) & 7).  The DMA
@@ -11,18 +12,36 @@
 //     fragment read, which makes every ds_read_b128 of an MFMA fragment bank-conflict-free;
 //   * the MFMA runs with swapped operands (D rows = n, cols = m) so each lane owns 4 consecutive output features
 //     of one row of y and the epilogue stores 8 B (bf16/fp16) or 16 B (fp32) per lane;
-//   * blockIdx -> tile mapping is XCD-aware: each of the 8 XCDs (private 4 MiB L2) gets a contiguous run of tiles
-//     in (sample, n-tile, m-tile) order, so the W_s n-panel and the x m-panels it re-reads stay in its own L2.
+//   * WHICH tiles a workgroup runs is decided on the host (build_schedule below): the output is cut into columns
+//     (sample, layer, n-tile) of ceil(M/32) units of 32 rows, every column into tiles of near-equal height, and the
+//     tiles are dealt to the 256 persistent workgroups so that all of them carry the same number of units.  With
+//     fixed 256-row tiles BERT-base's launches have 480 k tiles = 1.875 k rounds of 256 CUs — 1/16 of the CU-time is
+//     a partial last round; with heights {8, 7} every CU gets exactly 15 k units.  Tiles of one round form a
+//     contiguous run per XCD in (sample, m-band, column) order, so the W_s n-panel and the x m-panels an XCD's 32
+//     CUs re-read stay in its private 4 MiB L2.
 // Requirements: K % 64 == 0, 16-byte aligned operands; M and N are arbitrary (edge rows are clamped on load and
 // masked on store).  Everything else goes to the generic kernel in bf_gemm.hip.
 #include <stdlib.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <type_traits>
+#include <vector>
 
 #include "bf_common.h"
 #include "bf_gemm_params.h"
 
 namespace {
 
-constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int TN = 256, TK = 64;
+constexpr int UNIT = 32;                          // rows per schedule unit (one 16-row block per wave group)
+constexpr int HMAX = 8;                           // tallest tile: 256 rows = 128 fp32 accumulators per lane (9 and 10
+                                                  // were measured: they spill and run 6-8 % slower per flop)
+constexpr int HMIN = 4;                           // shortest tile the k-loop is instantiated for
+constexpr int TM = HMAX * UNIT;                   // rows of x a stage holds
+constexpr int XPIECES = TM / 64;                  // 1 KiB DMA pieces per wave for the x rows of a stage: 4
 constexpr int ROW_BYTES = TK * 2;                 // 128
 constexpr int X_BYTES = TM * ROW_BYTES;           // 32 KiB
 constexpr int STAGE_BYTES = (TM + TN) * ROW_BYTES;  // 64 KiB
@@ -52,10 +71,10 @@ __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-
 // acc[nb][mb][j] starts at bias[n] (n = the lane's 4 consecutive features of fragment nb): the bias add costs no
 // epilogue work and its loads overlap the first DMA wait of the tile.
-__device__ __forceinline__ void init_acc(f32x4_t (&acc)[4][8], const float* bias, int n0, int N, int wn, int lane) {
+template <int H>
+__device__ __forceinline__ void init_acc(f32x4_t (&acc)[4][H], const float* bias, int n0, int N, int wn, int lane) {
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         f32x4_t b = {0.f, 0.f, 0.f, 0.f};
@@ -70,111 +89,64 @@ __device__ __forceinline__ void init_acc(f32x4_t (&acc)[4][8], const float* bias
             }
         }
 #pragma unroll
-        for (int mb = 0; mb < 8; ++mb) acc[nb][mb] = b;
+        for (int mb = 0; mb < H; ++mb) acc[nb][mb] = b;
     }
 }
 
-// XCD-aware bijective remap of the flat block id (block b runs on XCD b % 8, observed; speed only).
-__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nwg) {
-    const unsigned xcd = b & 7u, q = nwg >> 3, r = nwg & 7u;
-    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (b >> 3);
-}
-
-
-// logical tile index -> (sample, tm, tn).  Inside a sample tiles are ordered (group of 4 m-tiles, tn, tm in group):
-// any 32 consecutive logical tiles (one XCD's concurrent set) span about 4-11 m-panels x 3-8 n-panels, which keeps
-// the panels every CU of the XCD re-reads in that XCD's private L2.
-__device__ __forceinline__ void tile_coords(unsigned lt, int tiles_m, int tiles_n, int& s, int& tm, int& tn) {
-    const unsigned per_s = (unsigned)(tiles_m * tiles_n);
-    s = lt / per_s;
-    const unsigned r = lt - s * per_s;
-    const unsigned grp = r / (4u * tiles_n);
-    const unsigned in = r - grp * 4u * tiles_n;
-    const unsigned gm = min(4u, (unsigned)tiles_m - grp * 4u);
-    tn = in / gm;
-    tm = grp * 4 + (in - tn * gm);
-}
-
-// Epilogue: accumulators -> LDS as row-major rows of YT (in passes, see epilogue_passes) -> whole-row 16-byte global
-// stores.  A lane's fragment registers are 4 consecutive n of one m (8 B for 16-bit outputs): written with
-// ds_write_b64 into rows padded by 16 B (2-way bank aliasing only), then every wave streams rows back with
-// ds_read_b128 and stores them with dwordx4 (512 contiguous bytes per row for bf16).
-constexpr int EPI_PAD = 16;
+// Epilogue: accumulators -> LDS as row-major rows of YT -> whole-row 16-byte global stores, as a software pipeline over
+// passes of 64 rows (32 for fp32 outputs) through TWO 32 KiB regions of the just-consumed stage buffer:
+//     pass p:  activation + convert + ds_write of the wave's blocks into region p & 1
+//              -> wait -> global stores of pass p-1's rows (already in registers)
+//              -> ONE workgroup barrier -> ds_read of this pass's rows (in flight during pass p+1's VALU work).
+// A lane's fragment registers are 4 consecutive n of one m (8 B for 16-bit outputs); rows are stored unpadded
+// (512 B / 1 KiB) with the 16-byte chunk index XORed by a function of the row (2-way bank aliasing at most on the
+// writes, none on the reads), and every wave streams whole rows back with ds_read_b128 and stores them with dwordx4
+// (512 contiguous bytes per row for bf16).  Pass p holds the tile's 16-row blocks [p BPP, (p+1) BPP): block b belongs
+// to wave group b & 1 as its fragment row-block b >> 1, so both groups write in every pass.
+// Wave group 0 finishes its k-loop one slot before group 1: it runs the VALU / LDS-write half of pass 0 in that slot
+// and only then joins the workgroup (`rejoin`), the barrier that pairs with group 1's last k-step barrier.
 #ifndef BF_NT_STORES
 #define BF_NT_STORES 1
 #endif
 constexpr bool NT_STORES = BF_NT_STORES;
-// ------------------------------------------------------------------------------------------------------------
-// The kernel: persistent ping-pong.
-// The two waves that share a SIMD belong to different wave groups (G0 = waves 0-3 = rows 0..127 of the tile,
-// G1 = waves 4-7 = rows 128..255) and run the same slot sequence one slot apart:
-//
-//      slot:   4t        4t+1      4t+2      4t+3      4t+4
-//      G0:     L0(t)     M0(t)     L1(t)     M1(t)     L0(t+1) ...
-//      G1:     M1(t-1)   L0(t)     M0(t)     L1(t)     M1(t)   ...
-//
-// L = 12 ds_read_b128 (the fragments of one 32-deep half of the k-tile) + lgkmcnt(0); M = 32 MFMAs on registers.
-// Every slot ends in one workgroup barrier, so a SIMD always has one wave on the matrix pipe while its partner is
-// on the LDS pipe.  The LDS DMA of k-step t+1 is issued by each wave at the start of its own L0(t) and is only
-// waited for at the last barrier before slot 4(t+1), i.e. it has 3-4 slots (>= 1500 cycles) to land.
-// One workgroup per CU walks tiles b, b+grid, b+2*grid, ... (same XCD every time, so the L2-aware tile order is
-// preserved), and:
-//   * the LDS DMA issued in the LAST k-step of a tile fetches k-step 0 of the workgroup's NEXT tile into the buffer
-//     that would otherwise idle, and is retired by the k-loop's existing waits — the next tile starts without a
-//     cold-start load;
-//   * the epilogue stages the accumulators through the just-consumed buffer in passes of 64 rows (32 for fp32
-//     outputs), so the prefetched stage in the other buffer survives it; its global stores are not waited for
-//     until the next tile's first k-step retires them together with that step's DMA.
-template <typename YT>
-__device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&acc)[4][8], const float* bias, YT* y,
-                                                int m0, int n0, int M, int N, int wm, int wn, int wid, int lane,
-                                                int act) {
-    constexpr int ROW = TN * (int)sizeof(YT) + EPI_PAD;
+
+template <typename YT, int H>
+__device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&acc)[4][H], YT* y, int m0, int m_end,
+                                                int n0, int N, int wm, int wn, int wid, int lane, int act,
+                                                bool skip) {
+    constexpr int ROWB = TN * (int)sizeof(YT);          // 512 or 1024
     constexpr int PASS_ROWS = sizeof(YT) == 4 ? 32 : 64;
-    constexpr int PASSES = TM / PASS_ROWS;            // 4 or 8
-    constexpr int PASSES_PER_GROUP = 128 / PASS_ROWS;  // 2 or 4
-    constexpr int MB_PER_PASS = PASS_ROWS / 16;        // 4 or 2
-    constexpr int CHUNKS = TN * (int)sizeof(YT) / 16;  // 16-byte chunks per row: 32 or 64
+    constexpr int REGION = PASS_ROWS * ROWB;            // 32 KiB
+    constexpr int MBP = PASS_ROWS / 32;                 // fragment row-blocks per wave per pass: 1 or 2
+    constexpr int PASSES = (H + MBP - 1) / MBP;
+    constexpr int CHUNKS = ROWB / 16;                   // 16-byte chunks per row: 32 or 64
     constexpr int EPC = 16 / (int)sizeof(YT);
-    constexpr int ROWS_PER_INST = 64 / CHUNKS > 0 ? 64 / CHUNKS : 1;  // 2 or 1
-    constexpr int INSTS = PASS_ROWS / 8 / ROWS_PER_INST;                // per wave per pass: 4
+    constexpr int RPI = CHUNKS < 64 ? 64 / CHUNKS : 1;  // rows per wave instruction: 2 or 1
+    constexpr int INSTS = PASS_ROWS / 8 / RPI;          // per wave per pass: 4
+    static_assert(2 * REGION <= STAGE_BYTES, "epilogue regions must fit the consumed stage buffer");
     const bool vec_ok = (N % EPC) == 0 && ((uintptr_t)y % 16) == 0;
-    // per-lane constants of the two access patterns (32-bit: one sample's y has < 2^31 elements, checked on the host)
-    const int wr_off = (lane & 15) * ROW + (wn * 64 + (lane >> 4) * 4) * (int)sizeof(YT);
+    // write side: row = (2 t + wm) 16 + (lane & 15); chunk swizzle depends on lane & 15 only
+    const int q = lane >> 4;
+    const int sw_w = sizeof(YT) == 2 ? ((lane & 15) >> 1) & 7 : lane & 7;
+    int wr_off[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int c = sizeof(YT) == 2 ? wn * 8 + nb * 2 + (q >> 1) : wn * 16 + nb * 4 + q;
+        wr_off[nb] = (wm * 16 + (lane & 15)) * ROWB + ((c ^ sw_w) << 4) + (sizeof(YT) == 2 ? (q & 1) * 8 : 0);
+    }
+    // read side: row = wid (PASS_ROWS / 8) + it RPI + lane / CHUNKS, chunk = lane % CHUNKS; swizzle = (4 wid + it) & 7
     const int rd_row = wid * (PASS_ROWS / 8) + (CHUNKS < 64 ? lane / CHUNKS : 0);
-    const int rd_q = CHUNKS < 64 ? lane % CHUNKS : lane;
-    const int rd_off = rd_row * ROW + rd_q * 16;
-    const int n = n0 + rd_q * EPC;
+    const int cq = CHUNKS < 64 ? lane % CHUNKS : lane;
+    const int n = n0 + cq * EPC;
     const bool n_ok = n < N, n_full = vec_ok && n + EPC <= N;
-#pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-        __builtin_amdgcn_s_barrier();  // the region is free (k-loop reads / previous pass's row reads are done)
-        if (wm == pass / PASSES_PER_GROUP) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-                for (int k = 0; k < MB_PER_PASS; ++k) {
-                    const int mb = (pass % PASSES_PER_GROUP) * MB_PER_PASS + k;
-                    const f32x4_t v = bf_apply_act(acc[nb][mb], act);
-                    char* dst = region + wr_off + k * 16 * ROW + nb * 16 * (int)sizeof(YT);
-                    if constexpr (sizeof(YT) == 4)
-                        *reinterpret_cast<f32x4_t*>(dst) = v;
-                    else if constexpr (__is_same(YT, __bf16))
-                        *reinterpret_cast<bf16x4_t*>(dst) = __builtin_convertvector(v, bf16x4_t);
-                    else
-                        *reinterpret_cast<f16x4_t*>(dst) = __builtin_convertvector(v, f16x4_t);
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+    f32x4_t rows[INSTS];
+    auto store_rows = [&](int pass) {
         const int mrow = m0 + pass * PASS_ROWS + rd_row;
 #pragma unroll
         for (int it = 0; it < INSTS; ++it) {
-            const int m = mrow + it * ROWS_PER_INST;
-            if (m < M && n_ok) {
-                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(region + rd_off + it * ROWS_PER_INST * ROW);
+            const int m = mrow + it * RPI;
+            if (m < m_end && n_ok) {
+                const f32x4_t v = rows[it];
                 YT* o = y + (unsigned)(m * N + n);
                 if (n_full) {
                     // streaming store: y is not re-read by this kernel, keep it from evicting operand panels in L2
@@ -187,12 +159,139 @@ __device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&ac
                 }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // row reads done before the region is rewritten
+    };
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        char* R = region + (pass & 1) * REGION;
+        if (!skip) {
+#pragma unroll
+            for (int t = 0; t < MBP; ++t) {
+                const int mb = pass * MBP + t;
+                if (mb < H) {
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        const f32x4_t v = bf_apply_act(acc[nb][mb < H ? mb : 0], act);
+                        char* dst = R + wr_off[nb] + t * 32 * ROWB;
+                        if constexpr (sizeof(YT) == 4)
+                            *reinterpret_cast<f32x4_t*>(dst) = v;
+                        else if constexpr (__is_same(YT, __bf16))
+                            *reinterpret_cast<bf16x4_t*>(dst) = __builtin_convertvector(v, bf16x4_t);
+                        else
+                            *reinterpret_cast<f16x4_t*>(dst) = __builtin_convertvector(v, f16x4_t);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own writes landed; the previous pass's rows arrived
+        if (pass == 0) {
+            if (wm == 0) __builtin_amdgcn_s_barrier();  // rejoin: pairs with group 1's last k-step barrier
+        } else if (!skip) {
+            store_rows(pass - 1);
+        }
+        __builtin_amdgcn_s_barrier();  // every wave's blocks of this pass are in the region
+        if (!skip) {
+#pragma unroll
+            for (int it = 0; it < INSTS; ++it)
+                rows[it] = *reinterpret_cast<const f32x4_t*>(R + (rd_row + it * RPI) * ROWB +
+                                                             ((cq ^ ((wid * 4 + it) & 7)) << 4));
+        }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!skip) store_rows(PASSES - 1);
 }
 
+#ifdef BF_DEV
+// A/B baseline of the pipelined epilogue (developer builds, BF_GEMM_ABLATE bit 32): two barriers per pass, one padded
+// region, row reads batched per pass.
+template <typename YT, int H>
+__device__ __forceinline__ void epilogue_simple(char* region, const f32x4_t (&acc)[4][H], YT* y, int m0, int m_end,
+                                                int n0, int N, int wm, int wn, int wid, int lane, int act) {
+    constexpr int ROW = TN * (int)sizeof(YT) + 16;
+    constexpr int PASS_ROWS = sizeof(YT) == 4 ? 32 : 64;
+    constexpr int MBP = PASS_ROWS / 32;
+    constexpr int PASSES = (H + MBP - 1) / MBP;
+    constexpr int CHUNKS = TN * (int)sizeof(YT) / 16;
+    constexpr int EPC = 16 / (int)sizeof(YT);
+    constexpr int ROWS_PER_INST = 64 / CHUNKS > 0 ? 64 / CHUNKS : 1;
+    constexpr int INSTS = PASS_ROWS / 8 / ROWS_PER_INST;
+    const bool vec_ok = (N % EPC) == 0 && ((uintptr_t)y % 16) == 0;
+    const int wr_off = (wm * 16 + (lane & 15)) * ROW + (wn * 64 + (lane >> 4) * 4) * (int)sizeof(YT);
+    const int rd_row = wid * (PASS_ROWS / 8) + (CHUNKS < 64 ? lane / CHUNKS : 0);
+    const int rd_q = CHUNKS < 64 ? lane % CHUNKS : lane;
+    const int rd_off = rd_row * ROW + rd_q * 16;
+    const int n = n0 + rd_q * EPC;
+    const bool n_ok = n < N, n_full = vec_ok && n + EPC <= N;
+    if (wm == 0) __builtin_amdgcn_s_barrier();  // rejoin
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int t = 0; t < MBP; ++t) {
+            const int mb = pass * MBP + t;
+            if (mb < H) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const f32x4_t v = bf_apply_act(acc[nb][mb < H ? mb : 0], act);
+                    char* dst = region + wr_off + t * 32 * ROW + nb * 16 * (int)sizeof(YT);
+                    if constexpr (sizeof(YT) == 4)
+                        *reinterpret_cast<f32x4_t*>(dst) = v;
+                    else if constexpr (__is_same(YT, __bf16))
+                        *reinterpret_cast<bf16x4_t*>(dst) = __builtin_convertvector(v, bf16x4_t);
+                    else
+                        *reinterpret_cast<f16x4_t*>(dst) = __builtin_convertvector(v, f16x4_t);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int mrow = m0 + pass * PASS_ROWS + rd_row;
+        f32x4_t rows[INSTS];
+#pragma unroll
+        for (int it = 0; it < INSTS; ++it)
+            rows[it] = *reinterpret_cast<const f32x4_t*>(region + rd_off + it * ROWS_PER_INST * ROW);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < INSTS; ++it) {
+            const int m = mrow + it * ROWS_PER_INST;
+            if (m < m_end && n_ok) {
+                const f32x4_t v = rows[it];
+                YT* o = y + (unsigned)(m * N + n);
+                if (n_full) {
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(o));
+                } else {
+                    const YT* e = reinterpret_cast<const YT*>(&v);
+                    for (int j = 0; j < EPC; ++j)
+                        if (n + j < N) o[j] = e[j];
+                }
+            }
+        }
+    }
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------------------
+// The kernel: persistent ping-pong over a host-built tile schedule.
+// The two waves that share a SIMD belong to different wave groups (G0 = waves 0-3 = even 16-row blocks of the tile,
+// G1 = waves 4-7 = odd blocks) and run the same slot sequence one slot apart:
+//
+//      slot:   4t        4t+1      4t+2      4t+3      4t+4
+//      G0:     L0(t)     M0(t)     L1(t)     M1(t)     L0(t+1) ...
+//      G1:     M1(t-1)   L0(t)     M0(t)     L1(t)     M1(t)   ...
+//
+// L = 4 + h ds_read_b128 (the fragments of one 32-deep half of the k-tile) + lgkmcnt(0); M = 4 h MFMAs on registers.
+// Every slot ends in one workgroup barrier, so a SIMD always has one wave on the matrix pipe while its partner is
+// on the LDS pipe.  The LDS DMA of k-step t+1 is issued by each wave at the start of its own L0(t) and is only
+// waited for at the last barrier before slot 4(t+1), i.e. it has 3-4 slots (>= 1500 cycles) to land.
+//   * the LDS DMA issued in the LAST k-step of a tile fetches k-step 0 of the workgroup's NEXT tile into the buffer
+//     that would otherwise idle, and is retired by the k-loop's existing waits — the next tile starts without a
+//     cold-start load;
+//   * the epilogue stages the accumulators through the just-consumed buffer in passes, so the prefetched stage in
+//     the other buffer survives it; its global stores are not waited for until the next tile's first k-step
+//     retires them together with that step's DMA.
+// Schedule entry (int4): x = (layer, sample) pair index into w / bias / y, y = sample index into x,
+// z = n-tile | height << 24 (height in 32-row units; 0 = no tile), w = first row.
 template <typename T, typename YT>
-__global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParams p) {
+__global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams p) {
     using frag = typename Mfma16<T>::frag;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
 
@@ -200,8 +299,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
     const int M = p.M, N = p.N, K = p.K;
-    const int tiles_nl = p.tiles_n * p.layers;  // the L layers sharing x form one wide row of n-tiles per m-panel
-    const unsigned total = (unsigned)(p.tiles_m * tiles_nl * p.S);
 
     const int prow = lane >> 3;
     const int kc8 = ((lane & 7) ^ ((((wid & 1) << 2) + (lane >> 4)) & 7)) * 8;
@@ -210,32 +307,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
     struct Src {
         const T* xb;
         const T* wb;
-        unsigned xo[4], wo[4];
+        unsigned xo[XPIECES], wo[4];
     };
-    // s = index of the (layer, sample) pair in w / bias / y; the activations only depend on the sample
-    auto tile_setup = [&](unsigned vb, Src& t, int& s, int& m0, int& n0) {
-        int tm, tn, xs;
-        tile_coords(xcd_remap(vb, total), p.tiles_m, tiles_nl, xs, tm, tn);
-        const int layer = tn / p.tiles_n;
-        tn -= layer * p.tiles_n;
-        s = layer * p.S + xs;
-        m0 = tm * TM;
-        n0 = tn * TN;
-        t.xb = reinterpret_cast<const T*>(p.x) + (long long)xs * p.x_sstride;
+    auto tile_setup = [&](const int4 d, Src& t, int& s, int& m0, int& n0, int& h) {
+        // the entry is the same for every lane: say so, so that everything derived from it lives in SGPRs
+        s = __builtin_amdgcn_readfirstlane(d.x);
+        const int z = __builtin_amdgcn_readfirstlane(d.z);
+        h = z >> 24;
+        m0 = __builtin_amdgcn_readfirstlane(d.w);
+        n0 = (z & 0xFFFFFF) * TN;
+        t.xb = reinterpret_cast<const T*>(p.x) + (long long)__builtin_amdgcn_readfirstlane(d.y) * p.x_sstride;
         t.wb = reinterpret_cast<const T*>(p.w) + (long long)s * N * K;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (i * 8 + wid) * 8 + prow;
-            t.xo[i] = (unsigned)min(m0 + row, M - 1) * (unsigned)K + kc8;
-            t.wo[i] = (unsigned)min(n0 + row, N - 1) * (unsigned)K + kc8;
-        }
+        for (int i = 0; i < XPIECES; ++i)
+            t.xo[i] = (unsigned)min(m0 + (i * 8 + wid) * 8 + prow, M - 1) * (unsigned)K + kc8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t.wo[i] = (unsigned)min(n0 + (i * 8 + wid) * 8 + prow, N - 1) * (unsigned)K + kc8;
     };
-    auto stage = [&](const Src& t, int kt, int buf) {
+    // piece q = i * 8 + wid covers rows 8 q .. 8 q + 7 of the stage; only the 4 h pieces of a tile's rows are fetched
+    // (inside a tile's k-loop h is the compile-time height, so a full-height tile issues its pieces without branches)
+    auto stage = [&](const Src& t, int kt, int buf, auto h) {
         char* base = smem + buf * STAGE_BYTES;
         const T* xk = t.xb + kt * TK;
         const T* wk = t.wb + kt * TK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(xk + t.xo[i], base + (i * 8 + wid) * 1024);
+        for (int i = 0; i < XPIECES; ++i)
+            if (i * 8 + 7 < 4 * h || i * 8 + wid < 4 * h) glds16(xk + t.xo[i], base + (i * 8 + wid) * 1024);
 #pragma unroll
         for (int i = 0; i < 4; ++i) glds16(wk + t.wo[i], base + X_BYTES + (i * 8 + wid) * 1024);
     };
@@ -243,114 +340,264 @@ __global__ __launch_bounds__(512, 2) void gemm256_persist_kernel(const GemmParam
     const int fsw = (lane >> 1) & 7;
     const int foff0 = (lane & 15) * ROW_BYTES + ((((lane >> 4)) ^ fsw) << 4);
     const int foff1 = (lane & 15) * ROW_BYTES + (((4 + (lane >> 4)) ^ fsw) << 4);
-    const int xfrag_base = wm * 128 * ROW_BYTES;
+    const int xfrag_base = wm * 16 * ROW_BYTES;  // + j * 32 rows: wave group wm owns blocks wm, wm + 2, ...
     const int wfrag_base = X_BYTES + wn * 64 * ROW_BYTES;
 
     const int nk = K / TK;
-    unsigned vb = blockIdx.x;
+    const int4* __restrict__ sched = p.sched + blockIdx.x;
+    const unsigned G = gridDim.x;
+    int4 d = sched[0];
+    if ((d.z >> 24) == 0) return;
     Src cur;
-    int s, m0, n0;
-    tile_setup(vb, cur, s, m0, n0);
+    int s, m0, n0, h;
+    tile_setup(d, cur, s, m0, n0, h);
     int g = 0;  // running k-step counter: step g lives in LDS buffer g & 1
-    stage(cur, 0, 0);
+    stage(cur, 0, 0, h);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    f32x4_t acc[4][8];
-    frag wf[4], xf[8];
-
-    // the four slots of one k-step; `dma()` issues this step's LDS DMA at the top of L0
-    auto kstep = [&](auto&& dma) {
-        const char* sb = smem + (g & 1) * STAGE_BYTES;
-        dma();
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            wf[i] = *reinterpret_cast<const frag*>(sb + wfrag_base + i * 16 * ROW_BYTES + foff0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            xf[j] = *reinterpret_cast<const frag*>(sb + xfrag_base + j * 16 * ROW_BYTES + foff0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            wf[i] = *reinterpret_cast<const frag*>(sb + wfrag_base + i * 16 * ROW_BYTES + foff1);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            xf[j] = *reinterpret_cast<const frag*>(sb + xfrag_base + j * 16 * ROW_BYTES + foff1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        if (wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        ++g;
-    };
-
+    int round = 0;
     for (;;) {
-        const bool has_next = vb + gridDim.x < total;
-        if (wm == 1) __builtin_amdgcn_s_barrier();  // G1 runs one slot behind G0
-        init_acc(acc, p.bias ? p.bias + (long long)s * N : nullptr, n0, N, wn, lane);
+        int4 dn = {0, 0, 0, 0};
+        if (round + 1 < p.sched_rounds) dn = sched[(unsigned)(round + 1) * G];
+        const bool has_next = (dn.z >> 24) != 0;
 
-        for (int kt = 0; kt + 1 < nk; ++kt)
-            kstep([&] { if (!(p.flags & 1)) stage(cur, (p.flags & 64) ? 0 : kt + 1, (g & 1) ^ 1); });
-        // last k-step: its DMA slot fetches k-step 0 of this workgroup's next tile
-        unsigned vbn = vb + gridDim.x;
-        asm volatile("" : "+s"(vbn));  // keep the next tile's address arithmetic out of the k-loop's live ranges
-        kstep([&] {
-            if (has_next && !(p.flags & 1)) {
-                Src nxt;
-                int s2, m2, n2;
-                tile_setup(vbn, nxt, s2, m2, n2);
-                stage(nxt, 0, (g & 1) ^ 1);
-            }
-        });
-        if (wm == 0) __builtin_amdgcn_s_barrier();  // rejoin: balance G1's leading barrier
+        auto body = [&](auto hc) {
+            constexpr int H = decltype(hc)::value;
+            f32x4_t acc[4][H];
+            frag wf[4], xf[H];
+            // the four slots of one k-step; `dma()` issues this step's LDS DMA at the top of L0
+            auto kstep = [&](auto&& dma) {
+                const char* sb = smem + (g & 1) * STAGE_BYTES;
+                dma();
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    wf[i] = *reinterpret_cast<const frag*>(sb + wfrag_base + i * 16 * ROW_BYTES + foff0);
+#pragma unroll
+                for (int j = 0; j < H; ++j)
+                    xf[j] = *reinterpret_cast<const frag*>(sb + xfrag_base + j * 32 * ROW_BYTES + foff0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < H; ++j) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    wf[i] = *reinterpret_cast<const frag*>(sb + wfrag_base + i * 16 * ROW_BYTES + foff1);
+#pragma unroll
+                for (int j = 0; j < H; ++j)
+                    xf[j] = *reinterpret_cast<const frag*>(sb + xfrag_base + j * 32 * ROW_BYTES + foff1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < H; ++j) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                if (wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                ++g;
+            };
 
-        // the last consumed buffer is (g-1)&1; buffer g&1 already holds k-step 0 of the next tile
-        YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
-        if (!(p.flags & 8))
-            epilogue_passes<YT>(smem + ((g - 1) & 1) * STAGE_BYTES, acc, nullptr, y, m0, n0, (p.flags & 16) ? 0 : M, N, wm,
-                                wn, wid, lane, p.act);
+            if (wm == 1) __builtin_amdgcn_s_barrier();  // G1 runs one slot behind G0
+            init_acc<H>(acc, p.bias ? p.bias + (long long)s * N : nullptr, n0, N, wn, lane);
+
+            for (int kt = 0; kt + 1 < nk; ++kt)
+                kstep([&] {
+#ifdef BF_DEV
+                    if (p.flags & 1) return;
+                    stage(cur, (p.flags & 64) ? 0 : kt + 1, (g & 1) ^ 1, hc);
+#else
+                    stage(cur, kt + 1, (g & 1) ^ 1, hc);
+#endif
+                });
+            // last k-step: its DMA slot fetches k-step 0 of this workgroup's next tile
+            kstep([&] {
+#ifdef BF_DEV
+                if (p.flags & 1) return;
+#endif
+                if (has_next) {
+                    Src nxt;
+                    int s2, m2, n2, h2;
+                    tile_setup(dn, nxt, s2, m2, n2, h2);
+                    stage(nxt, 0, (g & 1) ^ 1, h2);
+                }
+            });
+            // the last consumed buffer is (g-1)&1; buffer g&1 already holds k-step 0 of the next tile.  Group 0 is one
+            // slot ahead here; it rejoins group 1 inside the epilogue (after the first pass's VALU work)
+            YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
+            int m_end = min(M, m0 + h * UNIT);
+            bool skip = false;
+#ifdef BF_DEV
+            if (p.flags & 16) m_end = 0;
+            skip = (p.flags & 8) != 0;
+#endif
+#ifdef BF_DEV
+            if (p.flags & 32)
+                epilogue_simple<YT, H>(smem + ((g - 1) & 1) * STAGE_BYTES, acc, y, m0, m_end, n0, N, wm, wn, wid, lane,
+                                       p.act);
+            else
+#endif
+            epilogue_passes<YT, H>(smem + ((g - 1) & 1) * STAGE_BYTES, acc, y, m0, m_end, n0, N, wm, wn, wid, lane,
+                                   p.act, skip);
+        };
+        switch (h) {
+            case 8: body(std::integral_constant<int, 8>{}); break;
+            case 7: body(std::integral_constant<int, 7>{}); break;
+            case 6: body(std::integral_constant<int, 6>{}); break;
+            case 5: body(std::integral_constant<int, 5>{}); break;
+            default: body(std::integral_constant<int, 4>{}); break;  // h <= 4: rows past 32 h are masked on store
+        }
         if (!has_next) break;
-        vb = vbn;
-        tile_setup(vb, cur, s, m0, n0);
+        d = dn;
+        ++round;
+        tile_setup(d, cur, s, m0, n0, h);
         __builtin_amdgcn_s_barrier();  // every wave has left the epilogue before the region takes DMA again
     }
 }
 
-template <typename T>
-int launch256(const GemmParams& p, int y_dtype, hipStream_t stream) {
-    const uint32_t tiles = (uint32_t)(p.tiles_m * p.tiles_n * p.S * p.layers);
-    // persistent: one workgroup per CU (a grid that is a multiple of 8 keeps a workgroup's tiles on one XCD)
-    static int n_cu = 0;
+// ------------------------------------------------------------------------------------------------------------
+// Host side: the tile schedule.
+struct Tile {
+    int pair, xs, tn, m0, h;
+    long long key;  // locality order inside a height class
+};
+
+// XCD-aware bijective map of a block id to its position in the logical workgroup order (block b runs on XCD b % 8,
+// observed; speed only): XCD x owns a contiguous run of logical positions.
+unsigned xcd_remap(unsigned b, unsigned nwg) {
+    const unsigned xcd = b & 7u, q = nwg >> 3, r = nwg & 7u;
+    const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+// Cut S * layers * tiles_n columns of ceil(M / 32) units into tiles of 1..8 units and deal them to at most n_cu
+// workgroups.  Returns the table ([rounds][grid] int4) and the launch grid.
+// policy bit 0: workgroups at odd logical positions run their tiles in reverse order (short tiles first), which
+// spreads the workgroups' epilogue store bursts over time instead of all of them ending a tile in the same
+// microsecond.
+void build_schedule(int S, int layers, int tiles_n, int M, int n_cu, int policy, std::vector<int4>& table, int& rounds,
+                    int& grid) {
+    const int hmax = ((policy >> 4) & 15) ? std::min(HMAX, std::max(HMIN, (policy >> 4) & 15)) : HMAX;
+    const int C = S * layers * tiles_n;
+    const int Hc = (M + UNIT - 1) / UNIT;
+    const long long U = (long long)C * Hc;
+    const int n_min = (Hc + hmax - 1) / hmax;
+    const int n_max = std::max(n_min, Hc / HMIN);
+    long long T = std::max<long long>(1, (U + (long long)hmax * n_cu - 1) / ((long long)hmax * n_cu));  // tiles per CU
+    std::vector<Tile> tiles;
+    for (int iter = 0; iter < 4; ++iter) {
+        const long long target = T * n_cu;
+        tiles.clear();
+        for (int c = 0; c < C; ++c) {
+            // Bresenham spread of the target tile count over the columns
+            long long n = (target * (c + 1)) / C - (target * c) / C;
+            n = std::min<long long>(std::max<long long>(n, n_min), n_max);
+            const int q = Hc / (int)n, r = Hc % (int)n;
+            const int xs = c / (tiles_n * layers), cn = c % (tiles_n * layers);
+            const int layer = cn / tiles_n, tn = cn % tiles_n;
+            int u = 0;
+            for (int i = 0; i < (int)n; ++i) {
+                const int hh = q + (i < r ? 1 : 0);
+                Tile t;
+                t.pair = layer * S + xs;
+                t.xs = xs;
+                t.tn = tn;
+                t.m0 = u * UNIT;
+                t.h = hh;
+                // (sample, band of 1024 rows, column, row): the 32 concurrent tiles of an XCD share few panels
+                t.key = (((long long)xs * 4096 + t.m0 / 1024) * 4096 + cn) * 65536 + (t.m0 / UNIT);
+                tiles.push_back(t);
+                u += hh;
+            }
+        }
+        if ((long long)tiles.size() <= target) break;
+        T = ((long long)tiles.size() + n_cu - 1) / n_cu;  // the height cap forced more tiles than T rounds hold
+    }
+    std::stable_sort(tiles.begin(), tiles.end(), [](const Tile& a, const Tile& b) {
+        return a.h != b.h ? a.h > b.h : a.key < b.key;
+    });
+    const int total = (int)tiles.size();
+    grid = std::min(total, n_cu);
+    rounds = (total + grid - 1) / grid;
+    // per logical workgroup: its tiles, one per round (tallest classes first; odd rounds dealt backwards so that a
+    // workgroup that drew a tall tile in one round draws a short one in the next)
+    std::vector<std::vector<int>> lists(grid);
+    for (int k = 0; k < total; ++k) {
+        const int r = k / grid, pos = k % grid;
+        lists[(r & 1) ? grid - 1 - pos : pos].push_back(k);
+    }
+    if (policy & 1)
+        for (int li = 1; li < grid; li += 2) std::reverse(lists[li].begin(), lists[li].end());
+    table.assign((size_t)rounds * grid, int4{0, 0, 0, 0});
+    for (int b = 0; b < grid; ++b) {
+        const std::vector<int>& l = lists[xcd_remap((unsigned)b, (unsigned)grid)];
+        for (size_t j = 0; j < l.size(); ++j) {
+            const Tile& t = tiles[l[j]];
+            table[j * grid + b] = int4{t.pair, t.xs, t.tn | (t.h << 24), t.m0};
+        }
+    }
+}
+
+struct Sched {
+    int4* d_table;
+    int rounds, grid;
+};
+typedef std::tuple<int, int, int, int, int, int, int> SchedKey;  // device, S, layers, tiles_n, M, n_cu, policy
+std::mutex g_sched_mu;
+std::map<SchedKey, Sched> g_sched;
+
+// The schedule of a shape is built once per device and kept in device memory for the life of the process (a few KB
+// per shape).  The first launch of a shape therefore allocates: it cannot happen inside a stream capture.
+int get_schedule(int S, int layers, int tiles_n, int M, int policy, hipStream_t stream, Sched& out) {
+    int dev = 0;
+    BF_HIP_CHECK(hipGetDevice(&dev));
+    static std::map<int, int> cu_of;
+    std::lock_guard<std::mutex> lk(g_sched_mu);
+    int n_cu = cu_of[dev];
     if (!n_cu) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 256;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 256;
         else n_cu = prop.multiProcessorCount / 8 * 8;
         if (n_cu < 8) n_cu = 8;
+        cu_of[dev] = n_cu;
     }
-    const dim3 grid(tiles < (uint32_t)n_cu ? tiles : (uint32_t)n_cu);
+    const SchedKey key(dev, S, layers, tiles_n, M, n_cu, policy);
+    auto it = g_sched.find(key);
+    if (it != g_sched.end()) {
+        out = it->second;
+        return 0;
+    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+        BF_FAIL("bf_gemm_nt: the first launch of a shape (S=%d M=%d) builds its tile schedule and allocates device "
+                "memory; run the step once before capturing it into a graph", S, M);
+    std::vector<int4> table;
+    Sched sc;
+    build_schedule(S, layers, tiles_n, M, n_cu, policy, table, sc.rounds, sc.grid);
+    BF_HIP_CHECK(hipMalloc((void**)&sc.d_table, table.size() * sizeof(int4)));
+    BF_HIP_CHECK(hipMemcpy(sc.d_table, table.data(), table.size() * sizeof(int4), hipMemcpyHostToDevice));
+    g_sched[key] = sc;
+    out = sc;
+    return 0;
+}
+
+template <typename T>
+int launch256(const GemmParams& p, int y_dtype, hipStream_t stream, int grid) {
     if (y_dtype == BF_DT_F32)
-        hipLaunchKernelGGL((gemm256_persist_kernel<T, float>), grid, dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((gemm256_sched_kernel<T, float>), dim3(grid), dim3(512), 0, stream, p);
     else
-        hipLaunchKernelGGL((gemm256_persist_kernel<T, T>), grid, dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((gemm256_sched_kernel<T, T>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -367,19 +614,49 @@ bool bf_gemm256_supported(int x_dtype, int w_dtype, int y_dtype, int S, int M, i
     if (((uintptr_t)d_x | (uintptr_t)d_w) & 15) return false;
     if (((size_t)x_sample_stride * 2) % 16 != 0) return false;
     if ((long long)M * K >= (1ll << 32) || (long long)N * K >= (1ll << 32) || (long long)M * N >= (1ll << 31)) return false;
-    const long long tiles = (long long)((M + TM - 1) / TM) * ((N + TN - 1) / TN) * S;  // S counts (layer, sample) pairs
-    if (tiles > 0x7FFFFFFFll) return false;
-    (void)S;
+    if (M >= (1 << 24) || (N + TN - 1) / TN >= (1 << 24)) return false;  // schedule entry packing
+    const long long tiles = (long long)((M + UNIT * HMIN - 1) / (UNIT * HMIN)) * ((N + TN - 1) / TN) * S;  // S counts (layer, sample) pairs
+    if (tiles > 0x3FFFFFll) return false;  // the host-built schedule stays small
     return true;
+}
+
+extern "C" size_t bf_gemm_schedule(int S, int L, int M, int N, int n_cu, int32_t* out, size_t cap_values, int* rounds,
+                                   int* grid) {
+    if (S < 1 || L < 1 || M < 1 || N < 1 || n_cu < 1) return 0;
+    std::vector<int4> table;
+    int r = 0, g = 0;
+    build_schedule(S, L, (N + TN - 1) / TN, M, n_cu, 1, table, r, g);
+    if (rounds) *rounds = r;
+    if (grid) *grid = g;
+    const size_t n = table.size() * 4;
+    if (out && cap_values >= n)
+        for (size_t i = 0; i < table.size(); ++i) {
+            out[4 * i] = table[i].x;
+            out[4 * i + 1] = table[i].y;
+            out[4 * i + 2] = table[i].z;
+            out[4 * i + 3] = table[i].w;
+        }
+    return n;
 }
 
 int bf_launch_gemm256(const GemmParams& p0, int w_dtype, int y_dtype, hipStream_t stream) {
     GemmParams p = p0;
+    int policy = 1;
+#ifdef BF_DEV
     const char* ab = getenv("BF_GEMM_ABLATE");
     p.flags = ab ? atoi(ab) : 0;
+    const char* pol = getenv("BF_GEMM_SCHED");
+    if (pol) policy = atoi(pol);
+#else
+    p.flags = 0;
+#endif
     if (p.layers < 1) p.layers = 1;
     p.tiles_m = (p.M + TM - 1) / TM;
     p.tiles_n = (p.N + TN - 1) / TN;
-    if (w_dtype == BF_DT_BF16) return launch256<__bf16>(p, y_dtype, stream);
-    return launch256<_Float16>(p, y_dtype, stream);
+    Sched sc;
+    if (get_schedule(p.S, p.layers, p.tiles_n, p.M, policy, stream, sc)) return 1;
+    p.sched = sc.d_table;
+    p.sched_rounds = sc.rounds;
+    if (w_dtype == BF_DT_BF16) return launch256<__bf16>(p, y_dtype, stream, sc.grid);
+    return launch256<_Float16>(p, y_dtype, stream, sc.grid);
 }

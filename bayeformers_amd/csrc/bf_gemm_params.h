@@ -13,11 +13,19 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int act;      // BF_ACT_* applied to y in the epilogue
     int layers;   // L >= 1 layers that share x: w is [L][S][N][K], bias [L][S][N], y [L][S][M][N] (bf_gemm_nt_layers)
-    int flags;  // developer ablation bits (BF_GEMM_ABLATE): 1 = no DMA in the k-loop, 8 = no stores, 16 = no row mask,
-                // 64 = every k-step's DMA re-reads k-step 0 (operands always L2-hot)
+    // tile schedule of the 256-wide persistent kernel (bf_gemm256.hip): workgroup b runs sched[j * gridDim.x + b],
+    // j = 0 .. sched_rounds - 1, until an entry with height 0
+    const int4* sched;
+    int sched_rounds;
+    int flags;  // developer ablation bits, honoured by -DBF_DEV builds only (tools/): 1 = no DMA in the k-loop,
+                // 8 = no epilogue, 16 = no row mask, 64 = every k-step's DMA re-reads k-step 0 (operands L2-hot)
 };
 
-// fast 256x256x64 LDS-DMA kernel (bf_gemm256.hip)
+// fast 256-wide LDS-DMA kernel (bf_gemm256.hip)
 bool bf_gemm256_supported(int x_dtype, int w_dtype, int y_dtype, int S, int M, int N, int K, const void* d_x,
                           const void* d_w, int64_t x_sample_stride);
 int bf_launch_gemm256(const GemmParams& p, int w_dtype, int y_dtype, hipStream_t stream);
+#ifdef BF_DEV
+// round-1 kernel (fixed 256x256 tiles, arithmetic tile order), kept in developer builds as the A/B baseline
+int bf_launch_gemm256_r1(const GemmParams& p, int w_dtype, int y_dtype, hipStream_t stream);
+#endif

@@ -132,6 +132,14 @@ int bf_gemm_nt_layers(const void* d_x, int x_dtype, int64_t x_sample_stride, con
                       const float* d_bias, void* d_y, int y_dtype, int L, int S, int M, int N, int K, int act,
                       void* stream);
 
+/* The host-built tile schedule the 256-wide persistent GEMM kernel runs for a problem of S samples x L layers x
+ * [M, N] outputs on n_cu compute units (introspection: the library builds and caches the same table on the first
+ * launch of a shape).  The output is cut into tiles of 32 h rows (h = 1..8) x 256 columns; every workgroup b of the
+ * `grid` persistent workgroups runs entries out[(j * grid + b) * 4 ..] for j = 0 .. rounds - 1 until an entry of
+ * height 0.  Entry = {pair = l * S + s, s, n_tile | h << 24, first row}.  Returns the number of int32 values the
+ * table holds (4 * rounds * grid); fills `out` only when cap_values is large enough. */
+size_t bf_gemm_schedule(int S, int L, int M, int N, int n_cu, int32_t* out, size_t cap_values, int* rounds, int* grid);
+
 /* The whole of Linear.forward (layers/linear.py:83-104) for S Monte-Carlo samples in one call:
  * sample W_s and b_s, accumulate both log-probs, y[s] = x[s] W_s^T + b_s.
  *   weight.n must be N*K (row-major [N][K], as nn.Linear), bias may be NULL (NoneParameter, base.py:55-69);

@@ -1,15 +1,22 @@
-// gemm_bench — developer micro-benchmark of bf_gemm_nt variants (BF_GEMM_VARIANT env knob) through the C-ABI.
-//   hipcc --offload-arch=gfx950 -O2 tools/gemm_bench.cpp -Iinclude -Lbayeformers_amd/lib -lbayeformers_amd \
-//         -Wl,-rpath,'$ORIGIN/../bayeformers_amd/lib' -o tools/gemm_bench
-//   tools/gemm_bench [S M N K] ...        (defaults: the BERT-base shapes at S=10, M=4096)
-// For each shape: checks the 256x256x64 persistent kernel (variant 1) against variant 0 (the generic 128x128x32
-// kernel), then times both.  BF_GEMM_ABLATE bits: 1 no DMA in the k-loop, 8 no epilogue, 16 no global stores.
+// gemm_bench — developer micro-benchmark of the sampled-weight GEMM kernels through the C-ABI (bf_gemm_nt_act).
+// Needs the DEVELOPER build of the library (python -m bayeformers_amd.build --dev), whose environment switches select
+// the kernel per call:
+//   hipcc --offload-arch=gfx950 -O2 tools/gemm_bench.cpp -Iinclude -Lbayeformers_amd/lib -lbayeformers_amd_dev \
+//         -Wl,-rpath,'$ORIGIN/../bayeformers_amd/lib' -o tools/bin/gemm_bench
+//   tools/bin/gemm_bench [S M N K act] ...      (defaults: the BERT-base launches at S=10, M=4096)
+// BF_BENCH_CONFIGS="1 2:0 2:1:32" lists the configurations to compare as variant[:schedule policy[:ablation bits]] (variant 0 = generic
+// 128x128 kernel, 1 = round-1 fixed-tile kernel, 2 = scheduled kernel).  Every configuration is checked against
+// variant 0, then all of them are timed in interleaved rounds in this one process; median and best are reported.
+// BF_GEMM_ABLATE bits (dev build): 1 no DMA in the k-loop, 8 no epilogue, 16 no global stores, 64 L2-hot DMA.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <string>
 #include <vector>
 
 #include "bayeformers_amd.h"
@@ -36,42 +43,55 @@ static float bf2f(uint16_t h) {
     return f;
 }
 
-static double run(int variant, const void* x, const void* w, const float* b, void* y, int S, int M, int N, int K, int iters) {
-    char v[8];
-    snprintf(v, sizeof v, "%d", variant);
+struct Config {
+    int variant, policy;
+    std::string name;
+    int ablate = 0;
+};
+
+static void select(const Config& c) {
+    char v[16];
+    snprintf(v, sizeof v, "%d", c.variant);
     setenv("BF_GEMM_VARIANT", v, 1);
-    hipEvent_t e0, e1;
-    CK(hipEventCreate(&e0));
-    CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i)
-        if (bf_gemm_nt(x, BF_DT_BF16, (int64_t)M * K, w, BF_DT_BF16, b, y, BF_DT_BF16, S, M, N, K, nullptr)) {
-            printf("bf_gemm_nt: %s\n", bf_last_error());
-            exit(1);
-        }
-    CK(hipDeviceSynchronize());
-    CK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < iters; ++i) bf_gemm_nt(x, BF_DT_BF16, (int64_t)M * K, w, BF_DT_BF16, b, y, BF_DT_BF16, S, M, N, K, nullptr);
-    CK(hipEventRecord(e1, nullptr));
-    CK(hipEventSynchronize(e1));
-    float ms = 0;
-    CK(hipEventElapsedTime(&ms, e0, e1));
-    return ms / iters;
+    snprintf(v, sizeof v, "%d", c.policy);
+    setenv("BF_GEMM_SCHED", v, 1);
+    snprintf(v, sizeof v, "%d", c.ablate);
+    setenv("BF_GEMM_ABLATE", v, 1);
 }
 
 int main(int argc, char** argv) {
     std::vector<int> shapes;
     for (int i = 1; i < argc; ++i) shapes.push_back(atoi(argv[i]));
-    if (shapes.empty()) shapes = {10, 4096, 768, 768, 10, 4096, 3072, 768, 10, 4096, 768, 3072, 10, 4096, 2304, 768,
-                                  1, 4096, 4096, 4096};
-    const char* vs = getenv("BF_BENCH_VARIANTS");
-    std::vector<int> variants = {1};
-    if (vs) {
-        variants.clear();
-        for (const char* p = vs; *p; ++p)
-            if (*p >= '0' && *p <= '9') variants.push_back(*p - '0');
+    // S M N K act, with L = N / 768 stacked layers when N = 2304 (the one-launch Q/K/V shape is run as a plain N)
+    if (shapes.empty())
+        shapes = {10, 4096, 768, 768, 0, 10, 4096, 2304, 768, 0, 10, 4096, 3072, 768, 1, 10, 4096, 768, 3072, 0,
+                  1, 4096, 4096, 4096, 0};
+    std::vector<Config> configs;
+    const char* cs = getenv("BF_BENCH_CONFIGS");
+    std::string spec = cs ? cs : "1 2:0 2:1";
+    for (size_t p = 0; p < spec.size();) {
+        while (p < spec.size() && spec[p] == ' ') ++p;
+        if (p >= spec.size()) break;
+        size_t q = spec.find(' ', p);
+        if (q == std::string::npos) q = spec.size();
+        std::string tok = spec.substr(p, q - p);
+        Config c;
+        c.variant = atoi(tok.c_str());
+        size_t colon = tok.find(':');
+        c.policy = colon == std::string::npos ? 1 : atoi(tok.c_str() + colon + 1);
+        size_t colon2 = colon == std::string::npos ? colon : tok.find(':', colon + 1);
+        c.ablate = colon2 == std::string::npos ? (getenv("BF_GEMM_ABLATE") ? atoi(getenv("BF_GEMM_ABLATE")) : 0)
+                                               : atoi(tok.c_str() + colon2 + 1);
+        c.name = "v" + tok;
+        configs.push_back(c);
+        p = q;
     }
-    for (size_t q = 0; q + 3 < shapes.size(); q += 4) {
-        const int S = shapes[q], M = shapes[q + 1], N = shapes[q + 2], K = shapes[q + 3];
+    const int rounds = getenv("BF_BENCH_ROUNDS") ? atoi(getenv("BF_BENCH_ROUNDS")) : 7;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (size_t q = 0; q + 4 < shapes.size(); q += 5) {
+        const int S = shapes[q], M = shapes[q + 1], N = shapes[q + 2], K = shapes[q + 3], act = shapes[q + 4];
         const size_t nx = (size_t)S * M * K, nw = (size_t)S * N * K, ny = (size_t)S * M * N;
         std::vector<uint16_t> hx(nx), hw(nw);
         std::vector<float> hb((size_t)S * N);
@@ -94,14 +114,25 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dw, hw.data(), nw * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
         const double flop = 2.0 * S * M * (double)N * K;
-        const int iters = flop > 2e11 ? 10 : 30;
-        double t0 = run(0, dx, dw, db, dy0, S, M, N, K, iters);
-        printf("S=%d M=%d N=%d K=%d | v0 %.1f us %.0f TF", S, M, N, K, t0 * 1e3, flop / t0 / 1e9);
+        const int iters = flop > 2e11 ? 6 : 20;
+        auto call = [&](void* y) {
+            if (bf_gemm_nt_act(dx, BF_DT_BF16, (int64_t)M * K, dw, BF_DT_BF16, db, y, BF_DT_BF16, S, M, N, K, act, nullptr)) {
+                printf("bf_gemm_nt_act: %s\n", bf_last_error());
+                exit(1);
+            }
+        };
+        // reference: the generic kernel
+        select(Config{0, 0, "v0", 0});
+        call(dy0);
+        CK(hipDeviceSynchronize());
         std::vector<uint16_t> h0(ny), h1(ny);
         CK(hipMemcpy(h0.data(), dy0, ny * 2, hipMemcpyDeviceToHost));
-        for (int v : variants) {
+        printf("S=%d M=%d N=%d K=%d act=%d |", S, M, N, K, act);
+        for (const Config& c : configs) {
+            select(c);
             CK(hipMemset(dy1, 0xFF, ny * 2));
-            double t1 = run(v, dx, dw, db, dy1, S, M, N, K, iters);
+            call(dy1);
+            CK(hipDeviceSynchronize());
             CK(hipMemcpy(h1.data(), dy1, ny * 2, hipMemcpyDeviceToHost));
             double maxd = 0;
             size_t bad = 0;
@@ -110,9 +141,28 @@ int main(int argc, char** argv) {
                 if (!(d <= 1e-2 * (1.0 + fabs((double)bf2f(h0[i]))))) ++bad;
                 if (d > maxd || d != d) maxd = d;
             }
-            printf(" | v%d %.1f us %.0f TF maxdiff %.3g bad %zu", v, t1 * 1e3, flop / t1 / 1e9, maxd, bad);
+            printf(" %s maxdiff %.3g bad %zu |", c.name.c_str(), maxd, bad);
         }
         printf("\n");
+        std::vector<std::vector<double>> t(configs.size());
+        for (int rd = 0; rd < rounds + 1; ++rd)
+            for (size_t ci = 0; ci < configs.size(); ++ci) {
+                select(configs[ci]);
+                call(dy1);  // warm
+                CK(hipEventRecord(e0, nullptr));
+                for (int i = 0; i < iters; ++i) call(dy1);
+                CK(hipEventRecord(e1, nullptr));
+                CK(hipEventSynchronize(e1));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rd) t[ci].push_back(ms / iters);
+            }
+        for (size_t ci = 0; ci < configs.size(); ++ci) {
+            std::sort(t[ci].begin(), t[ci].end());
+            const double med = t[ci][t[ci].size() / 2], best = t[ci][0];
+            printf("    %-6s median %.1f us %.0f TF | best %.1f us %.0f TF\n", configs[ci].name.c_str(), med * 1e3,
+                   flop / med / 1e9, best * 1e3, flop / best / 1e9);
+        }
         hipFree(dx); hipFree(dw); hipFree(dy0); hipFree(dy1); hipFree(db);
     }
     return 0;
