@@ -43,6 +43,7 @@ SYMBOLS = {
     "bf_version": (_i, []),
     "bf_last_error": (ctypes.c_char_p, []),
     "bf_set_sample_counter": (_i, [_vp]),
+    "bf_get_sample_counter": (_vp, []),
     "bf_device_info": (_i, [ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "bf_philox_normal_host": (_i, [_vp, _u64, _u64, _u32, _u32, _u64]),
     "bf_philox_normal": (_i, [_vp, _u64, _i, _u64, _u32, _u32, _vp]),
@@ -72,7 +73,7 @@ SYMBOLS = {
     "bf_profile_read": (_i, [_i, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
                              ctypes.POINTER(ctypes.c_double)]),
 }
-BF_PROF_SAMPLE, BF_PROF_GEMM = 0, 1
+BF_PROF_SAMPLE, BF_PROF_GEMM, BF_PROF_FUSED_SMALL = 0, 1, 2
 BF_ACT_NONE, BF_ACT_GELU = 0, 1
 
 _lib = None

@@ -7,9 +7,18 @@
 #include "bf_philox.h"
 
 static thread_local char g_err[512] = "";
-static const uint32_t* g_sample_counter = nullptr;
+// device-resident sample counters, one slot per HIP device: a pointer is only meaningful on the device it was
+// allocated on, and launches look it up by the calling thread's current device
+static constexpr int kMaxDevices = 64;
+static const uint32_t* g_sample_counter[kMaxDevices] = {};
 
-const uint32_t* bf_sample_counter() { return g_sample_counter; }
+static int current_device_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+    return dev;
+}
+
+const uint32_t* bf_sample_counter() { return g_sample_counter[current_device_slot()]; }
 
 void bf_set_error(const char* fmt, ...) {
     va_list ap;
@@ -115,9 +124,11 @@ int bf_profile_read(int kind, uint64_t* launches, double* total_ms, double* tota
 int bf_version(void) { return BF_VERSION_MAJOR * 1000 + BF_VERSION_MINOR; }
 
 int bf_set_sample_counter(const uint32_t* d_counter) {
-    g_sample_counter = d_counter;
+    g_sample_counter[current_device_slot()] = d_counter;
     return 0;
 }
+
+const uint32_t* bf_get_sample_counter(void) { return g_sample_counter[current_device_slot()]; }
 
 const char* bf_last_error(void) { return g_err; }
 
@@ -261,13 +272,17 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
     char* ws = reinterpret_cast<char*>(d_workspace);
 
     // small M: one fused kernel (epsilon in registers -> MFMA operand), no sampled weights in memory
-    static const bool fused_off = getenv("BF_NO_FUSED_SMALL") != nullptr;
+#ifdef BF_DEV
+    static const bool fused_off = getenv("BF_NO_FUSED_SMALL") != nullptr;  // developer A/B of the small-M path
+#else
+    constexpr bool fused_off = false;
+#endif
     if (!fused_off && bf_fused_small_supported(x_dtype, y_dtype, compute_dtype, x_sample_stride, d_x, weight, bias, S, M, N, K)) {
         for (int i = 0; i < (bias ? 2 : 1); ++i)
             if ((i ? bias : weight)->prior.kind == BF_PRIOR_GAUSSIAN &&
                 (!(i ? bias : weight)->prior.d_mu || !(i ? bias : weight)->prior.d_rho))
                 BF_FAIL("bf_linear_fwd: gaussian prior needs d_mu/d_rho");
-        ProfScope prof(BF_PROF_GEMM, 2.0 * S * M * (double)N * K, (hipStream_t)stream);
+        ProfScope prof(BF_PROF_FUSED_SMALL, 2.0 * S * M * (double)N * K, (hipStream_t)stream);
         int rc = bf_launch_fused_small(d_x, x_dtype, x_sample_stride, weight, bias, d_y, compute_dtype, S, M, N, K, seed,
                                        sample_base, reinterpret_cast<double*>(ws + op), (hipStream_t)stream);
         if (rc) return rc;

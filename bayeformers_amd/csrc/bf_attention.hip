@@ -218,10 +218,14 @@ int bf_launch_attention_fwd(const void* d_q, const void* d_k, const void* d_v, c
     p.T = T;
     p.H = H;
     p.scale_log2e = scaling * 1.4426950408889634f;
+#ifdef BF_DEV
     {
         const char* e = getenv("BF_ATTN_ABLATE");
         p.ablate = e ? atoi(e) : 0;
     }
+#else
+    p.ablate = 0;
+#endif
     const dim3 grid(T / TQ, H, B);
     if (dtype == BF_DT_BF16) hipLaunchKernelGGL(attention_fwd_kernel<__bf16>, grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(attention_fwd_kernel<_Float16>, grid, dim3(256), 0, stream, p);

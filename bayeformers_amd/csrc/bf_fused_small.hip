@@ -17,12 +17,11 @@
 #include <stdlib.h>
 
 #include "bf_common.h"
+#include "bf_device.h"
 #include "bf_philox.h"
 
 namespace {
 
-constexpr float kLogSqrt2Pi = 0.91893853320467274178f;
-constexpr float kLn2 = 0.69314718055994531f;
 
 struct FusedParams {
     const void* x;
@@ -62,37 +61,6 @@ struct Mf<_Float16> {
     }
 };
 
-__device__ __forceinline__ float exp_fast(float x) {
-    const float y = x * 1.4426950408889634f;
-    const float yh = __builtin_rintf(y);
-    float r = fmaf(x, 1.4426950408889634f, -yh);
-    r = fmaf(x, 1.9259629911266175e-8f, r);
-    return __builtin_ldexpf(__builtin_amdgcn_exp2f(r), (int)yh);
-}
-__device__ __forceinline__ float softplus_fast(float rho) {
-    const float t = exp_fast(fminf(rho, 21.0f));
-    const float ser = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, fmaf(t, -1.0f / 6.0f, 0.2f), -0.25f), 1.0f / 3.0f), -0.5f), 1.0f);
-    const float u = 1.0f + t;
-    const float big = fmaf(kLn2, __builtin_amdgcn_logf(u), (t - (u - 1.0f)) * __builtin_amdgcn_rcpf(u));
-    const float sp = t < 0.03125f ? ser : big;
-    return rho > 20.0f ? rho : sp;
-}
-__device__ __forceinline__ float log_fast(float x) { return kLn2 * __builtin_amdgcn_logf(x); }
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true);
-    return v + __builtin_bit_cast(float, t);
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    v = dpp_add<0x111, 0xf>(v);
-    v = dpp_add<0x112, 0xf>(v);
-    v = dpp_add<0x114, 0xf>(v);
-    v = dpp_add<0x118, 0xf>(v);
-    v = dpp_add<0x142, 0xa>(v);
-    v = dpp_add<0x143, 0xc>(v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
 
 // log prior of one sampled value (natural log), prior kind is wave-uniform
 __device__ __forceinline__ float prior_term(int kind, float w, float a1, float b1, float a2, float b2, float pmu,
@@ -312,21 +280,10 @@ template <typename T, typename XT>
 int launch_mb(const FusedParams& p, int MB, dim3 grid, hipStream_t stream) {
     // K is split over the waves of a block: 8 waves when that still leaves >= 2 slices per wave and the grid alone
     // would not give each SIMD ~4 waves
-    static const char* nw_env = getenv("BF_FUSED_NW");
     const int nkb = p.K / 32;
-    int nw = (nkb >= 16 && (long long)grid.x * grid.y < 2048) ? 8 : 4;
-    if (nw_env) nw = atoi(nw_env) == 8 ? 8 : 4;
+    const int nw = (nkb >= 16 && (long long)grid.x * grid.y < 2048) ? 8 : 4;
     if (nw == 8) return launch_nw<T, XT, 8>(p, MB, grid, stream);
     return launch_nw<T, XT, 4>(p, MB, grid, stream);
-}
-
-template <typename T, typename XT>
-int launch_mb_unused(const FusedParams& p, int MB, dim3 grid, hipStream_t stream) {
-    switch (MB) {
-        default: break;
-    }
-    BF_HIP_CHECK(hipGetLastError());
-    return 0;
 }
 
 void mixture_consts(const bf_prior_t& pr, float& a1, float& b1, float& a2, float& b2) {

@@ -7,23 +7,10 @@
 // store, statistics by the two-pass formula on those registers (mean, then sum of squared deviations), wave
 // reductions on the DPP network.  Algorithmic bytes per row: N * (2 reads + 1 write) * sizeof(T).
 #include "bf_common.h"
+#include "bf_device.h"
 
 namespace {
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true);
-    return v + __builtin_bit_cast(float, t);
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    v = dpp_add<0x111, 0xf>(v);
-    v = dpp_add<0x112, 0xf>(v);
-    v = dpp_add<0x114, 0xf>(v);
-    v = dpp_add<0x118, 0xf>(v);
-    v = dpp_add<0x142, 0xa>(v);
-    v = dpp_add<0x143, 0xc>(v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
 
 // 8 consecutive elements <-> 8 floats
 __device__ __forceinline__ void load8(const __bf16* p, float (&v)[8]) {

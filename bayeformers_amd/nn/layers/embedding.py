@@ -47,8 +47,9 @@ class _EmbeddingFn(torch.autograd.Function):
             dmu, drho = ops.embedding_backward(ids, grad, layer.weight.mu, layer.weight.rho, ctx.S, ctx.seed,
                                                ctx.base, 2 * layer.layer_id, ctx.needs_input_grad[1],
                                                ctx.needs_input_grad[2])
-        if dmu is not None and layer.padding_idx is not None:
-            dmu[layer.padding_idx].zero_()  # nn.Embedding: the padding row receives no gradient
+        if layer.padding_idx is not None:  # nn.Embedding: the padding row receives no gradient (mu frozen or not)
+            if dmu is not None:
+                dmu[layer.padding_idx].zero_()
             if drho is not None:
                 drho[layer.padding_idx].zero_()
         return None, dmu, drho, None, None, None, None, None

@@ -131,8 +131,8 @@ class Linear(KernelLayer):
         rho_b = self.bias.rho if isinstance(self.bias, Gaussian) else None
         # the fused activation has no backward: when a gradient may be needed it runs as a separate op
         want_act = self.activation == "gelu"
-        need_grad = torch.is_grad_enabled() and (x2.requires_grad or self.weight.rho.requires_grad or
-                                                 self.weight.mu.requires_grad)
+        need_grad = torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (x2, self.weight.mu, self.weight.rho, mu_b, rho_b))
         rows_per_sample = x2.shape[0] // S
         small = rows_per_sample <= 64 and self.in_features % 32 == 0 and x2.dtype != torch.float64
         if small != self._small_m:
@@ -173,7 +173,9 @@ class Linear(KernelLayer):
             M = x2.shape[0] // S
             y = ops.gemm_nt_layers(x2, entry[1], entry[2], len(run), S, M, self.out_features, self.in_features,
                                    M * self.in_features, x2.dtype)
-            cached = (ident, y)
+            # the input tensor is kept with the outputs: its storage cannot be recycled (same address, shape and
+            # version) for another activation while the entry is alive, e.g. when a block runs twice in one forward
+            cached = (ident, y, x2)
             ctx.shared_out[id(run[0])] = cached
         return cached[1][run.index(self)].view(-1, self.out_features)
 

@@ -231,7 +231,7 @@ def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_
     K, N = layer.in_features, layer.out_features
     M = x.shape[0] // S
     has_bias = not isinstance(layer.bias, NoneParameter)
-    xg = x if x.dtype == cdt else x.to(cdt)
+    xg = (x if x.dtype == cdt else x.to(cdt)).contiguous()
     dy = grad_y.reshape(S * M, N)
     dy = (dy if dy.dtype == cdt else dy.to(cdt)).contiguous()
     dev = x.device

@@ -7,8 +7,6 @@ and the next unused Monte-Carlo sample index.  Every forward of a bnn.Model (or 
 consecutive sample indices; all layers inside one forward share them, which is what makes results independent
 of kernel tiling, of S-batching and of how samples are sharded over GPUs.
 """
-import threading
-
 import torch
 
 DEFAULT_SEED = 0x5EED
@@ -20,7 +18,11 @@ _DTYPES = {
 }
 
 
-class _State(threading.local):
+class _State:
+    """Process-wide (NOT thread-local): autograd runs backward nodes on its own thread, which must see the same seed,
+    device counter and running forward as the thread that ran the forward — like the reference's use of torch's
+    global generator.  One process drives one GPU (one rank per device), so there is nothing to keep apart."""
+
     def __init__(self):
         self.seed = DEFAULT_SEED
         self.next_sample = 0
@@ -114,18 +116,23 @@ def counter_snapshot():
 
 
 class counter_override:
-    """Temporarily point the kernels at a saved counter value (used by backward passes)."""
+    """Temporarily point the kernels at a saved counter value (used by backward passes, which run on autograd's own
+    thread).  Restores exactly the pointer that was set before, read back from the library."""
 
     def __init__(self, snapshot):
         self.snapshot = snapshot
+        self.prev = None
 
     def __enter__(self):
         if self.snapshot is not None:
             from . import _C
-            _C.check(_C.lib().bf_set_sample_counter(self.snapshot.data_ptr()), "bf_set_sample_counter")
+            lib = _C.lib()
+            with torch.cuda.device(self.snapshot.device):
+                self.prev = lib.bf_get_sample_counter()
+                _C.check(lib.bf_set_sample_counter(self.snapshot.data_ptr()), "bf_set_sample_counter")
 
     def __exit__(self, *exc):
         if self.snapshot is not None:
             from . import _C
-            cur = STATE.device_counter
-            _C.check(_C.lib().bf_set_sample_counter(cur.data_ptr() if cur is not None else None), "bf_set_sample_counter")
+            with torch.cuda.device(self.snapshot.device):
+                _C.check(_C.lib().bf_set_sample_counter(self.prev), "bf_set_sample_counter")

@@ -3,6 +3,11 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bert_base|linear768|linear768_m32|mlp]
 
+With --gpus N > 1 and no torch.distributed environment (WORLD_SIZE unset) this process only LAUNCHES the job: it starts
+`python -m torch.distributed.run --nproc-per-node N ... bench.py <same flags>` as a child process (it never touches a
+GPU itself), relays the child's output and exits with its return code.  A rank refuses to run (exit 2) when the world
+size it finds differs from --gpus, so a line with `"n_gpus": N` always comes from N ranks.
+
 One step = one pass of the hot path over one synthetic batch: S Monte-Carlo samples of the converted model
 (sampling + log-probs + MFMA GEMMs for every Bayesian linear, everything else of the wrapped model in torch),
 the mean over samples, the NLL on the mean logits and the ELBO scalar read back to the host
@@ -43,6 +48,9 @@ def parse():
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / process-group check only: every rank joins the group (RCCL on GPUs, gloo without), "
+                         "one all-reduce, rank 0 prints a JSON line with n_gpus; no kernels run")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="capture the step in a HIP graph (device-resident sample counter); auto = on for the "
                          "launch-bound single-layer / MLP workloads")
@@ -163,6 +171,7 @@ def make_bert_large_qa(device, S, dtype):
                 "sample": f"1 MC sample (fwd + log-probs) of the same BERT-large B=16 L=384 batch, torch-CPU fp32, {dt:.1f}s"}
 
     cfgd = {"workload": "to_bayesian(BERT-large QA, delta=0.05, freeze=True) fwd+ELBO", "samples_per_gpu": S, "batch": B,
+            "allreduce_values": 2 * B * L + 2,
             "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "gelu_fused_into_gemm": n_fused,
             "residual_layernorm_fused": n_ln, "qkv_in_one_launch": n_qkv,
             "attention_kernel": bool(attn)}
@@ -304,7 +313,7 @@ def measure_traffic(args):
             vals = []
             for f in files:
                 for r in csv.DictReader(open(f)):
-                    if "gemm256" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    if "gemm256_sched" in r["Kernel_Name"] and r["Counter_Name"] == counter:
                         vals.append(float(r["Counter_Value"]))
             if not vals:
                 return None
@@ -317,17 +326,71 @@ def measure_traffic(args):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def launch_ranks(args) -> int:
+    """--gpus N without a torch.distributed environment: run the N ranks as a CHILD process tree (one rank per GPU,
+    torch.distributed.run) and relay its output.  This process does not initialise a GPU — it only counts them."""
+    import socket
+    import subprocess
+
+    if not args.dry_run and torch.cuda.device_count() < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def dry_run(args, world, rank, device):
+    """Process-group check: one all-reduce over all ranks, rank 0 reports how many took part."""
+    t = torch.ones(1, dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "value": None, "n_gpus": world, "ranks_counted": int(t.item()),
+                          "backend": dist.get_backend() if world > 1 else None, "steps": 0, "warmup": 0}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # never report an N-rank flag over a different number of ranks
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
+              f"`python bench.py --gpus {args.gpus}` or torch.distributed.run --nproc-per-node {args.gpus}",
+              file=sys.stderr)
+        sys.exit(2)
+    have_gpu = torch.cuda.is_available()
+    if args.dry_run and not have_gpu:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+        return dry_run(args, world, rank, torch.device("cpu"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            print(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(2)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    if args.dry_run:
+        return dry_run(args, world, rank, device)
 
     import bayeformers_amd as bf
     from bayeformers_amd import _C
@@ -406,11 +469,27 @@ def main():
     torch.cuda.synchronize()
     lib.bf_profile_enable(0)
     prof = {}
-    for kind, name in ((_C.BF_PROF_GEMM, "gemm"), (_C.BF_PROF_SAMPLE, "sample")):
+    for kind, name in ((_C.BF_PROF_GEMM, "gemm"), (_C.BF_PROF_SAMPLE, "sample"), (_C.BF_PROF_FUSED_SMALL, "fused")):
         n, ms, work = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
         _C.check(lib.bf_profile_read(kind, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work)), "bf_profile_read")
         prof[name] = (n.value, ms.value, work.value)
     lib.bf_profile_reset()
+
+    # the step's one collective on its own: the packed [sum of outputs | sum log_prior | sum lvp] fp64 buffer
+    allreduce_ms = None
+    if world > 1:
+        n_vals = int(cfgd.get("allreduce_values", 66))
+        buf = torch.zeros(n_vals, dtype=torch.float64, device=device)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        allreduce_ms = e0.elapsed_time(e1) / 50
 
     if rank == 0:
         gn, gms, gflop = prof["gemm"]
@@ -422,12 +501,25 @@ def main():
             per_read = 16 if isinstance(plan.layers[0].weight_prior, Gaussian) else 8
             esz = 4 if dtype == "fp32" else 2
             sbytes = float(plan.scalars) * (per_read + S * esz) * prof_steps
+        fn, fms, fflop = prof["fused"]
+        fused = {"kernel": "fused_small_kernel (sampling + log-probs + MFMA in one launch, M <= 64)", "bound": "latency",
+                 "launches_per_step": fn // prof_steps, "avg_launch_us": round(1e3 * fms / max(fn, 1), 2),
+                 "flop_per_step": fflop / prof_steps} if fn else None
+        if gn == 0 and fn:
+            # small-M workloads: the only matrix kernel of the step is the single fused launch, a latency-bound kernel
+            # (a few microseconds of work); the MFMA rate is reported for completeness, it is not what bounds it
+            gn, gms, gflop = fn, fms, fflop
+            kernel, bound, fused = fused["kernel"], "latency", None
+        else:
+            kernel = "gemm256_sched_kernel (sampled-weight GEMM; mean over the step's tiled-GEMM launches)"
+            bound = "mfma"
         tflops = gflop / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "gemm256_persist_kernel (sampled-weight GEMM; mean over all Bayesian linears of the step)",
+        roofline = {"bound": bound, "kernel": kernel,
                     "achieved": round(tflops, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tflops / PEAK_TFLOPS, 4), "traffic": None,
                     "launches_per_step": gn // prof_steps, "avg_launch_us": round(1e3 * gms / max(gn, 1), 2),
                     "flop_per_step": gflop / prof_steps, "gemm_ms_per_step": round(gms / prof_steps, 3),
+                    "fused_small_kernel": fused,
                     "sample_kernel": {"bound": "hbm", "achieved": round(sbytes / (sms * 1e-3) / 1e9, 1) if sms > 0 else 0.0,
                                       "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                       "frac": round(sbytes / (sms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if sms > 0 else 0.0,
@@ -444,10 +536,13 @@ def main():
                                               "hbm_fetch": round(tr["fetch_bytes"]), "hbm_write": round(tr["write_bytes"]),
                                               "algorithmic": alg_gemm_bytes(bmodel, cfgd, S, dtype)}
         total_samples = S * world * args.steps
-        cfgd.update({"parallelism": f"mc-sample-shard x{world}", "last_elbo": last, "hip_graph": bool(use_graph)})
+        n_ranks = dist.get_world_size() if world > 1 else 1
+        cfgd.update({"parallelism": f"mc-sample-shard x{n_ranks}", "last_elbo": last, "hip_graph": bool(use_graph),
+                     "samples_total": total_samples, "samples_per_step": S * n_ranks,
+                     "allreduce_ms_per_step": round(allreduce_ms, 4) if allreduce_ms is not None else None})
         metric = "MC-samples/sec (fwd+ELBO+backward+Adam)" if args.workload.endswith("_train") else "MC-samples/sec (fwd+ELBO)"
         out = {"metric": metric, "value": round(total_samples / dt, 3), "unit": "MC-samples/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+               "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": cfgd, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)

@@ -60,11 +60,14 @@ typedef struct bf_tensor {
 int bf_version(void);
 const char* bf_last_error(void);
 
-/* Device-resident Monte-Carlo sample counter (optional, process-wide; NULL = off, the default).  While set, every
- * kernel adds the uint32 at d_counter to its `sample_base` argument.  This is what makes a whole step capturable in
- * a hipGraph: the graph bakes the host-side sample_base, and a captured one-element `counter += S` moves every
- * replay on to fresh epsilon. */
+/* Device-resident Monte-Carlo sample counter (optional; one per HIP device, set for / read from the calling
+ * thread's current device; NULL = off, the default).  While set, every kernel launched on that device adds the
+ * uint32 at d_counter to its `sample_base` argument.  This is what makes a whole step capturable in a hipGraph: the
+ * graph bakes the host-side sample_base, and a captured one-element `counter += S` moves every replay on to fresh
+ * epsilon.  bf_get_sample_counter returns the pointer currently set (so that a caller that points the kernels at a
+ * saved counter for a backward pass can restore exactly what was there, from any thread). */
 int bf_set_sample_counter(const uint32_t* d_counter);
+const uint32_t* bf_get_sample_counter(void);
 
 /* Number of compute units / name of the current device (diagnostics for bench.py). */
 int bf_device_info(char* name, size_t name_len, int* n_cu, int* wave_size);
@@ -221,10 +224,11 @@ int bf_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const fl
  * While enabled, every sampling launch (kind BF_PROF_SAMPLE) and every GEMM launch (BF_PROF_GEMM) made through
  * this library is bracketed by two events; bf_profile_read() synchronises them and returns, per kind, the number
  * of launches, the summed kernel time and the summed ALGORITHMIC work:
- *   BF_PROF_GEMM   work = 2*S*M*N*K flop;
+ *   BF_PROF_GEMM   work = 2*S*M*N*K flop (the tiled MFMA GEMM kernels);
+ *   BF_PROF_FUSED_SMALL  work = 2*S*M*N*K flop (the single fused sampling+MFMA kernel of bf_linear_fwd, M <= 64);
  *   BF_PROF_SAMPLE work = bytes: (8 | 16 with a Gaussian prior) per scalar read + S * sizeof(out) per scalar written
  *                  (0 for bf_sample_logprob_table launches: the caller knows the table's totals). */
-enum { BF_PROF_SAMPLE = 0, BF_PROF_GEMM = 1 };
+enum { BF_PROF_SAMPLE = 0, BF_PROF_GEMM = 1, BF_PROF_FUSED_SMALL = 2 };
 int bf_profile_enable(int on);
 int bf_profile_reset(void);
 int bf_profile_read(int kind, uint64_t* launches, double* total_ms, double* total_work);

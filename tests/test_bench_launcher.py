@@ -1,0 +1,44 @@
+"""bench.py --gpus N must run N ranks or fail: the launcher starts torch.distributed.run as a child process (the
+parent never touches a GPU), rank 0 reports the size of the process group it actually joined, and a rank whose
+WORLD_SIZE differs from --gpus exits non-zero.  Runs on CPU: --dry-run joins the group over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(args, env_extra=None):
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")  # gloo even on a GPU box
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=300)
+
+
+def last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert lines, stdout
+    return json.loads(lines[-1])
+
+
+def test_gpus_2_launches_two_ranks():
+    r = run(["--gpus", "2", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = last_json(r.stdout)
+    assert out["n_gpus"] == 2 and out["ranks_counted"] == 2 and out["backend"] == "gloo"
+
+
+def test_single_rank_needs_no_launcher():
+    r = run(["--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert last_json(r.stdout)["n_gpus"] == 1
+
+
+def test_world_size_mismatch_is_an_error():
+    # a 1-rank environment under an N-rank flag must not print a line at all
+    r = run(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -248,6 +248,38 @@ def test_hip_graph_replay_draws_fresh_samples():
     assert not torch.equal(got[0], got[1])
 
 
+def test_device_counter_survives_backward():
+    """Device-counter mode with a backward pass in between (autograd runs it on its own thread): the counter the
+    kernels add must still be the live one afterwards, so step k draws the eps of eager step k — not step 0's again."""
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.ReLU(), torch.nn.Linear(96, 10))
+    bmodel = bf.to_bayesian(net, delta=0.05).cuda()
+    x = torch.randn(16, 64, device="cuda")
+
+    def step(grad):
+        with torch.set_grad_enabled(grad):
+            raw, mean, lp, lq = sample_bayesian(bmodel, x, 4)
+            out = torch.cat([mean[0].double().reshape(-1), lp.reshape(1), lq.reshape(1)])
+            if grad:
+                mean[0].float().sum().backward()
+                for p in bmodel.parameters():
+                    p.grad = None
+        return out.detach().clone()
+
+    bf.manual_seed(SEED)
+    eager = [step(False) for _ in range(3)]
+    try:
+        bf.use_device_counter(True)
+        bf.manual_seed(SEED)
+        got = [step(True), step(True), step(False)]      # forward+backward, forward+backward, forward
+        torch.cuda.synchronize()
+    finally:
+        bf.use_device_counter(False)
+    for k in range(3):
+        assert torch.equal(got[k], eager[k]), k
+    assert not torch.equal(got[0], got[1]) and not torch.equal(got[1], got[2])
+
+
 def test_rccl_single_rank_collective_path():
     """The sharded harness through a real RCCL process group (world size 1: one GPU here): exercises backend init,
     the packed fp64 all-reduce and the all-gather on device tensors, and must equal the non-distributed result."""
