@@ -59,6 +59,8 @@ SYMBOLS = {
     "bf_gemm_schedule": (_sz, [_i, _i, _i, _i, _i, _vp, _sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "bf_linear_fwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "bf_linear_fwd": (_i, [_vp, _i, _i64, _tp, _tp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u32, _vp, _vp, _sz, _vp]),
+    "bf_linear_fwd_ws_workspace_bytes": (_sz, [_i, _i]),
+    "bf_linear_fwd_ws": (_i, [_vp, _i, _i64, _tp, _tp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u32, _i, _vp, _vp, _sz, _vp]),
     "bf_linear_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "bf_linear_bwd": (_i, [_vp, _i64, _vp, _i, _tp, _tp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u64, _u32, _vp, _sz, _vp]),
     "bf_kl_grad": (_i, [_tp, _i, _u64, _u32, _vp, _vp, _vp, _vp]),
@@ -73,7 +75,7 @@ SYMBOLS = {
     "bf_profile_read": (_i, [_i, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
                              ctypes.POINTER(ctypes.c_double)]),
 }
-BF_PROF_SAMPLE, BF_PROF_GEMM, BF_PROF_FUSED_SMALL = 0, 1, 2
+BF_PROF_SAMPLE, BF_PROF_GEMM, BF_PROF_FUSED_SMALL, BF_PROF_FUSED_WS = 0, 1, 2, 3
 BF_ACT_NONE, BF_ACT_GELU = 0, 1
 
 _lib = None

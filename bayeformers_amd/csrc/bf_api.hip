@@ -314,6 +314,31 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
                              (hipStream_t)stream);
 }
 
+size_t bf_linear_fwd_ws_workspace_bytes(int S, int N) {
+    if (S < 1 || N < 1) return 0;
+    return bf_align_up(bf_fused_ws_partial_rows(N) * (size_t)S * 2 * sizeof(double), 256);
+}
+
+int bf_linear_fwd_ws(const void* d_x, int x_dtype, int64_t x_sample_stride, const bf_tensor_t* weight,
+                     const bf_tensor_t* bias, void* d_y, int y_dtype, int compute_dtype, int S, int M, int N, int K,
+                     uint64_t seed, uint32_t sample_base, int row_shares, double* d_logprob_out, void* d_workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (!weight || !d_x || !d_y || !d_logprob_out) BF_FAIL("bf_linear_fwd_ws: NULL argument");
+    if (weight->n != (uint64_t)N * (uint64_t)K) BF_FAIL("bf_linear_fwd_ws: weight.n != N*K");
+    if (bias && bias->n != (uint64_t)N) BF_FAIL("bf_linear_fwd_ws: bias.n != N");
+    if (!bf_fused_ws_supported(x_dtype, y_dtype, compute_dtype, x_sample_stride, d_x, weight, bias, S, M, N, K))
+        BF_FAIL("bf_linear_fwd_ws: unsupported problem (needs 16-bit x/y of the compute dtype, N %% 64 == 0, "
+                "K %% 64 == 0, K <= 768): S=%d M=%d N=%d K=%d", S, M, N, K);
+    if (!d_workspace || workspace_bytes < bf_linear_fwd_ws_workspace_bytes(S, N))
+        BF_FAIL("bf_linear_fwd_ws: workspace too small");
+    ProfScope prof(BF_PROF_FUSED_WS, 2.0 * S * M * (double)N * K, (hipStream_t)stream);
+    int rc = bf_launch_fused_ws(d_x, x_sample_stride, weight, bias, d_y, compute_dtype, S, M, N, K, seed, sample_base,
+                                row_shares, reinterpret_cast<double*>(d_workspace), (hipStream_t)stream);
+    if (rc) return rc;
+    return bf_launch_reduce_partials(reinterpret_cast<const double*>(d_workspace),
+                                     (uint32_t)bf_fused_ws_partial_rows(N), S, d_logprob_out, (hipStream_t)stream);
+}
+
 int bf_kl_grad(const bf_tensor_t* tensor, int S, uint64_t seed, uint32_t sample_base, const double* d_g,
                float* d_dmu, float* d_drho, void* stream) {
     return bf_launch_kl_grad(tensor, S, seed, sample_base, d_g, d_dmu, d_drho, (hipStream_t)stream);

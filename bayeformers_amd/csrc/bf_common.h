@@ -111,6 +111,12 @@ size_t bf_fused_small_partial_rows(int N);
 int bf_launch_fused_small(const void* d_x, int x_dtype, int64_t x_sample_stride, const bf_tensor_t* weight,
                           const bf_tensor_t* bias, void* d_y, int compute_dtype, int S, int M, int N, int K, uint64_t seed,
                           uint32_t sample_base, double* d_partials, hipStream_t stream);
+bool bf_fused_ws_supported(int x_dtype, int y_dtype, int compute_dtype, int64_t x_sample_stride, const void* d_x,
+                           const bf_tensor_t* weight, const bf_tensor_t* bias, int S, int M, int N, int K);
+size_t bf_fused_ws_partial_rows(int N);
+int bf_launch_fused_ws(const void* d_x, int64_t x_sample_stride, const bf_tensor_t* weight, const bf_tensor_t* bias,
+                       void* d_y, int compute_dtype, int S, int M, int N, int K, uint64_t seed, uint32_t sample_base,
+                       int msplit, double* d_partials, hipStream_t stream);
 int bf_launch_kl_grad(const bf_tensor_t* t, int S, uint64_t seed, uint32_t sample_base, const double* d_g,
                       float* d_dmu, float* d_drho, hipStream_t stream);
 int bf_launch_embedding_fwd(const long long* d_ids, const float* d_mu, const float* d_rho, void* d_out, int out_dtype,

@@ -31,6 +31,14 @@ class KernelLayer(Module):
             self._sync_logprobs()
         return super(KernelLayer, self).__getattr__(name)
 
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        """state_dict() reads `_parameters` directly: refresh the two log-prob scalars first, so that a checkpoint
+        holds the values of the last forward like the reference's does (layers/linear.py:99-102 assign them eagerly;
+        /root/reference/examples/bert_glue.py:303-309 saves them)."""
+        if self.__dict__.get("_lp_dirty", False):
+            self._sync_logprobs()
+        super(KernelLayer, self)._save_to_state_dict(destination, prefix, keep_vars)
+
     def _sync_logprobs(self) -> None:
         self.__dict__["_lp_dirty"] = False
         v = self._lp_view.mean(0).to(torch.float32)

@@ -186,6 +186,33 @@ def linear_forward(layer, x: Tensor, S: int, seed: int, sample_base: int, lp_out
     return y
 
 
+def linear_forward_ws(layer, x: Tensor, S: int, seed: int, sample_base: int, lp_out: Tensor, row_shares: int = 0) -> Tensor:
+    """Linear.forward for S samples in ONE launch, weight-stationary (bf_linear_fwd_ws): the measured alternative to
+    sampling launch + GEMM for large M.  Same arguments and results as linear_forward; 16-bit x only."""
+    from .nn.parameters.base import NoneParameter
+
+    _require_device(x, "input")
+    K, N = layer.in_features, layer.out_features
+    x = x if x.is_contiguous() else x.contiguous()
+    M = x.numel() // K // S
+    cdt = layer.compute_dtype or bfr.get_compute_dtype()
+    has_bias = not isinstance(layer.bias, NoneParameter)
+    w, b = _C.bf_tensor_t(), _C.bf_tensor_t()
+    ok = fill_tensor(w, layer.weight, layer.weight_prior, 2 * layer.layer_id)
+    if has_bias:
+        ok = fill_tensor(b, layer.bias, layer.bias_prior, 2 * layer.layer_id + 1) and ok
+    if not ok:
+        raise _C.BayeFormersAMDError("linear_forward_ws: user-defined priors are not supported")
+    lib = _C.lib()
+    y = torch.empty((S * M, N), dtype=x.dtype, device=x.device)
+    ws = workspace(x.device, lib.bf_linear_fwd_ws_workspace_bytes(S, N))
+    _C.check(lib.bf_linear_fwd_ws(x.data_ptr(), _TORCH2BF[x.dtype], M * K, ctypes.byref(w),
+                                  ctypes.byref(b) if has_bias else None, y.data_ptr(), _TORCH2BF[x.dtype],
+                                  _TORCH2BF[cdt], S, M, N, K, seed, sample_base & 0xFFFFFFFF, int(row_shares),
+                                  lp_out.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr()), "bf_linear_fwd_ws")
+    return y
+
+
 def _linear_forward_generic(layer, x, S, M, N, K, seed, sample_base, lp_out, cdt, has_bias):
     """User-defined prior (any Parameter with log_prob): the kernels sample W_s/b_s in fp32 and produce log q;
     the prior's own log_prob is then called on each sample, as the reference does (layers/linear.py:99-100)."""

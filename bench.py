@@ -61,12 +61,14 @@ class Workload:
     """name, S (per GPU), dtype, step() -> python float (the ELBO), config dict, cpu_baseline() -> dict."""
 
 
-def make_bert(device, S, dtype, train=False):
+def build_bert(device, dtype):
+    """The benchmarked BERT-base model, exactly as timed: conversion, the four rewrites of the callers around the
+    Bayesian layers, bf16, and the synthetic batch.  tests/test_gpu_models.py builds its parity model with this
+    function, so what is benchmarked is what is compared with the reference's outputs (tests/golden/bert_c3.npz)."""
     import bayeformers_amd as bf
-    from bayeformers_amd.sampling import elbo, sample_bayesian
     from transformers import BertConfig, BertForSequenceClassification
 
-    B, L, n_batches = 32, 128, 2105  # SST-2: 67,349 train sentences / 32
+    B, L = 32, 128
     torch.manual_seed(0)
     cfg = BertConfig()
     model = BertForSequenceClassification(cfg).eval()
@@ -81,6 +83,16 @@ def make_bert(device, S, dtype, train=False):
     ids = torch.randint(0, cfg.vocab_size, (B, L), generator=g)
     labels = torch.randint(0, 2, (B,), generator=g)
     inputs = {"input_ids": ids.to(device), "attention_mask": torch.ones(B, L, dtype=torch.long, device=device)}
+    info = {"gelu_fused_into_gemm": n_fused, "residual_layernorm_fused": n_ln, "qkv_in_one_launch": n_qkv,
+            "attention_kernel": bool(attn)}
+    return bmodel, model, inputs, ids, labels, info
+
+
+def make_bert(device, S, dtype, train=False):
+    from bayeformers_amd.sampling import elbo, sample_bayesian
+
+    B, L, n_batches = 32, 128, 2105  # SST-2: 67,349 train sentences / 32
+    bmodel, model, inputs, ids, labels, info = build_bert(device, dtype)
     labels_d = labels.to(device)
 
     def step():
@@ -122,10 +134,8 @@ def make_bert(device, S, dtype, train=False):
 
     cfgd = {"workload": "to_bayesian(BERT-base seq-cls, delta=0.05, freeze=True) " +
                         ("training step: fwd+ELBO+backward+Adam" if train else "fwd+ELBO"), "samples_per_gpu": S,
-            "batch": B, "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "bayesian_scalars": 85609730,
-            "gelu_fused_into_gemm": n_fused,
-            "residual_layernorm_fused": n_ln, "qkv_in_one_launch": n_qkv,
-            "attention_kernel": bool(attn)}
+            "batch": B, "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "bayesian_scalars": 85609730}
+    cfgd.update(info)
     return step, cpu_baseline, cfgd, bmodel
 
 

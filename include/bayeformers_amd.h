@@ -155,6 +155,19 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
                   uint64_t seed, uint32_t sample_base, double* d_logprob_out, void* d_workspace,
                   size_t workspace_bytes, void* stream);
 
+/* The same operation as bf_linear_fwd in ONE launch for LARGE M, weight-stationary: a workgroup owns (sample, strip
+ * of 64 output features, a share of the rows), draws the strip's 64 x K sampled weights once into LDS — they never
+ * exist in HBM — accumulates the log-probs exactly once (row share 0), and streams its rows of x against the resident
+ * strip (csrc/bf_fused_ws.hip).  Needs 16-bit x / y of the compute dtype, N % 64 == 0, K % 64 == 0, K <= 768.
+ * row_shares: workgroups per (sample, strip) along M (each regenerates the strip); 0 = enough to fill the chip.
+ * This is the measured alternative to sampling launch + 256-wide GEMM: it is NOT what
+ * bnn.Linear dispatches to, because it is slower — four times the LDS-DMA bytes per flop of the 256 x 256 tile. */
+size_t bf_linear_fwd_ws_workspace_bytes(int S, int N);
+int bf_linear_fwd_ws(const void* d_x, int x_dtype, int64_t x_sample_stride, const bf_tensor_t* weight,
+                     const bf_tensor_t* bias, void* d_y, int y_dtype, int compute_dtype, int S, int M, int N, int K,
+                     uint64_t seed, uint32_t sample_base, int row_shares, double* d_logprob_out, void* d_workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* Backward of bf_linear_fwd, reproducing the reference's autograd graph: gradients flow through
  * F.linear(input, mu + eps*softplus(rho), ...) (layers/linear.py:97,104, gaussian.py:100-101) with eps a constant and
  * the two log-prob scalars detached (linear.py:99-102: the KL terms carry no gradient in the reference).
@@ -228,7 +241,7 @@ int bf_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const fl
  *   BF_PROF_FUSED_SMALL  work = 2*S*M*N*K flop (the single fused sampling+MFMA kernel of bf_linear_fwd, M <= 64);
  *   BF_PROF_SAMPLE work = bytes: (8 | 16 with a Gaussian prior) per scalar read + S * sizeof(out) per scalar written
  *                  (0 for bf_sample_logprob_table launches: the caller knows the table's totals). */
-enum { BF_PROF_SAMPLE = 0, BF_PROF_GEMM = 1, BF_PROF_FUSED_SMALL = 2 };
+enum { BF_PROF_SAMPLE = 0, BF_PROF_GEMM = 1, BF_PROF_FUSED_SMALL = 2, BF_PROF_FUSED_WS = 3 };
 int bf_profile_enable(int on);
 int bf_profile_reset(void);
 int bf_profile_read(int kind, uint64_t* launches, double* total_ms, double* total_work);

@@ -170,7 +170,7 @@ def mlp_case():
 
 
 # ---------------------------------------------------------------------------------------------- C3: BERT
-def bert_case(tiny):
+def bert_case(tiny, samples=None):
     from transformers import BertConfig, BertForSequenceClassification
 
     if tiny:
@@ -180,6 +180,8 @@ def bert_case(tiny):
     else:
         cfg = BertConfig()
         S, B, L = 10, 32, 128
+    if samples is not None:
+        S = samples  # BASELINE config 4: S = 64 global sample indices (8 per GPU x 8 GPUs on the HIP side)
     torch.manual_seed(0)
     model = BertForSequenceClassification(cfg).eval()
     bmodel = ref_to_bayesian(model, delta=0.05, freeze=True).eval()
@@ -284,6 +286,48 @@ def bert_large_qa_case():
             "start_s0": t2n(start[0]), "end_s9": t2n(end[9]), "log_prior": t2n(lp), "lvp": t2n(lq)}
 
 
+def checkpoint_case():
+    """What /root/reference/examples/bert_glue.py:303-309 saves — `b_model.state_dict()` after forwards — for a small
+    converted model, in both prior variants (default scale mixture; MOPED, delta given), together with the
+    reference's forward of that model for S Philox samples.  The HIP path must load these state dicts as they are
+    (duplicated shared-prior keys, the two per-layer log-prob scalars included) and reproduce the outputs."""
+    out = {}
+    for name, kw in (("mixture", {}), ("moped", {"delta": 0.07, "freeze": True})):
+        torch.manual_seed(21)
+        net = torch.nn.Sequential(torch.nn.Linear(48, 96), torch.nn.Tanh(), torch.nn.Linear(96, 32), torch.nn.Tanh(),
+                                  torch.nn.Linear(32, 6, bias=False))
+        torch.manual_seed(22)
+        bmodel = ref_to_bayesian(net, **kw)
+        with torch.no_grad():  # a "trained" posterior: move rho (and mu where it is free) away from the init
+            g = torch.Generator().manual_seed(23)
+            for n_, p_ in bmodel.named_parameters():
+                if n_.endswith("rho") and "prior" not in n_:
+                    p_.add_(0.3 * torch.randn(p_.shape, generator=g))
+                if n_.endswith("mu") and "prior" not in n_ and p_.requires_grad:
+                    p_.add_(0.05 * torch.randn(p_.shape, generator=g))
+        S, B, base = 4, 24, 40
+        torch.manual_seed(24)
+        x = torch.randn(B, 48)
+        clock = {"seed": SEED, "sample": base}
+        inject(bmodel, clock)
+        ys, lps, lqs = [], [], []
+        with torch.no_grad():
+            for s_ in range(S):
+                clock["sample"] = base + s_
+                ys.append(t2n(bmodel(x)))
+                lps.append(float(bmodel.log_prior()))
+                lqs.append(float(bmodel.log_variational_posterior()))
+        sd = bmodel.state_dict()  # taken after the forward of sample base + S - 1, as a training script would
+        out[f"{name}/keys"] = np.array(list(sd.keys()))
+        for k, v in sd.items():
+            out[f"{name}/sd/{k}"] = t2n(v)
+        out[f"{name}/x"], out[f"{name}/y"] = t2n(x), np.stack(ys)
+        out[f"{name}/log_prior"], out[f"{name}/lvp"] = np.array(lps, np.float64), np.array(lqs, np.float64)
+        out[f"{name}/S"], out[f"{name}/base"] = S, base
+        out[f"{name}/requires_grad"] = np.array(sorted(n_ for n_, p_ in bmodel.named_parameters() if p_.requires_grad))
+    return out
+
+
 def conversion_case():
     """to_bayesian / from_frequentist numerics and state-dict layout (bayeformers/__init__.py:19-63)."""
     torch.manual_seed(7)
@@ -308,8 +352,16 @@ def main():
     ap.add_argument("--skip-bert", action="store_true")
     ap.add_argument("--only-grads", action="store_true")
     ap.add_argument("--only-bert-large", action="store_true")
+    ap.add_argument("--only-c4", action="store_true", help="BASELINE config 4: BERT-base, S = 64 (about 6 minutes of CPU)")
+    ap.add_argument("--only-checkpoint", action="store_true")
     args = ap.parse_args()
     torch.set_num_threads(8)
+    if args.only_c4:
+        np.savez_compressed(os.path.join(HERE, "bert_c4.npz"), **bert_case(False, samples=64))
+        return
+    if args.only_checkpoint:
+        np.savez_compressed(os.path.join(HERE, "checkpoint.npz"), **checkpoint_case())
+        return
     if args.only_bert_large:
         np.savez_compressed(os.path.join(HERE, "bert_large_qa_c5.npz"), **bert_large_qa_case())
         return
@@ -321,10 +373,13 @@ def main():
     print("linear cases"); np.savez_compressed(os.path.join(HERE, "linear_cases.npz"), **linear_cases())
     print("grad cases"); np.savez_compressed(os.path.join(HERE, "linear_grads.npz"), **grad_cases())
     print("conversion"); np.savez_compressed(os.path.join(HERE, "conversion.npz"), **conversion_case())
+    print("checkpoint"); np.savez_compressed(os.path.join(HERE, "checkpoint.npz"), **checkpoint_case())
     print("mlp C1"); np.savez_compressed(os.path.join(HERE, "mlp_c1.npz"), **mlp_case())
     print("bert tiny"); np.savez_compressed(os.path.join(HERE, "bert_tiny.npz"), **bert_case(True))
     if not args.skip_bert:
         print("bert base C3 (about a minute of CPU)"); np.savez_compressed(os.path.join(HERE, "bert_c3.npz"), **bert_case(False))
+        print("bert base C4, S = 64 (about 6 minutes of CPU)")
+        np.savez_compressed(os.path.join(HERE, "bert_c4.npz"), **bert_case(False, samples=64))
 
 
 if __name__ == "__main__":

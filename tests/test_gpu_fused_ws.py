@@ -1,0 +1,60 @@
+"""The weight-stationary fused kernel for large M (bf_linear_fwd_ws, NS-1 — the measured alternative of DESIGN.md 4.3)
+against the shipped two-launch path and the oracle: same epsilon (same Philox counters), so the sampled weights are the
+same bits, the outputs agree to bf16 accumulation order, and the log-probs to fp32 summation order."""
+import numpy as np
+import pytest
+import torch
+
+import bayeformers_amd as bf
+import bayeformers_amd.nn as bnn
+from bayeformers_amd import ops
+from oracle import bayes_oracle as bo
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EED
+
+
+@pytest.mark.parametrize("prior", ["mixture", "moped"])
+@pytest.mark.parametrize("S,M,N,K,shares", [(3, 300, 128, 256, 1), (2, 1024, 64, 768, 2), (4, 513, 192, 64, 0)])
+def test_fused_ws_matches_two_launch_path_and_oracle(prior, S, M, N, K, shares):
+    torch.manual_seed(S * 1000 + N)
+    if prior == "mixture":
+        layer = bnn.Linear(K, N)
+    else:
+        layer = bnn.Linear.from_frequentist(torch.nn.Linear(K, N), delta=0.05, freeze=True)
+    layer = layer.cuda()
+    layer.layer_id = 3
+    x = torch.randn(S * M, K, device="cuda").to(torch.bfloat16)
+    lp_a = torch.zeros(S, 2, dtype=torch.float64, device="cuda")
+    lp_b = torch.zeros_like(lp_a)
+    bf.set_compute_dtype("bf16")
+    base = 17
+    ya = ops.linear_forward(layer, x, S, SEED, base, lp_a)
+    yb = ops.linear_forward_ws(layer, x, S, SEED, base, lp_b, shares)
+    torch.cuda.synchronize()
+    # identical sampled weights and k order: the outputs differ by nothing or by bf16 rounding of a different tile split
+    assert (ya.float() - yb.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, ya.float().abs().max().item())
+    np.testing.assert_allclose(lp_b.cpu().numpy(), lp_a.cpu().numpy(), rtol=2e-6)
+    # and against the oracle's fp64 closed forms (sample 0)
+    mu_w, rho_w = layer.weight.mu.detach().cpu(), layer.weight.rho.detach().cpu()
+    mu_b, rho_b = layer.bias.mu.detach().cpu(), layer.bias.rho.detach().cpu()
+    if prior == "mixture":
+        pw = pb = ("mixture", 0.5, 1.0, float(np.float32(np.exp(-6))))
+    else:
+        pw = ("gaussian", layer.weight_prior.mu.detach().cpu(), layer.weight_prior.rho.detach().cpu())
+        pb = ("gaussian", layer.bias_prior.mu.detach().cpu(), layer.bias_prior.rho.detach().cpu())
+    eps_w, eps_b = bo.eps_tensor((N, K), SEED, base, 3, 0), bo.eps_tensor((N,), SEED, base, 3, 1)
+    lp64, lq64 = bo.linear_logprobs_f64(mu_w, rho_w, mu_b, rho_b, eps_w, eps_b, pw, pb)
+    got = lp_b[0].cpu().numpy()
+    assert abs(got[0] - lp64) <= 2e-6 * abs(lp64) and abs(got[1] - lq64) <= 2e-6 * abs(lq64)
+    y_ref, _, _ = bo.linear_forward(x[:M].float().cpu(), mu_w, rho_w, mu_b, rho_b, eps_w, eps_b, pw, pb)
+    err = (yb[:M].float().cpu() - y_ref).abs().max().item()
+    assert err <= 2.0 ** -7 * float(x[:M].float().norm(dim=1).max()) * float((mu_w.abs() + 1).norm(dim=1).max())
+
+
+def test_fused_ws_refuses_what_it_cannot_take():
+    layer = bnn.Linear(1024, 128).cuda()   # K > 768: the strip does not fit beside the x stages in LDS
+    x = torch.randn(256, 1024, device="cuda").to(torch.bfloat16)
+    lp = torch.zeros(1, 2, dtype=torch.float64, device="cuda")
+    with pytest.raises(Exception):
+        ops.linear_forward_ws(layer, x, 1, SEED, 0, lp)

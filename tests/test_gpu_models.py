@@ -109,6 +109,78 @@ def test_bert(golden_dir, fixture, tiny, dtype, tol):
     assert float(elbo(lp, lq, nll.double(), n_batches)) == pytest.approx(ref_loss, rel=1e-3)
 
 
+def test_benchmarked_configuration_matches_reference_c3(golden_dir):
+    """Exactly what bench.py times — bench.build_bert: to_bayesian(BERT-base) with GELU in the GEMM epilogue,
+    residual+LayerNorm fused, Q/K/V in one launch, the attention kernel, bf16 — against the reference's outputs for
+    BASELINE config 3 (per-sample logits, per-sample log-probs, NLL, ELBO to 1e-3 relative)."""
+    import bench
+
+    g = np.load(f"{golden_dir}/bert_c3.npz")
+    S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
+    bf.set_compute_dtype("bf16")
+    bmodel, _, inputs, ids, labels, info = bench.build_bert(torch.device("cuda"), "bf16")
+    assert info == {"gelu_fused_into_gemm": 12, "residual_layernorm_fused": 24, "qkv_in_one_launch": 12,
+                    "attention_kernel": True}
+    assert tuple(ids.shape) == (B, L) and int(ids.sum()) == int(g["ids_sum"]) and np.array_equal(labels.numpy(), g["labels"])
+    assert len(bmodel.fused_children()) == int(g["n_layers"])
+    bf.manual_seed(SEED)
+    with torch.no_grad():
+        raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S)
+        nll = torch.nn.functional.cross_entropy(mean[0].float(), labels.cuda())
+    lps = bmodel.log_prob_samples().cpu().numpy()
+    np.testing.assert_allclose(lps[:, 0], g["log_prior"], rtol=2e-6)
+    np.testing.assert_allclose(lps[:, 1], g["lvp"], rtol=2e-6)
+    logits = raw[0].float().cpu().numpy()
+    tol = 5e-2
+    assert np.abs(logits - g["logits"]).max() < tol * max(1.0, np.abs(g["logits"]).max())
+    assert float(nll) == pytest.approx(float(g["nll"]), rel=tol, abs=tol)
+    n_batches = 2105
+    ref_loss = (g["lvp"].mean() - g["log_prior"].mean()) / n_batches + float(g["nll"])
+    assert float(elbo(lp, lq, nll.double(), n_batches)) == pytest.approx(ref_loss, rel=1e-3)
+
+
+def test_config4_shards_of_8_match_reference_c4(golden_dir):
+    """BASELINE config 4 at size: S = 64 Monte-Carlo samples of BERT-base (B=32, L=128) as 8 shards of 8 — what rank r
+    of 8 runs is `monte_carlo(8, shard=(r, 8))` — executed here one shard after the other on one GPU, in the
+    benchmarked configuration, each slice against the reference's samples [8 r, 8 r + 8) (tests/golden/bert_c4.npz);
+    then the all-reduced quantities (mean logits, mean log-probs, ELBO) against the reference's over all 64."""
+    import bench
+
+    g = np.load(f"{golden_dir}/bert_c4.npz")
+    S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
+    assert S == 64
+    G, s_local = 8, 8
+    bf.set_compute_dtype("bf16")
+    bmodel, _, inputs, ids, labels, info = bench.build_bert(torch.device("cuda"), "bf16")
+    assert int(ids.sum()) == int(g["ids_sum"])
+    from bayeformers_amd.sampling import repeat_inputs
+
+    rep = repeat_inputs(inputs, s_local)
+    sum_logits = torch.zeros(B, 2, dtype=torch.float64, device="cuda")
+    sum_lp = torch.zeros(2, dtype=torch.float64, device="cuda")
+    tol = 5e-2
+    scale = max(1.0, np.abs(g["logits"]).max())
+    for r in range(G):
+        bf.manual_seed(SEED)  # every rank starts the step from the same global sample counter
+        with torch.no_grad(), bmodel.monte_carlo(s_local, shard=(r, G)):
+            out = bmodel(**rep)
+        logits = out.logits.float().reshape(s_local, B, 2)
+        lps = bmodel.log_prob_samples()
+        sl = slice(r * s_local, (r + 1) * s_local)
+        np.testing.assert_allclose(lps[:, 0].cpu().numpy(), g["log_prior"][sl], rtol=2e-6)
+        np.testing.assert_allclose(lps[:, 1].cpu().numpy(), g["lvp"][sl], rtol=2e-6)
+        assert np.abs(logits.cpu().numpy() - g["logits"][sl]).max() < tol * scale, r
+        sum_logits += logits.double().sum(0)   # what the rank would contribute to the all-reduce
+        sum_lp += lps.sum(0)
+    mean_logits = (sum_logits / S).float()
+    nll = torch.nn.functional.cross_entropy(mean_logits, labels.cuda())
+    assert float(nll) == pytest.approx(float(g["nll"]), rel=tol, abs=tol)
+    lp, lq = sum_lp[0] / S, sum_lp[1] / S
+    n_batches = 2105
+    ref_loss = (g["lvp"].mean() - g["log_prior"].mean()) / n_batches + float(g["nll"])
+    assert float(elbo(lp, lq, nll.double(), n_batches)) == pytest.approx(ref_loss, rel=1e-3)
+
+
 def test_fused_gelu_matches_unfused_bert():
     """fuse_activations(): dense + exact GELU in the GEMM epilogue gives the same logits as the separate GELU op."""
     cfg, model = _bert(True)
@@ -194,6 +266,7 @@ def test_bert_large_qa_c5(golden_dir, dtype, tol):
     bf.fuse_activations(bmodel)
     bf.fuse_residual_layernorm(bmodel)
     assert bf.fuse_shared_inputs(bmodel) == cfg.num_hidden_layers
+    assert bf.fuse_attention(bmodel)  # the configuration bench.py --workload bert_large_qa times
     bf.manual_seed(SEED)
     bf.set_compute_dtype(dtype)
     try:
