@@ -21,7 +21,7 @@ from .nn.parameters.initializations import DEFAULT_UNIFORM, Initialization
 from .random import (get_compute_dtype, manual_seed, set_compute_dtype, set_kl_gradient,  # noqa: F401
                      use_device_counter)
 
-__all__ = ["to_bayesian", "fuse_activations", "fuse_residual_layernorm", "fuse_shared_inputs", "fuse_attention", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
+__all__ = ["to_bayesian", "fuse_activations", "fuse_residual_layernorm", "fuse_shared_inputs", "fuse_attention", "fuse_embeddings", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
            "use_device_counter", "set_kl_gradient"]
 
 
@@ -142,6 +142,54 @@ def fuse_residual_layernorm(model: torch.nn.Module) -> int:
     return fused
 
 
+def _embeddings_forward(self, input_ids=None, token_type_ids=None, position_ids=None, inputs_embeds=None,
+                        past_key_values_length: int = 0):
+    """forward of an HF `*Embeddings` block — LayerNorm(word[ids] + type[type_ids] + pos[pos_ids]) — as one pass
+    (bf_embed_layernorm) when it is the plain inference case; anything else runs the module's own forward."""
+    from . import ops
+
+    w, t, p, ln = self.word_embeddings, self.token_type_embeddings, self.position_embeddings, self.LayerNorm
+    plain = (input_ids is not None and inputs_embeds is None and input_ids.dim() == 2 and input_ids.is_cuda
+             and input_ids.dtype == torch.long and not (self.training and self.dropout.p > 0)
+             and not (torch.is_grad_enabled() and (w.weight.requires_grad or t.weight.requires_grad or
+                                                   p.weight.requires_grad or ln.weight.requires_grad))
+             and w.weight.dtype == t.weight.dtype == p.weight.dtype and w.weight.dtype in ops._TORCH2BF
+             and ln.weight.dtype in (torch.float32, w.weight.dtype) and ln.bias is not None
+             and ln.bias.dtype == ln.weight.dtype and w.weight.shape[1] % 8 == 0 and w.weight.shape[1] <= 4096
+             and past_key_values_length + input_ids.shape[1] <= p.weight.shape[0]
+             and (token_type_ids is None or token_type_ids.dtype == torch.long)
+             and (position_ids is None or (position_ids.dtype == torch.long and position_ids.dim() == 2
+                                           and position_ids.shape[1] == input_ids.shape[1]
+                                           and position_ids.shape[0] in (1, input_ids.shape[0]))))
+    if not plain:
+        return self._bf_plain_forward(input_ids=input_ids, token_type_ids=token_type_ids, position_ids=position_ids,
+                                      inputs_embeds=inputs_embeds, past_key_values_length=past_key_values_length)
+    if position_ids is None and past_key_values_length:
+        position_ids = self.position_ids[:, past_key_values_length:input_ids.shape[1] + past_key_values_length]
+    return ops.embed_layernorm(input_ids, token_type_ids, position_ids, w.weight, t.weight, p.weight, ln.weight, ln.bias,
+                               ln.eps)
+
+
+def fuse_embeddings(model: torch.nn.Module) -> int:
+    """Run embedding blocks of the HuggingFace BERT family (modules holding `word_embeddings`,
+    `token_type_embeddings`, `position_embeddings`, `LayerNorm`, `dropout`) as ONE launch: three table gathers, two
+    full-size adds and the LayerNorm of their result become bf_embed_layernorm.  Inference-time rewrite like the other
+    fuse_* functions: with dropout active, gradients needed or unusual arguments the module's own forward runs.
+    Returns the number of blocks rewritten."""
+    fused = 0
+    for m in model.modules():
+        parts = [getattr(m, n, None) for n in ("word_embeddings", "token_type_embeddings", "position_embeddings")]
+        ln, drop = getattr(m, "LayerNorm", None), getattr(m, "dropout", None)
+        if (all(isinstance(e, torch.nn.Embedding) for e in parts) and isinstance(ln, torch.nn.LayerNorm)
+                and isinstance(drop, torch.nn.Dropout) and ln.elementwise_affine and ln.bias is not None
+                and getattr(m, "position_embedding_type", "absolute") == "absolute"
+                and not hasattr(m, "_bf_plain_forward")):
+            m._bf_plain_forward = m.forward
+            m.forward = types.MethodType(_embeddings_forward, m)
+            fused += 1
+    return fused
+
+
 def fuse_shared_inputs(model: torch.nn.Module, names=("query", "key", "value")) -> int:
     """Multiply the activations of an attention block by its query / key / value weights in ONE launch
     (bf_gemm_nt_layers): marks modules that hold `names` as bnn.Linear children of one shape (HF BertSelfAttention
@@ -175,8 +223,12 @@ def _attention_interface(module, query, key, value, attention_mask, dropout: flo
     usable = (dropout == 0.0 and not (torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or
                                                                     value.requires_grad))
               and not kwargs.get("is_causal", False) and ops.attention_supported(query, key, value))
-    key_mask = None
-    if usable and attention_mask is not None:
+    key_mask = mask_off = None
+    ready = getattr(attention_mask, "_bf_key_mask", None) if attention_mask is not None else None
+    if usable and ready is not None and ready.shape == (query.shape[0], query.shape[2]):
+        # built once per forward by _padding_mask_interface: additive fp32 [B, T] + the device flag "hides nothing"
+        key_mask, mask_off = ready, attention_mask._bf_mask_off
+    elif usable and attention_mask is not None:
         m = attention_mask
         B, H, T, _ = query.shape
         # a padding mask: [B, 1, 1 or T (broadcast), T]; per-query structure is not handled here
@@ -189,9 +241,38 @@ def _attention_interface(module, query, key, value, attention_mask, dropout: flo
         else:
             usable = False
     if not usable:
+        if attention_mask is not None and attention_mask.dtype not in (torch.bool, query.dtype):
+            attention_mask = attention_mask.to(query.dtype)  # the framework's kernels want bool or the query's dtype
         return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
     scale = scaling if scaling is not None else query.shape[-1] ** -0.5
-    return ops.attention_forward(query, key, value, key_mask, scale), None
+    return ops.attention_forward(query, key, value, key_mask, scale, mask_off), None
+
+
+def _padding_mask_interface(batch_size, q_length=None, kv_length=None, q_offset=0, kv_offset=0, mask_function=None,
+                            attention_mask=None, **kwargs):
+    """Mask function in the HuggingFace `AttentionMaskInterface` convention for models routed through
+    `_attention_interface`.  A plain bidirectional padding mask [B, T] becomes, ONCE per forward and without a host
+    round trip, the additive fp32 key mask bf_attention_fwd reads plus a one-byte device flag "nothing is hidden" that
+    lets the kernel skip the mask (the framework's own function answers that question with `mask.all()` on the host —
+    a device synchronisation in every forward, and a different code path under HIP-graph capture).  The 4-D tensor
+    returned ([B, 1, 1, T] additive) is what the framework's attention takes when the kernel does not apply.
+    Anything else (4-D masks, extra mask functions, cached keys) goes to the framework's scaled-dot-product mask."""
+    from transformers.masking_utils import bidirectional_mask_function, sdpa_mask
+
+    plain = (attention_mask is not None and attention_mask.dim() == 2 and mask_function is bidirectional_mask_function
+             and not kwargs.get("use_vmap", False) and q_offset == 0 and kv_offset == 0
+             and attention_mask.shape == (batch_size, kv_length))
+    if attention_mask is None and mask_function is bidirectional_mask_function:
+        return None
+    if not plain:
+        return sdpa_mask(batch_size=batch_size, q_length=q_length, kv_length=kv_length, q_offset=q_offset,
+                         kv_offset=kv_offset, mask_function=mask_function, attention_mask=attention_mask, **kwargs)
+    visible = attention_mask if attention_mask.dtype == torch.bool else attention_mask != 0
+    additive = torch.zeros(visible.shape, dtype=torch.float32, device=visible.device).masked_fill_(~visible, float("-inf"))
+    out = additive[:, None, None, :]
+    out._bf_key_mask = additive
+    out._bf_mask_off = visible.all().reshape(1)  # stays on the device
+    return out
 
 
 def fuse_attention(model: torch.nn.Module) -> bool:
@@ -209,7 +290,7 @@ def fuse_attention(model: torch.nn.Module) -> bool:
     if config is None or not hasattr(config, "_attn_implementation"):
         return False
     AttentionInterface.register(_ATTENTION_NAME, _attention_interface)
-    AttentionMaskInterface.register(_ATTENTION_NAME, sdpa_mask)
+    AttentionMaskInterface.register(_ATTENTION_NAME, _padding_mask_interface)
     for m in inner.modules():
         c = getattr(m, "config", None)
         if c is not None and hasattr(c, "_attn_implementation"):

@@ -57,6 +57,7 @@ struct AttnParams {
     const void* k;
     const void* v;
     const float* mask;  // [B][T] additive, nullable
+    const unsigned char* mask_off;  // nullable device flag: non-zero = the mask is all zeros, skip it
     void* out;
     long long tok_stride;  // elements between consecutive tokens of q / k / v (H * 64 for packed heads)
     int B, T, H;
@@ -72,6 +73,8 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams 
     char* const ks = smem;
     char* const vs = smem + K_BYTES;
     float* const ms = reinterpret_cast<float*>(smem + K_BYTES + V_BYTES);  // this tile's key mask, in log2 units
+    // the caller may not know on the host whether its padding mask hides anything: a device flag says so (uniform)
+    const float* const mask = (p.mask && !(p.mask_off && *p.mask_off)) ? p.mask : nullptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
@@ -107,9 +110,9 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams 
             const f32x4_t vv = *reinterpret_cast<const f32x4_t*>(vb + (long long)(key0 + row) * p.tok_stride + c8 * 8);
             *reinterpret_cast<f32x4_t*>(vs + row * V_ROW + (c8 << 4)) = vv;
         }
-        if (p.mask && tid < TKEY / 4)
+        if (mask && tid < TKEY / 4)
             *reinterpret_cast<f32x4_t*>(ms + tid * 4) =
-                *reinterpret_cast<const f32x4_t*>(p.mask + (long long)b * p.T + key0 + tid * 4) * 1.4426950408889634f;
+                *reinterpret_cast<const f32x4_t*>(mask + (long long)b * p.T + key0 + tid * 4) * 1.4426950408889634f;
         __syncthreads();
 
         // One block of 16 queries at a time (keeps the live scores at 32 registers, 4 waves per SIMD fit).
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams 
 #pragma unroll
             for (int kbk = 0; kbk < 8; ++kbk) {
                 f32x4_t mk = {0.f, 0.f, 0.f, 0.f};
-                if (p.mask) mk = *reinterpret_cast<const f32x4_t*>(ms + kbk * 16 + lg * 4);
+                if (mask) mk = *reinterpret_cast<const f32x4_t*>(ms + kbk * 16 + lg * 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     s[kbk][j] = fmaf(s[kbk][j], p.scale_log2e, mk[j]);
@@ -197,9 +200,9 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams 
 
 }  // namespace
 
-int bf_launch_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, void* d_out, int dtype,
-                            int B, int T, int H, int head_dim, long long token_stride, float scaling,
-                            hipStream_t stream) {
+int bf_launch_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask,
+                            const unsigned char* d_mask_off, void* d_out, int dtype, int B, int T, int H, int head_dim,
+                            long long token_stride, float scaling, hipStream_t stream) {
     if (!d_q || !d_k || !d_v || !d_out) BF_FAIL("bf_attention_fwd: NULL argument");
     if (dtype != BF_DT_BF16 && dtype != BF_DT_F16) BF_FAIL("bf_attention_fwd: dtype must be bf16 or fp16");
     if (head_dim != HD) BF_FAIL("bf_attention_fwd: head size %d (only %d)", head_dim, HD);
@@ -212,6 +215,7 @@ int bf_launch_attention_fwd(const void* d_q, const void* d_k, const void* d_v, c
     p.k = d_k;
     p.v = d_v;
     p.mask = d_mask;
+    p.mask_off = d_mask_off;
     p.out = d_out;
     p.tok_stride = token_stride;
     p.B = B;

@@ -271,6 +271,90 @@ int launch_gt(const void* x, const void* res, const void* gamma, const void* bet
     BF_FAIL("bf_add_layernorm: gamma/beta must be fp32 or have the activation dtype");
 }
 
+
+// Embedding block in one pass (HF BertEmbeddings: LayerNorm(word[ids] + type[type_ids] + pos[pos_ids]), the block
+// that feeds the first Bayesian layers of the converted model): one wave per token gathers its three table rows,
+// adds them in fp32, normalises.  Replaces three gather launches, two full-size adds and the LayerNorm's own read
+// of their result.  pos_ids / type_ids may be NULL: position = token index within its sequence of `seq_len` tokens,
+// type 0 (the module's defaults).
+template <typename T, typename GT, int VPL>
+__global__ __launch_bounds__(64 * kRowsPerBlock) void embed_layernorm_kernel(
+    const long long* __restrict__ ids, const long long* __restrict__ type_ids, const long long* __restrict__ pos_ids,
+    const T* __restrict__ word, const T* __restrict__ type, const T* __restrict__ pos, const GT* __restrict__ gamma,
+    const GT* __restrict__ beta, T* __restrict__ out, long long rows, int N, int seq_len, long long pos_rows,
+    float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = N >> 3;
+    const T* wr = word + ids[row] * N;
+    const T* tr = type + (type_ids ? type_ids[row] : 0) * N;
+    const T* pr = pos + (pos_ids ? pos_ids[row % pos_rows] : row % seq_len) * N;
+    float v[VPL][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) {
+        const int vi = lane + 64 * c;
+        if (vi < nvec) {
+            float a[8], b[8];
+            load8(wr + vi * 8, v[c]);
+            load8(tr + vi * 8, a);
+            load8(pr + vi * 8, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[c][i] = (v[c][i] + a[i]) + b[i];
+                sum += v[c][i];
+            }
+        }
+    }
+    const float inv_n = 1.0f / (float)N;
+    const float mean = wave_sum(sum) * inv_n;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) {
+        if (lane + 64 * c < nvec) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float d = v[c][i] - mean;
+                sq = fmaf(d, d, sq);
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_n + eps);
+    T* orow = out + row * N;
+#pragma unroll
+    for (int c = 0; c < VPL; ++c) {
+        const int vi = lane + 64 * c;
+        if (vi < nvec) {
+            float g[8], b[8], o[8];
+            load8(gamma + vi * 8, g);
+            load8(beta + vi * 8, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = fmaf((v[c][i] - mean) * rstd, g[i], b[i]);
+            store8(orow + vi * 8, o);
+        }
+    }
+}
+
+template <typename T, typename GT>
+int launch_embed(const long long* ids, const long long* type_ids, const long long* pos_ids, const void* word,
+                 const void* type, const void* pos, const void* gamma, const void* beta, void* out, long long rows, int N,
+                 int seq_len, long long pos_rows, float eps, hipStream_t stream) {
+    const dim3 grid((unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock)), block(64 * kRowsPerBlock);
+    const int nvec = N / 8;
+#define BF_EMB(V)                                                                                                      \
+    hipLaunchKernelGGL((embed_layernorm_kernel<T, GT, V>), grid, block, 0, stream, ids, type_ids, pos_ids,              \
+                       (const T*)word, (const T*)type, (const T*)pos, (const GT*)gamma, (const GT*)beta, (T*)out, rows, \
+                       N, seq_len, pos_rows, eps)
+    if (nvec <= 64) BF_EMB(1);
+    else if (nvec <= 128) BF_EMB(2);
+    else if (nvec <= 256) BF_EMB(4);
+    else BF_EMB(8);
+#undef BF_EMB
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 int bf_launch_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta,
@@ -289,6 +373,35 @@ int bf_launch_add_layernorm(const void* d_x, const void* d_residual, const void*
         case BF_DT_F32: return launch_gt<float>(d_x, d_residual, d_gamma, d_beta, param_dtype, dtype, d_out, rows, N, eps, stream);
     }
     BF_FAIL("bf_add_layernorm: unknown dtype %d", dtype);
+}
+
+
+int bf_launch_embed_layernorm(const long long* d_ids, const long long* d_type_ids, const long long* d_pos_ids,
+                              const void* d_word, const void* d_type, const void* d_pos, const void* d_gamma,
+                              const void* d_beta, int param_dtype, void* d_out, int dtype, long long rows, int N,
+                              int seq_len, long long pos_rows, float eps, hipStream_t stream) {
+    if (rows < 0 || N <= 0 || seq_len < 1) BF_FAIL("bf_embed_layernorm: bad shape rows=%lld N=%d seq_len=%d", rows, N, seq_len);
+    if (rows == 0) return 0;
+    if (!d_ids || !d_word || !d_type || !d_pos || !d_gamma || !d_beta || !d_out) BF_FAIL("bf_embed_layernorm: null pointer");
+    if (d_pos_ids && pos_rows < 1) BF_FAIL("bf_embed_layernorm: pos_rows must be >= 1 with explicit position ids");
+    if (N % 8 || N > 4096) BF_FAIL("bf_embed_layernorm: N=%d must be a multiple of 8 and at most 4096", N);
+    if (rows > 0x7fffffffLL * kRowsPerBlock) BF_FAIL("bf_embed_layernorm: too many rows");
+    const uintptr_t al = (uintptr_t)d_word | (uintptr_t)d_type | (uintptr_t)d_pos | (uintptr_t)d_gamma | (uintptr_t)d_beta | (uintptr_t)d_out;
+    if (al & 15) BF_FAIL("bf_embed_layernorm: pointers must be 16-byte aligned");
+    if (param_dtype != dtype && param_dtype != BF_DT_F32) BF_FAIL("bf_embed_layernorm: gamma/beta must be fp32 or the table dtype");
+    const bool pf = param_dtype == BF_DT_F32;
+#define BF_EMB_T(T)                                                                                                     \
+    return pf ? launch_embed<T, float>(d_ids, d_type_ids, d_pos_ids, d_word, d_type, d_pos, d_gamma, d_beta, d_out, rows, N, \
+                                       seq_len, pos_rows, eps, stream)                                                     \
+              : launch_embed<T, T>(d_ids, d_type_ids, d_pos_ids, d_word, d_type, d_pos, d_gamma, d_beta, d_out, rows, N,    \
+                                   seq_len, pos_rows, eps, stream)
+    switch (dtype) {
+        case BF_DT_BF16: BF_EMB_T(__bf16);
+        case BF_DT_F16: BF_EMB_T(_Float16);
+        case BF_DT_F32: BF_EMB_T(float);
+    }
+#undef BF_EMB_T
+    BF_FAIL("bf_embed_layernorm: unknown dtype %d", dtype);
 }
 
 static int bwd_blocks(long long rows) {

@@ -8,7 +8,7 @@
 //   the four accumulations in Linear.forward  /root/reference/bayeformers/nn/layers/linear.py:99-102
 // with ONE launch over all S samples: mu/rho (and the Gaussian prior's mu/rho) are read once from HBM with 16-byte
 // loads (8 or 16 B per scalar), softplus/log are evaluated once per scalar and reused for every sample, epsilon is
-// generated in registers from the Philox counter (bf_philox.h, one Philox4x32-10 block = the 4 scalars a thread
+// generated in registers from the Philox counter (bf_philox.h, one Philox4x32-7 block = the 4 scalars a thread
 // owns), W_s is written once as bf16/fp16/fp32 and the two log-probs are reduced lane -> wave (DPP) -> block (LDS)
 // -> fixed-order fp64 partials (deterministic).
 //
@@ -154,6 +154,70 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[kMax
     }
     const uint32_t g_lo = (uint32_t)(e0 >> 2), g_hi = (uint32_t)(e0 >> 34);
 
+    // Fast path — every lane of the wave owns 4 valid scalars and the output takes one vector store: no validity
+    // selects, no per-sample branches, and the per-scalar arithmetic on PAIRS (v_pk_fma_f32 / v_pk_mul_f32).  Only the
+    // last wave of a tensor whose size is not a multiple of 256 goes through the general loop below.
+    const bool fast = __builtin_amdgcn_readfirstlane((int)__all(nvalid == 4 && (!a.out || a.vec_out))) != 0;
+    if (fast) {
+        const f32x2_t mu01 = {mu[0], mu[1]}, mu23 = {mu[2], mu[3]};
+        const f32x2_t sg01 = {sigma[0], sigma[1]}, sg23 = {sigma[2], sigma[3]};
+        f32x2_t pm01 = {0.f, 0.f}, pm23 = pm01, pi01 = pm01, pi23 = pm01;
+        if constexpr (PRIOR == BF_PRIOR_GAUSSIAN) {
+            pm01 = f32x2_t{pmu[0], pmu[1]};
+            pm23 = f32x2_t{pmu[2], pmu[3]};
+            pi01 = f32x2_t{pinv[0], pinv[1]};
+            pi23 = f32x2_t{pinv[2], pinv[3]};
+        }
+        int out_dt = OUT_DT;
+        if constexpr (OUT_DT == OUT_RUNTIME) out_dt = __builtin_amdgcn_readfirstlane(a.out_dt);
+        char* outp = reinterpret_cast<char*>(a.out);
+        for (int s = s_begin; s < s_end; ++s) {
+            float z[4];
+            bf_normal4_dev(g_lo, g_hi, a.sample_base + (uint32_t)s, a.stream, a.k0, a.k1, z);
+            const f32x2_t z01 = {z[0], z[1]}, z23 = {z[2], z[3]};
+            const f32x2_t w01 = __builtin_elementwise_fma(sg01, z01, mu01), w23 = __builtin_elementwise_fma(sg23, z23, mu23);
+            const f32x2_t q2 = __builtin_elementwise_fma(z23, z23, z01 * z01);
+            float lq = -0.5f * (q2[0] + q2[1]);
+            float lp = 0.f;
+            if constexpr (PRIOR == BF_PRIOR_MIXTURE) {
+                const f32x2_t v01 = w01 * w01, v23 = w23 * w23;
+                const f32x2_t a1 = {a.a1, a.a1}, b1 = {a.b1, a.b1}, a2 = {a.a2, a.a2}, b2 = {a.b2, a.b2};
+                const f32x2_t t1a = __builtin_elementwise_fma(a1, v01, b1), t2a = __builtin_elementwise_fma(a2, v01, b2);
+                const f32x2_t t1b = __builtin_elementwise_fma(a1, v23, b1), t2b = __builtin_elementwise_fma(a2, v23, b2);
+                const f32x2_t ma = __builtin_elementwise_max(t1a, t2a), mb = __builtin_elementwise_max(t1b, t2b);
+                const f32x2_t da = __builtin_elementwise_abs(t1a - t2a) * (f32x2_t)(-1.4426950408889634f);
+                const f32x2_t db = __builtin_elementwise_abs(t1b - t2b) * (f32x2_t)(-1.4426950408889634f);
+                f32x2_t la, lb;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // log(e^t1 + e^t2) = max + ln2 * log2(1 + 2^(-|t1 - t2| log2 e))
+                    la[j] = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(da[j]));
+                    lb[j] = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(db[j]));
+                }
+                const f32x2_t pa = __builtin_elementwise_fma((f32x2_t)(kLn2), la, ma);
+                const f32x2_t pb = __builtin_elementwise_fma((f32x2_t)(kLn2), lb, mb);
+                const f32x2_t ps = pa + pb;
+                lp = ps[0] + ps[1];
+            } else if constexpr (PRIOR == BF_PRIOR_GAUSSIAN) {
+                const f32x2_t d01 = w01 - pm01, d23 = w23 - pm23;
+                const f32x2_t p2 = __builtin_elementwise_fma(d23 * d23, pi23, (d01 * d01) * pi01);
+                lp = -(p2[0] + p2[1]);
+            }
+            if (outp) {
+                const unsigned long long idx = (unsigned long long)s * a.n + e0;
+                const f32x4_t w4 = {w01[0], w01[1], w23[0], w23[1]};
+                if (out_dt == BF_DT_BF16) *reinterpret_cast<bf16x4_t*>(outp + idx * 2) = __builtin_convertvector(w4, bf16x4_t);
+                else if (out_dt == BF_DT_F16) *reinterpret_cast<f16x4_t*>(outp + idx * 2) = __builtin_convertvector(w4, f16x4_t);
+                else *reinterpret_cast<f32x4_t*>(outp + idx * 4) = w4;
+            }
+            lq = wave_sum(lq);
+            lp = wave_sum(lp);
+            if (lane == 0) {
+                red[wid][s - s_begin][0] = lp;
+                red[wid][s - s_begin][1] = lq;
+            }
+        }
+    } else
     for (int s = s_begin; s < s_end; ++s) {
         float lq = 0.f, lp = 0.f;
         if (nvalid > 0) {

@@ -355,6 +355,29 @@ def add_layernorm(x: Tensor, residual: Optional[Tensor], gamma: Tensor, beta: Te
     return out.view(x.shape)
 
 
+def embed_layernorm(ids: Tensor, type_ids: Optional[Tensor], pos_ids: Optional[Tensor], word: Tensor, type_table: Tensor,
+                    pos_table: Tensor, gamma: Tensor, beta: Tensor, eps: float) -> Tensor:
+    """LayerNorm(word[ids] + type[type_ids or 0] + pos[pos_ids or position in sequence]) in one pass
+    (bf_embed_layernorm).  ids: [B, L] int64; type_ids: [B, L] or None; pos_ids: [1 or B, L] or None; returns [B, L, N]."""
+    _require_device(ids, "embed_layernorm ids")
+    B, L = ids.shape
+    N = word.shape[1]
+    ids = ids.contiguous()
+    if type_ids is not None:
+        type_ids = type_ids.expand(B, L).contiguous()
+    pos_rows = 0
+    if pos_ids is not None:
+        pos_ids = pos_ids.contiguous()
+        pos_rows = pos_ids.numel()  # [1, L]: r % L; [B, L]: r
+    out = torch.empty((B, L, N), dtype=word.dtype, device=word.device)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    _C.check(_C.lib().bf_embed_layernorm(ids.data_ptr(), ptr(type_ids), ptr(pos_ids), word.data_ptr(), type_table.data_ptr(),
+                                         pos_table.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _TORCH2BF[gamma.dtype],
+                                         out.data_ptr(), _TORCH2BF[word.dtype], B * L, N, L, pos_rows, float(eps),
+                                         _stream_ptr()), "bf_embed_layernorm")
+    return out
+
+
 def attention_supported(q: Tensor, k: Tensor, v: Tensor) -> bool:
     """q, k, v as the attention hook gets them: [B, H, T, 64] views of the projections' [B*T, H*64] outputs."""
     if not (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and k.dtype == q.dtype and v.dtype == q.dtype):
@@ -368,13 +391,16 @@ def attention_supported(q: Tensor, k: Tensor, v: Tensor) -> bool:
     return all(t.stride() == st and t.data_ptr() % 16 == 0 for t in (q, k, v))
 
 
-def attention_forward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tensor], scaling: float) -> Tensor:
+def attention_forward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tensor], scaling: float,
+                      mask_off: Optional[Tensor] = None) -> Tensor:
     """softmax(q k^T * scaling + key_mask) v (bf_attention_fwd).  q, k, v: [B, H, T, 64] views as described by
-    attention_supported; key_mask: additive fp32 [B, T] or None.  Returns [B, T, H, 64] contiguous."""
+    attention_supported; key_mask: additive fp32 [B, T] or None; mask_off: optional 1-element bool/uint8 device tensor,
+    true = the mask is all zeros (the kernel then skips it).  Returns [B, T, H, 64] contiguous."""
     B, H, T, D = q.shape
     out = torch.empty((B, T, H, D), dtype=q.dtype, device=q.device)
     _C.check(_C.lib().bf_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(),
-                                       key_mask.data_ptr() if key_mask is not None else None, out.data_ptr(),
+                                       key_mask.data_ptr() if key_mask is not None else None,
+                                       mask_off.data_ptr() if mask_off is not None else None, out.data_ptr(),
                                        _TORCH2BF[q.dtype], B, T, H, D, H * D, float(scaling), _stream_ptr()),
              "bf_attention_fwd")
     return out

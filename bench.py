@@ -77,6 +77,7 @@ def build_bert(device, dtype):
     n_ln = bf.fuse_residual_layernorm(bmodel) if os.environ.get("BF_BENCH_NO_LN_FUSION") is None else 0
     n_qkv = bf.fuse_shared_inputs(bmodel) if os.environ.get("BF_BENCH_NO_QKV_FUSION") is None else 0
     attn = bf.fuse_attention(bmodel) if os.environ.get("BF_BENCH_NO_ATTENTION") is None else False
+    n_emb = bf.fuse_embeddings(bmodel) if os.environ.get("BF_BENCH_NO_EMBED_FUSION") is None else 0
     if dtype != "fp32":
         bmodel = bmodel.to(torch.bfloat16 if dtype == "bf16" else torch.float16)
     g = torch.Generator().manual_seed(321)
@@ -84,7 +85,7 @@ def build_bert(device, dtype):
     labels = torch.randint(0, 2, (B,), generator=g)
     inputs = {"input_ids": ids.to(device), "attention_mask": torch.ones(B, L, dtype=torch.long, device=device)}
     info = {"gelu_fused_into_gemm": n_fused, "residual_layernorm_fused": n_ln, "qkv_in_one_launch": n_qkv,
-            "attention_kernel": bool(attn)}
+            "attention_kernel": bool(attn), "embeddings_in_one_launch": n_emb}
     return bmodel, model, inputs, ids, labels, info
 
 
@@ -154,6 +155,7 @@ def make_bert_large_qa(device, S, dtype):
     n_ln = bf.fuse_residual_layernorm(bmodel) if os.environ.get("BF_BENCH_NO_LN_FUSION") is None else 0
     n_qkv = bf.fuse_shared_inputs(bmodel) if os.environ.get("BF_BENCH_NO_QKV_FUSION") is None else 0
     attn = bf.fuse_attention(bmodel) if os.environ.get("BF_BENCH_NO_ATTENTION") is None else False
+    n_emb = bf.fuse_embeddings(bmodel) if os.environ.get("BF_BENCH_NO_EMBED_FUSION") is None else 0
     if dtype != "fp32":
         bmodel = bmodel.to(torch.bfloat16 if dtype == "bf16" else torch.float16)
     g = torch.Generator().manual_seed(654)
@@ -184,7 +186,7 @@ def make_bert_large_qa(device, S, dtype):
             "allreduce_values": 2 * B * L + 2,
             "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "gelu_fused_into_gemm": n_fused,
             "residual_layernorm_fused": n_ln, "qkv_in_one_launch": n_qkv,
-            "attention_kernel": bool(attn)}
+            "attention_kernel": bool(attn), "embeddings_in_one_launch": n_emb}
     return step, cpu_baseline, cfgd, bmodel
 
 

@@ -12,7 +12,7 @@
  *   - return value 0 = ok, non-zero = error; bf_last_error() returns a thread-local description.  No C++
  *     exception crosses the boundary;
  *   - no hidden RNG state: epsilon is a pure function of (seed, sample index, stream id, element index) —
- *     see bayeformers_amd/csrc/bf_philox.h for the contract (Philox4x32-10 + Box-Muller).
+ *     see bayeformers_amd/csrc/bf_philox.h for the contract (Philox4x32-7 + Box-Muller).
  */
 #ifndef BAYEFORMERS_AMD_H
 #define BAYEFORMERS_AMD_H
@@ -215,6 +215,14 @@ int bf_embedding_bwd(const int64_t* d_ids, const void* d_grad, int grad_dtype, c
 int bf_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, int param_dtype,
                      void* d_out, int dtype, int64_t rows, int N, float eps, void* stream);
 
+/* The embedding block that feeds the first Bayesian layers of a converted transformer (HF BertEmbeddings, called
+ * ahead of bnn.Linear.forward, bayeformers/nn/layers/linear.py:83-104), in one pass:
+ *   out[r] = LayerNorm(word[ids[r]] + type[type_ids ? type_ids[r] : 0] + pos[pos_ids ? pos_ids[r % pos_rows] : r % seq_len])
+ * tables [*, N] and out [rows, N] of `dtype`; gamma/beta fp32 or `dtype`; ids int64 [rows].  Sum and statistics in fp32. */
+int bf_embed_layernorm(const int64_t* d_ids, const int64_t* d_type_ids, const int64_t* d_pos_ids, const void* d_word,
+                       const void* d_type, const void* d_pos, const void* d_gamma, const void* d_beta, int param_dtype,
+                       void* d_out, int dtype, int64_t rows, int N, int seq_len, int64_t pos_rows, float eps, void* stream);
+
 /* Backward of bf_add_layernorm.  z = x + residual and its row statistics are recomputed from the forward's inputs;
  * d_dz [rows, N] of `dtype` is the gradient of BOTH x and residual; d_dgamma / d_dbeta are fp32 [N], written (not
  * accumulated) in a fixed summation order.  N % 8 == 0, N <= 4096. */
@@ -229,9 +237,12 @@ int bf_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_
  * reference runs whatever the wrapped model runs there).  Inference-time forward.  q, k, v: element (b, t, h, d) at
  * ((b*T + t) * token_stride + h*head_dim + d) of `dtype` (BF16 | F16) — i.e. the [B*T, H*head_dim] outputs of the
  * projections as they are; d_mask: additive fp32 [B][T] over the keys (-inf = masked), nullable; d_out: [B][T][H][head_dim]
- * contiguous.  head_dim == 64, T a multiple of 128, 16-byte aligned pointers; anything else is refused (status 1). */
-int bf_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, void* d_out, int dtype,
-                     int B, int T, int H, int head_dim, int64_t token_stride, float scaling, void* stream);
+ * contiguous.  d_mask_off (nullable): one device byte; non-zero means "the mask hides nothing" and the kernel skips it —
+ * lets a caller that builds the additive mask from a padding mask on the device avoid a host round trip to find out.
+ * head_dim == 64, T a multiple of 128, 16-byte aligned pointers; anything else is refused (status 1). */
+int bf_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
+                     void* d_out, int dtype, int B, int T, int H, int head_dim, int64_t token_stride, float scaling,
+                     void* stream);
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * While enabled, every sampling launch (kind BF_PROF_SAMPLE) and every GEMM launch (BF_PROF_GEMM) made through

@@ -37,29 +37,32 @@ def _lib():
         lib.oracle_normals.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
                                        ctypes.c_uint32, ctypes.c_uint64]
         lib.oracle_normals.restype = None
-        lib.oracle_philox4x32_10.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-        lib.oracle_philox4x32_10.restype = None
+        lib.oracle_philox4x32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        lib.oracle_philox4x32.restype = None
         _LIB = lib
     return _LIB
 
 
-def philox4x32_10(ctr, key):
-    """Raw Philox4x32-10 block (C implementation, oracle/philox_oracle.c)."""
+PHILOX_ROUNDS = 7  # the epsilon contract (csrc/bf_philox.h BF_PHILOX_ROUNDS, oracle/philox_oracle.c)
+
+
+def philox4x32(ctr, key, rounds=PHILOX_ROUNDS):
+    """Raw Philox4x32-R block (C implementation, oracle/philox_oracle.c)."""
     c = np.asarray(ctr, dtype=np.uint32).copy()
     k = np.asarray(key, dtype=np.uint32).copy()
     out = np.zeros(4, dtype=np.uint32)
-    _lib().oracle_philox4x32_10(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    _lib().oracle_philox4x32(c.ctypes.data, k.ctypes.data, int(rounds), out.ctypes.data)
     return out
 
 
-def philox4x32_10_numpy(ctr, key):
-    """Vectorised numpy Philox4x32-10, written independently of the C one.  ctr: [...,4] uint32, key: [2]."""
+def philox4x32_numpy(ctr, key, rounds=PHILOX_ROUNDS):
+    """Vectorised numpy Philox4x32-R, written independently of the C one.  ctr: [...,4] uint32, key: [2]."""
     c = np.asarray(ctr, dtype=np.uint64).copy()
     k0, k1 = np.uint64(key[0]), np.uint64(key[1])
     m0, m1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
     mask = np.uint64(0xFFFFFFFF)
     sh = np.uint64(32)
-    for r in range(10):
+    for r in range(rounds):
         p0 = m0 * c[..., 0]
         p1 = m1 * c[..., 2]
         n0 = (p1 >> sh) ^ c[..., 1] ^ k0
@@ -88,7 +91,7 @@ def normals_numpy(n, seed, sample, stream, offset=0):
     g = e >> np.uint64(2)
     ctr = np.stack([g & np.uint64(0xFFFFFFFF), np.full_like(g, sample & 0xFFFFFFFF),
                     np.full_like(g, stream & 0xFFFFFFFF), g >> np.uint64(32)], axis=-1)
-    x = philox4x32_10_numpy(ctr, [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF])
+    x = philox4x32_numpy(ctr, [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF])
     j = (e & np.uint64(3)).astype(np.int64)
     pair = j >> 1
     a = np.take_along_axis(x, (2 * pair)[:, None], axis=1)[:, 0]

@@ -184,8 +184,11 @@ def test_kl_gradient_opt_in_matches_autograd_of_the_closed_forms(golden_dir, nam
         # fp32 ulp of w there is worth ~1e-4 of gradient, so the mixture case gets a looser bound
         tol = 2e-3 if pr[0] == "mixture" else 2e-5
         err = (got.double().cpu() - ref).abs()
-        assert err.max().item() <= tol * scale, what
-        assert (err > 2e-5 * scale).double().mean().item() < 0.1, what  # only the few values near the crossover
+        # each gradient is a signed sum over S samples of per-sample scores of magnitude up to ~1 (coef * w / sigma^2):
+        # fp32 rounding of those terms leaves a few 1e-7 absolute, whatever the size of the sum that survives
+        floor = 3e-7
+        assert err.max().item() <= tol * scale + floor, what
+        assert (err > 2e-5 * scale + floor).double().mean().item() < 0.1, what  # only the few values near the crossover
 
 
 def test_training_loop_reduces_the_elbo():

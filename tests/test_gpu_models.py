@@ -120,7 +120,7 @@ def test_benchmarked_configuration_matches_reference_c3(golden_dir):
     bf.set_compute_dtype("bf16")
     bmodel, _, inputs, ids, labels, info = bench.build_bert(torch.device("cuda"), "bf16")
     assert info == {"gelu_fused_into_gemm": 12, "residual_layernorm_fused": 24, "qkv_in_one_launch": 12,
-                    "attention_kernel": True}
+                    "attention_kernel": True, "embeddings_in_one_launch": 1}
     assert tuple(ids.shape) == (B, L) and int(ids.sum()) == int(g["ids_sum"]) and np.array_equal(labels.numpy(), g["labels"])
     assert len(bmodel.fused_children()) == int(g["n_layers"])
     bf.manual_seed(SEED)
@@ -179,6 +179,31 @@ def test_config4_shards_of_8_match_reference_c4(golden_dir):
     n_batches = 2105
     ref_loss = (g["lvp"].mean() - g["log_prior"].mean()) / n_batches + float(g["nll"])
     assert float(elbo(lp, lq, nll.double(), n_batches)) == pytest.approx(ref_loss, rel=1e-3)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-2), (torch.float16, 2e-3)])
+def test_fused_embeddings_match_the_module(dtype, tol):
+    """fuse_embeddings(): bf_embed_layernorm against HF BertEmbeddings' own forward — default ids, explicit token
+    types and positions, a padded vocabulary id — and the attention-mask interface against the framework's."""
+    cfg, model = _bert(True)
+    emb = model.bert.embeddings.cuda().to(dtype).eval()
+    torch.manual_seed(11)
+    ids = torch.randint(0, cfg.vocab_size, (6, 48)).cuda()
+    ids[0, :3] = cfg.pad_token_id
+    tt = torch.randint(0, cfg.type_vocab_size, (6, 48)).cuda()
+    pos = torch.arange(48).flip(0)[None].cuda()
+    with torch.no_grad():
+        refs = [emb(input_ids=ids), emb(input_ids=ids, token_type_ids=tt), emb(input_ids=ids, position_ids=pos),
+                emb(input_ids=ids, token_type_ids=tt, position_ids=pos.expand(6, 48).contiguous())]
+        assert bf.fuse_embeddings(model) == 1 and bf.fuse_embeddings(model) == 0
+        outs = [emb(input_ids=ids), emb(input_ids=ids, token_type_ids=tt), emb(input_ids=ids, position_ids=pos),
+                emb(input_ids=ids, token_type_ids=tt, position_ids=pos.expand(6, 48).contiguous())]
+        for r, o in zip(refs, outs):
+            assert o.shape == r.shape and o.dtype == r.dtype
+            assert (o.float() - r.float()).abs().max().item() <= tol * max(1.0, r.float().abs().max().item())
+        # what the rewrite does not take runs the module's own forward
+        e = emb.word_embeddings(ids)
+        assert torch.equal(emb(inputs_embeds=e), emb._bf_plain_forward(inputs_embeds=e))
 
 
 def test_fused_gelu_matches_unfused_bert():
@@ -267,6 +292,7 @@ def test_bert_large_qa_c5(golden_dir, dtype, tol):
     bf.fuse_residual_layernorm(bmodel)
     assert bf.fuse_shared_inputs(bmodel) == cfg.num_hidden_layers
     assert bf.fuse_attention(bmodel)  # the configuration bench.py --workload bert_large_qa times
+    assert bf.fuse_embeddings(bmodel) == 1
     bf.manual_seed(SEED)
     bf.set_compute_dtype(dtype)
     try:

@@ -3,19 +3,27 @@ import numpy as np
 
 from oracle import bayes_oracle as bo
 
-# Random123 kat_vectors, philox4x32 with 10 rounds: counter[4], key[2] -> output[4]
-KAT = [
-    ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
-    ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
-    ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0],
-     [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
-]
+# Random123 kat_vectors, `philox4x32 R counter[4] key[2] -> output[4]`, for the contract's R = 7 and for R = 10
+# (the same round function, so the second set pins it independently of the round count)
+PI_CTR, PI_KEY = [0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]
+KAT = {
+    7: [([0, 0, 0, 0], [0, 0], [0x5F6FB709, 0x0D893F64, 0x4F121F81, 0x4F730A48]),
+        ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x5207DDC2, 0x45165E59, 0x4D8EE751, 0x8C52F662]),
+        (PI_CTR, PI_KEY, [0x4DFCCABA, 0x190A87F0, 0xC47362BA, 0xB6B5242A])],
+    10: [([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+         ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+         (PI_CTR, PI_KEY, [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1])],
+}
 
 
 def test_philox_known_answers():
-    for ctr, key, exp in KAT:
-        assert list(bo.philox4x32_10(ctr, key)) == exp
-        assert list(bo.philox4x32_10_numpy(np.array(ctr), key)) == exp
+    assert bo.PHILOX_ROUNDS == 7
+    for rounds, vectors in KAT.items():
+        for ctr, key, exp in vectors:
+            assert list(bo.philox4x32(ctr, key, rounds)) == exp
+            assert list(bo.philox4x32_numpy(np.array(ctr), key, rounds)) == exp
+    ctr, key, exp = KAT[7][2]
+    assert list(bo.philox4x32(ctr, key)) == exp  # the default round count is the contract's
 
 
 def test_c_and_numpy_normals_agree_bitwise():

@@ -91,3 +91,24 @@ def test_two_rank_sharding_matches_single_process():
         assert lp == pytest.approx(elp) and lq == pytest.approx(elq)
         # second step: this rank ran global samples [6 + 3*rank, 6 + 3*rank + 3)
         np.testing.assert_allclose(raw_local, expected(x, 3, 6 + 3 * rank)[0], rtol=1e-5)
+
+
+def test_repeated_inputs_are_cached_until_the_input_changes():
+    """repeat_inputs keeps the S-fold copies of resident inputs between steps (no_grad): same tensor object, unchanged
+    -> the same repeated tensor; modified in place, another tensor or another S -> repeated again."""
+    from bayeformers_amd.sampling import repeat_inputs
+
+    x = torch.arange(12).reshape(3, 4)
+    with torch.no_grad():
+        a = repeat_inputs({"input_ids": x}, 5)["input_ids"]
+        b = repeat_inputs({"input_ids": x}, 5)["input_ids"]
+        assert a is b and a.shape == (15, 4) and torch.equal(a[3:6], x)
+        x[0, 0] = 99                                   # in-place edit bumps the version counter
+        c = repeat_inputs({"input_ids": x}, 5)["input_ids"]
+        assert c is not a and int(c[0, 0]) == 99 and int(c[3, 0]) == 99
+        d = repeat_inputs({"input_ids": x}, 2)["input_ids"]
+        assert d.shape == (6, 4)
+        assert repeat_inputs(x, 1) is x
+    y = torch.ones(2, 3, requires_grad=True)
+    r = repeat_inputs(y, 3)                            # differentiable inputs are never cached
+    assert r.requires_grad and r.shape == (6, 3)
