@@ -90,6 +90,74 @@ BF_D void bf_box_muller_dev(uint32_t a, uint32_t b, float& z0, float& z1) {
     z1 = r * __builtin_amdgcn_sinf(u2);
 }
 
+// The same block function split at what does NOT depend on the Monte-Carlo sample index.  The counter is
+// {lo32(group), sample, stream, hi32(group)}: the sample enters round 0 through c1 only, so in rounds 0-2 half of the
+// products (M0 * lo32(group) in round 0, M1 * c2 in round 1, M0 * c0 in round 2) and the words they feed are the same
+// for every sample of a group.  A kernel that draws S samples of the same elements computes them once
+// (bf_philox_prepare) and pays 9 instead of 14 64-bit multiplies per further block (bf_philox_finish).  Bit-identical
+// to bf_philox4x32 by construction (tests/test_gpu_philox.py compares the kernels that use it with the oracle).
+struct bf_philox_inv {
+    uint32_t c3a;   // round 0: lo(M0 * group_lo)                              -> c3 entering round 1
+    uint32_t x1;    // round 1: lo(M1 * c2a) ^ (k0 + 2 W0)   (c1 entering round 2, pre-xored with that round's key)
+    uint32_t h0k;   // round 2: hi(M0 * c0b) ^ (k1 + 2 W1)   (c0b = c0 entering round 2, sample-independent)
+    uint32_t l0;    // round 2: lo(M0 * c0b)                                  -> c3 entering round 3
+};
+
+BF_D bf_philox_inv bf_philox_prepare(uint32_t group_lo, uint32_t group_hi, uint32_t stream, uint32_t k0, uint32_t k1) {
+    static_assert(BF_PHILOX_ROUNDS >= 3, "the split assumes at least three rounds");
+    const uint64_t p0 = (uint64_t)BF_PHILOX_M0 * group_lo;                    // round 0, counter word 0
+    const uint32_t c2a = (uint32_t)(p0 >> 32) ^ group_hi ^ k1;                // c2 entering round 1
+    const uint64_t p1s = (uint64_t)BF_PHILOX_M1 * stream;                     // round 0, counter word 2 (scalar)
+    const uint32_t c1a = (uint32_t)p1s;                                       // c1 entering round 1
+    const uint64_t q1 = (uint64_t)BF_PHILOX_M1 * c2a;                         // round 1
+    const uint32_t c0b = (uint32_t)(q1 >> 32) ^ c1a ^ (k0 + BF_PHILOX_W0);    // c0 entering round 2
+    const uint64_t r0 = (uint64_t)BF_PHILOX_M0 * c0b;                         // round 2
+    bf_philox_inv v;
+    v.c3a = (uint32_t)p0;
+    v.x1 = (uint32_t)q1 ^ (k0 + 2u * BF_PHILOX_W0);
+    v.h0k = (uint32_t)(r0 >> 32) ^ (k1 + 2u * BF_PHILOX_W1);
+    v.l0 = (uint32_t)r0;
+    return v;
+}
+
+BF_D bf_u32x4 bf_philox_finish(const bf_philox_inv& v, uint32_t sample, uint32_t stream, uint32_t k0, uint32_t k1) {
+    // round 0, the sample-dependent word (uniform across the wave: scalar arithmetic)
+    const uint64_t p1s = (uint64_t)BF_PHILOX_M1 * stream;
+    const uint32_t c0a = (uint32_t)(p1s >> 32) ^ sample ^ k0;                 // c0 entering round 1
+    // round 1: M0 * c0a is uniform too
+    const uint64_t q0 = (uint64_t)BF_PHILOX_M0 * c0a;
+    const uint32_t c2b = (uint32_t)(q0 >> 32) ^ v.c3a ^ (k1 + BF_PHILOX_W1);  // c2 entering round 2
+    const uint32_t c3b = (uint32_t)q0;                                        // c3 entering round 2 (uniform)
+    // round 2: one product left
+    const uint64_t r1 = (uint64_t)BF_PHILOX_M1 * c2b;
+    uint32_t c0 = (uint32_t)(r1 >> 32) ^ v.x1;
+    uint32_t c1 = (uint32_t)r1;
+    uint32_t c2 = v.h0k ^ c3b;
+    uint32_t c3 = v.l0;
+    uint32_t ka = k0 + 3u * BF_PHILOX_W0, kb = k1 + 3u * BF_PHILOX_W1;
+#pragma unroll
+    for (int r = 3; r < BF_PHILOX_ROUNDS; ++r) {
+        const uint64_t p0 = (uint64_t)BF_PHILOX_M0 * c0;
+        const uint64_t p1 = (uint64_t)BF_PHILOX_M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ ka;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ kb;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        ka += BF_PHILOX_W0;
+        kb += BF_PHILOX_W1;
+    }
+    bf_u32x4 o = {c0, c1, c2, c3};
+    return o;
+}
+
+BF_D void bf_normal4_split_dev(const bf_philox_inv& v, uint32_t sample, uint32_t stream, uint32_t k0, uint32_t k1,
+                               float z[4]) {
+    const bf_u32x4 x = bf_philox_finish(v, sample, stream, k0, k1);
+    bf_box_muller_dev(x.x, x.y, z[0], z[1]);
+    bf_box_muller_dev(x.z, x.w, z[2], z[3]);
+}
+
 BF_D void bf_normal4_dev(uint32_t group_lo, uint32_t group_hi, uint32_t sample, uint32_t stream, uint32_t k0,
                          uint32_t k1, float z[4]) {
     const bf_u32x4 x = bf_philox4x32(group_lo, sample, stream, group_hi, k0, k1);

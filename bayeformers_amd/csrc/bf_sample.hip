@@ -29,7 +29,11 @@
 namespace {
 
 constexpr int kThreads = 256;  // 4 waves
-constexpr int kEPT = 4;        // scalars per thread = one Philox block per sample
+#ifndef BF_SAMPLE_GPT
+#define BF_SAMPLE_GPT 2
+#endif
+constexpr int kGPT = BF_SAMPLE_GPT;  // groups of 4 scalars (= Philox blocks per sample) a thread owns
+constexpr int kEPT = 4 * kGPT;         // scalars per thread
 constexpr int kMaxSChunk = 32;
 constexpr int kMaxSeg = 2;
 constexpr int OUT_NONE = -1;
@@ -117,101 +121,109 @@ struct BodyArgs {
     double* partial_row;  // this block's [S][2] row of the partials
 };
 
-// block = 256 threads; thread = 4 consecutive scalars x the samples of chunk blockIdx.y.
+// block = 256 threads; a thread owns kGPT groups of 4 consecutive scalars (group j of thread t = group j*256 + t of the
+// block: 16-byte loads stay contiguous across the wave) x the samples of chunk blockIdx.y.  Several groups per thread
+// amortise the two wave reductions a sample needs (about a quarter of the per-sample instructions at one group).
 template <int PRIOR, int OUT_DT>
 __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[kMaxSChunk][2], float (*cst)[2]) {
+    constexpr int G = kGPT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned long long e0 = ((unsigned long long)a.rel_block * kThreads + tid) * kEPT;
-    const int nvalid = e0 >= a.n ? 0 : (a.n - e0 >= 4 ? 4 : (int)(a.n - e0));
     // balanced sample chunks: chunk y covers [y*S/ny, (y+1)*S/ny)
     const int s_begin = (int)(((long long)blockIdx.y * a.S) / a.ny);
     const int s_end = (int)(((long long)(blockIdx.y + 1) * a.S) / a.ny);
 
-    float mu[4], sigma[4];
-    float pmu[4], pinv[4];  // gaussian prior: mean and 1/(2 sigma_p^2)
+    unsigned long long e0[G];
+    int nvalid[G];
+    float mu[G][4], sigma[G][4];
+    float pmu[G][4], pinv[G][4];  // gaussian prior: mean and 1/(2 sigma_p^2)
     float constq = 0.f, constp = 0.f;
-    if (nvalid > 0) {
-        float rho[4];
-        load4(a.mu, e0, nvalid, a.vec_in, mu);
-        load4(a.rho, e0, nvalid, a.vec_in, rho);
+    bool all_full = true;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            sigma[i] = softplus_fast(rho[i]);
-            if (i < nvalid) constq += -kLogSqrt2Pi - log_fast(sigma[i]);
-        }
-        if constexpr (PRIOR == BF_PRIOR_GAUSSIAN) {
-            float prho[4];
-            load4(a.mu_p, e0, nvalid, a.vec_in, pmu);
-            load4(a.rho_p, e0, nvalid, a.vec_in, prho);
+    for (int j = 0; j < G; ++j) {
+        e0[j] = (((unsigned long long)a.rel_block * G + j) * kThreads + tid) * 4;
+        nvalid[j] = e0[j] >= a.n ? 0 : (a.n - e0[j] >= 4 ? 4 : (int)(a.n - e0[j]));
+        all_full = all_full && nvalid[j] == 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mu[j][i] = sigma[j][i] = pmu[j][i] = pinv[j][i] = 0.f;
+        if (nvalid[j] > 0) {
+            float rho[4];
+            load4(a.mu, e0[j], nvalid[j], a.vec_in, mu[j]);
+            load4(a.rho, e0[j], nvalid[j], a.vec_in, rho);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float sp = softplus_fast(prho[i]);
-                pinv[i] = 0.5f * __builtin_amdgcn_rcpf(sp * sp);
-                if (i < nvalid) constp += -kLogSqrt2Pi - log_fast(sp);
+                sigma[j][i] = softplus_fast(rho[i]);
+                if (i < nvalid[j]) constq += -kLogSqrt2Pi - log_fast(sigma[j][i]);
+            }
+            if constexpr (PRIOR == BF_PRIOR_GAUSSIAN) {
+                float prho[4];
+                load4(a.mu_p, e0[j], nvalid[j], a.vec_in, pmu[j]);
+                load4(a.rho_p, e0[j], nvalid[j], a.vec_in, prho);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float sp = softplus_fast(prho[i]);
+                    pinv[j][i] = 0.5f * __builtin_amdgcn_rcpf(sp * sp);
+                    if (i < nvalid[j]) constp += -kLogSqrt2Pi - log_fast(sp);
+                }
             }
         }
     }
-    const uint32_t g_lo = (uint32_t)(e0 >> 2), g_hi = (uint32_t)(e0 >> 34);
 
-    // Fast path — every lane of the wave owns 4 valid scalars and the output takes one vector store: no validity
-    // selects, no per-sample branches, and the per-scalar arithmetic on PAIRS (v_pk_fma_f32 / v_pk_mul_f32).  Only the
-    // last wave of a tensor whose size is not a multiple of 256 goes through the general loop below.
-    const bool fast = __builtin_amdgcn_readfirstlane((int)__all(nvalid == 4 && (!a.out || a.vec_out))) != 0;
+    // Fast path — every lane of the wave owns only full groups and the output takes one vector store per group: no
+    // validity selects, no per-sample branches, and the per-scalar arithmetic on PAIRS (v_pk_fma_f32 / v_pk_mul_f32).
+    // Only the last block of a tensor whose size is not a multiple of the block goes through the general loop below.
+    const bool fast = __builtin_amdgcn_readfirstlane((int)__all(all_full && (!a.out || a.vec_out))) != 0;
     if (fast) {
-        const f32x2_t mu01 = {mu[0], mu[1]}, mu23 = {mu[2], mu[3]};
-        const f32x2_t sg01 = {sigma[0], sigma[1]}, sg23 = {sigma[2], sigma[3]};
-        f32x2_t pm01 = {0.f, 0.f}, pm23 = pm01, pi01 = pm01, pi23 = pm01;
-        if constexpr (PRIOR == BF_PRIOR_GAUSSIAN) {
-            pm01 = f32x2_t{pmu[0], pmu[1]};
-            pm23 = f32x2_t{pmu[2], pmu[3]};
-            pi01 = f32x2_t{pinv[0], pinv[1]};
-            pi23 = f32x2_t{pinv[2], pinv[3]};
-        }
         int out_dt = OUT_DT;
         if constexpr (OUT_DT == OUT_RUNTIME) out_dt = __builtin_amdgcn_readfirstlane(a.out_dt);
         char* outp = reinterpret_cast<char*>(a.out);
-        for (int s = s_begin; s < s_end; ++s) {
-            float z[4];
-            bf_normal4_dev(g_lo, g_hi, a.sample_base + (uint32_t)s, a.stream, a.k0, a.k1, z);
-            const f32x2_t z01 = {z[0], z[1]}, z23 = {z[2], z[3]};
-            const f32x2_t w01 = __builtin_elementwise_fma(sg01, z01, mu01), w23 = __builtin_elementwise_fma(sg23, z23, mu23);
-            const f32x2_t q2 = __builtin_elementwise_fma(z23, z23, z01 * z01);
-            float lq = -0.5f * (q2[0] + q2[1]);
-            float lp = 0.f;
-            if constexpr (PRIOR == BF_PRIOR_MIXTURE) {
-                const f32x2_t v01 = w01 * w01, v23 = w23 * w23;
-                const f32x2_t a1 = {a.a1, a.a1}, b1 = {a.b1, a.b1}, a2 = {a.a2, a.a2}, b2 = {a.b2, a.b2};
-                const f32x2_t t1a = __builtin_elementwise_fma(a1, v01, b1), t2a = __builtin_elementwise_fma(a2, v01, b2);
-                const f32x2_t t1b = __builtin_elementwise_fma(a1, v23, b1), t2b = __builtin_elementwise_fma(a2, v23, b2);
-                const f32x2_t ma = __builtin_elementwise_max(t1a, t2a), mb = __builtin_elementwise_max(t1b, t2b);
-                const f32x2_t da = __builtin_elementwise_abs(t1a - t2a) * (f32x2_t)(-1.4426950408889634f);
-                const f32x2_t db = __builtin_elementwise_abs(t1b - t2b) * (f32x2_t)(-1.4426950408889634f);
-                f32x2_t la, lb;
+        bf_philox_inv inv[G];  // the sample-independent part of each group's Philox block, once
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    // log(e^t1 + e^t2) = max + ln2 * log2(1 + 2^(-|t1 - t2| log2 e))
-                    la[j] = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(da[j]));
-                    lb[j] = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(db[j]));
+        for (int j = 0; j < G; ++j)
+            inv[j] = bf_philox_prepare((uint32_t)(e0[j] >> 2), (uint32_t)(e0[j] >> 34), a.stream, a.k0, a.k1);
+        for (int s = s_begin; s < s_end; ++s) {
+            f32x2_t q2 = {0.f, 0.f}, p2 = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                float z[4];
+                bf_normal4_split_dev(inv[j], a.sample_base + (uint32_t)s, a.stream, a.k0, a.k1, z);
+                const f32x2_t z01 = {z[0], z[1]}, z23 = {z[2], z[3]};
+                const f32x2_t w01 = __builtin_elementwise_fma(f32x2_t{sigma[j][0], sigma[j][1]}, z01, f32x2_t{mu[j][0], mu[j][1]});
+                const f32x2_t w23 = __builtin_elementwise_fma(f32x2_t{sigma[j][2], sigma[j][3]}, z23, f32x2_t{mu[j][2], mu[j][3]});
+                q2 = __builtin_elementwise_fma(z01, z01, q2);
+                q2 = __builtin_elementwise_fma(z23, z23, q2);
+                if constexpr (PRIOR == BF_PRIOR_MIXTURE) {
+                    const f32x2_t v01 = w01 * w01, v23 = w23 * w23;
+                    const f32x2_t a1 = {a.a1, a.a1}, b1 = {a.b1, a.b1}, a2 = {a.a2, a.a2}, b2 = {a.b2, a.b2};
+                    const f32x2_t t1a = __builtin_elementwise_fma(a1, v01, b1), t2a = __builtin_elementwise_fma(a2, v01, b2);
+                    const f32x2_t t1b = __builtin_elementwise_fma(a1, v23, b1), t2b = __builtin_elementwise_fma(a2, v23, b2);
+                    const f32x2_t ma = __builtin_elementwise_max(t1a, t2a), mb = __builtin_elementwise_max(t1b, t2b);
+                    const f32x2_t da = __builtin_elementwise_abs(t1a - t2a) * (f32x2_t)(-1.4426950408889634f);
+                    const f32x2_t db = __builtin_elementwise_abs(t1b - t2b) * (f32x2_t)(-1.4426950408889634f);
+                    f32x2_t la, lb;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        // log(e^t1 + e^t2) = max + ln2 * log2(1 + 2^(-|t1 - t2| log2 e))
+                        la[i] = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(da[i]));
+                        lb[i] = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(db[i]));
+                    }
+                    p2 += __builtin_elementwise_fma((f32x2_t)(kLn2), la, ma);
+                    p2 += __builtin_elementwise_fma((f32x2_t)(kLn2), lb, mb);
+                } else if constexpr (PRIOR == BF_PRIOR_GAUSSIAN) {
+                    const f32x2_t d01 = w01 - f32x2_t{pmu[j][0], pmu[j][1]}, d23 = w23 - f32x2_t{pmu[j][2], pmu[j][3]};
+                    p2 = __builtin_elementwise_fma(d01 * d01, f32x2_t{-pinv[j][0], -pinv[j][1]}, p2);
+                    p2 = __builtin_elementwise_fma(d23 * d23, f32x2_t{-pinv[j][2], -pinv[j][3]}, p2);
                 }
-                const f32x2_t pa = __builtin_elementwise_fma((f32x2_t)(kLn2), la, ma);
-                const f32x2_t pb = __builtin_elementwise_fma((f32x2_t)(kLn2), lb, mb);
-                const f32x2_t ps = pa + pb;
-                lp = ps[0] + ps[1];
-            } else if constexpr (PRIOR == BF_PRIOR_GAUSSIAN) {
-                const f32x2_t d01 = w01 - pm01, d23 = w23 - pm23;
-                const f32x2_t p2 = __builtin_elementwise_fma(d23 * d23, pi23, (d01 * d01) * pi01);
-                lp = -(p2[0] + p2[1]);
+                if (outp) {
+                    const unsigned long long idx = (unsigned long long)s * a.n + e0[j];
+                    const f32x4_t w4 = {w01[0], w01[1], w23[0], w23[1]};
+                    if (out_dt == BF_DT_BF16) *reinterpret_cast<bf16x4_t*>(outp + idx * 2) = __builtin_convertvector(w4, bf16x4_t);
+                    else if (out_dt == BF_DT_F16) *reinterpret_cast<f16x4_t*>(outp + idx * 2) = __builtin_convertvector(w4, f16x4_t);
+                    else *reinterpret_cast<f32x4_t*>(outp + idx * 4) = w4;
+                }
             }
-            if (outp) {
-                const unsigned long long idx = (unsigned long long)s * a.n + e0;
-                const f32x4_t w4 = {w01[0], w01[1], w23[0], w23[1]};
-                if (out_dt == BF_DT_BF16) *reinterpret_cast<bf16x4_t*>(outp + idx * 2) = __builtin_convertvector(w4, bf16x4_t);
-                else if (out_dt == BF_DT_F16) *reinterpret_cast<f16x4_t*>(outp + idx * 2) = __builtin_convertvector(w4, f16x4_t);
-                else *reinterpret_cast<f32x4_t*>(outp + idx * 4) = w4;
-            }
-            lq = wave_sum(lq);
-            lp = wave_sum(lp);
+            const float lq = wave_sum(-0.5f * (q2[0] + q2[1]));
+            const float lp = wave_sum(p2[0] + p2[1]);
             if (lane == 0) {
                 red[wid][s - s_begin][0] = lp;
                 red[wid][s - s_begin][1] = lq;
@@ -220,12 +232,15 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[kMax
     } else
     for (int s = s_begin; s < s_end; ++s) {
         float lq = 0.f, lp = 0.f;
-        if (nvalid > 0) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            if (nvalid[j] <= 0) continue;
             float z[4], w[4];
-            bf_normal4_dev(g_lo, g_hi, a.sample_base + (uint32_t)s, a.stream, a.k0, a.k1, z);
+            bf_normal4_dev((uint32_t)(e0[j] >> 2), (uint32_t)(e0[j] >> 34), a.sample_base + (uint32_t)s, a.stream, a.k0,
+                           a.k1, z);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                w[i] = fmaf(sigma[i], z[i], mu[i]);
+                w[i] = fmaf(sigma[j][i], z[i], mu[j][i]);
                 const float tq = -0.5f * z[i] * z[i];
                 float tp = 0.f;
                 if constexpr (PRIOR == BF_PRIOR_MIXTURE) {
@@ -238,23 +253,23 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[kMax
                     const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * d);
                     tp = fmaf(kLn2, __builtin_amdgcn_logf(1.0f + e), m);
                 } else if constexpr (PRIOR == BF_PRIOR_GAUSSIAN) {
-                    const float dlt = w[i] - pmu[i];
-                    tp = -(dlt * dlt) * pinv[i];
+                    const float dlt = w[i] - pmu[j][i];
+                    tp = -(dlt * dlt) * pinv[j][i];
                 }
-                if (i < nvalid) {
+                if (i < nvalid[j]) {
                     lq += tq;
                     lp += tp;
                 }
             }
             if (a.out) {
-                const unsigned long long idx = (unsigned long long)s * a.n + e0;
-                const bool vec = a.vec_out && nvalid == 4;
+                const unsigned long long idx = (unsigned long long)s * a.n + e0[j];
+                const bool vec = a.vec_out && nvalid[j] == 4;
                 if constexpr (OUT_DT == OUT_RUNTIME) {
-                    if (a.out_dt == BF_DT_BF16) store4<BF_DT_BF16>(a.out, idx, w, vec, nvalid);
-                    else if (a.out_dt == BF_DT_F16) store4<BF_DT_F16>(a.out, idx, w, vec, nvalid);
-                    else store4<BF_DT_F32>(a.out, idx, w, vec, nvalid);
+                    if (a.out_dt == BF_DT_BF16) store4<BF_DT_BF16>(a.out, idx, w, vec, nvalid[j]);
+                    else if (a.out_dt == BF_DT_F16) store4<BF_DT_F16>(a.out, idx, w, vec, nvalid[j]);
+                    else store4<BF_DT_F32>(a.out, idx, w, vec, nvalid[j]);
                 } else if constexpr (OUT_DT != OUT_NONE) {
-                    store4<OUT_DT>(a.out, idx, w, vec, nvalid);
+                    store4<OUT_DT>(a.out, idx, w, vec, nvalid[j]);
                 }
             }
         }

@@ -90,11 +90,13 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
+    // BF_BENCH_LAYERS=L: run every shape as L stacked layers sharing x (bf_gemm_nt_layers), N per layer
+    const int L = getenv("BF_BENCH_LAYERS") ? atoi(getenv("BF_BENCH_LAYERS")) : 1;
     for (size_t q = 0; q + 4 < shapes.size(); q += 5) {
         const int S = shapes[q], M = shapes[q + 1], N = shapes[q + 2], K = shapes[q + 3], act = shapes[q + 4];
-        const size_t nx = (size_t)S * M * K, nw = (size_t)S * N * K, ny = (size_t)S * M * N;
+        const size_t nx = (size_t)S * M * K, nw = (size_t)L * S * N * K, ny = (size_t)L * S * M * N;
         std::vector<uint16_t> hx(nx), hw(nw);
-        std::vector<float> hb((size_t)S * N);
+        std::vector<float> hb((size_t)L * S * N);
         uint32_t r = 12345;
         auto rnd = [&]() {
             r = r * 1664525u + 1013904223u;
@@ -113,11 +115,15 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(dw, hw.data(), nw * 2, hipMemcpyHostToDevice));
         CK(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
-        const double flop = 2.0 * S * M * (double)N * K;
+        const double flop = 2.0 * L * S * M * (double)N * K;
         const int iters = flop > 2e11 ? 6 : 20;
         auto call = [&](void* y) {
-            if (bf_gemm_nt_act(dx, BF_DT_BF16, (int64_t)M * K, dw, BF_DT_BF16, db, y, BF_DT_BF16, S, M, N, K, act, nullptr)) {
-                printf("bf_gemm_nt_act: %s\n", bf_last_error());
+            const int rc = L > 1 ? bf_gemm_nt_layers(dx, BF_DT_BF16, (int64_t)M * K, dw, BF_DT_BF16, db, y, BF_DT_BF16, L, S, M,
+                                                     N, K, act, nullptr)
+                                 : bf_gemm_nt_act(dx, BF_DT_BF16, (int64_t)M * K, dw, BF_DT_BF16, db, y, BF_DT_BF16, S, M, N, K,
+                                                  act, nullptr);
+            if (rc) {
+                printf("bf_gemm_nt: %s\n", bf_last_error());
                 exit(1);
             }
         };
@@ -127,7 +133,7 @@ int main(int argc, char** argv) {
         CK(hipDeviceSynchronize());
         std::vector<uint16_t> h0(ny), h1(ny);
         CK(hipMemcpy(h0.data(), dy0, ny * 2, hipMemcpyDeviceToHost));
-        printf("S=%d M=%d N=%d K=%d act=%d |", S, M, N, K, act);
+        printf("L=%d S=%d M=%d N=%d K=%d act=%d |", L, S, M, N, K, act);
         for (const Config& c : configs) {
             select(c);
             CK(hipMemset(dy1, 0xFF, ny * 2));
