@@ -66,7 +66,9 @@ SYMBOLS = {
     "bf_kl_grad": (_i, [_tp, _i, _u64, _u32, _vp, _vp, _vp, _vp]),
     "bf_embedding_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i64, _i, _u64, _u32, _u32, _vp]),
     "bf_embedding_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i64, _i64, _i, _u64, _u32, _u32, _vp]),
-    "bf_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, ctypes.c_float, _vp]),
+    "bf_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, ctypes.c_float, _vp]),
+    "bf_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64,
+                              ctypes.c_float, _vp]),
     "bf_add_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "bf_add_layernorm_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i64, _i, ctypes.c_float, _vp]),
     "bf_embed_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i64, ctypes.c_float, _vp]),

@@ -214,15 +214,15 @@ _ATTENTION_NAME = "bayeformers_amd"
 
 def _attention_interface(module, query, key, value, attention_mask, dropout: float = 0.0, scaling=None, **kwargs):
     """Attention function in the HuggingFace `AttentionInterface` convention: query/key/value [B, H, T, D], returns
-    ([B, T, H, D], None).  Runs bf_attention_fwd when it applies (inference, no dropout, head size 64, T a multiple of
-    128, no mask or a key-padding mask); anything else goes to the framework's scaled-dot-product attention."""
+    ([B, T, H, D], None).  Runs bf_attention_fwd (with bf_attention_bwd as its backward when a gradient is needed) when
+    it applies (no dropout, head size 64, T a multiple of 128, no mask or a key-padding mask); anything else goes to the
+    framework's scaled-dot-product attention."""
     from transformers.integrations.sdpa_attention import sdpa_attention_forward
 
     from . import ops
 
-    usable = (dropout == 0.0 and not (torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or
-                                                                    value.requires_grad))
-              and not kwargs.get("is_causal", False) and ops.attention_supported(query, key, value))
+    usable = (dropout == 0.0 and not kwargs.get("is_causal", False) and ops.attention_supported(query, key, value))
+    need_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
     key_mask = mask_off = None
     ready = getattr(attention_mask, "_bf_key_mask", None) if attention_mask is not None else None
     if usable and ready is not None and ready.shape == (query.shape[0], query.shape[2]):
@@ -245,6 +245,8 @@ def _attention_interface(module, query, key, value, attention_mask, dropout: flo
             attention_mask = attention_mask.to(query.dtype)  # the framework's kernels want bool or the query's dtype
         return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
     scale = scaling if scaling is not None else query.shape[-1] ** -0.5
+    if need_grad:  # training: the same kernel, with bf_attention_bwd behind it
+        return ops.AttentionFn.apply(query, key, value, key_mask, mask_off, scale), None
     return ops.attention_forward(query, key, value, key_mask, scale, mask_off), None
 
 

@@ -373,10 +373,18 @@ int bf_embed_layernorm(const int64_t* d_ids, const int64_t* d_type_ids, const in
 }
 
 int bf_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
-                     void* d_out, int dtype, int B, int T, int H, int head_dim, int64_t token_stride, float scaling,
+                     void* d_out, float* d_lse, int dtype, int B, int T, int H, int head_dim, int64_t token_stride,
+                     float scaling, void* stream) {
+    return bf_launch_attention_fwd(d_q, d_k, d_v, d_mask, d_mask_off, d_out, d_lse, dtype, B, T, H, head_dim,
+                                   token_stride, scaling, (hipStream_t)stream);
+}
+
+int bf_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
+                     const void* d_out, const void* d_dout, const float* d_lse, float* d_delta, void* d_dq, void* d_dk,
+                     void* d_dv, int dtype, int B, int T, int H, int head_dim, int64_t token_stride, float scaling,
                      void* stream) {
-    return bf_launch_attention_fwd(d_q, d_k, d_v, d_mask, d_mask_off, d_out, dtype, B, T, H, head_dim, token_stride,
-                                   scaling, (hipStream_t)stream);
+    return bf_launch_attention_bwd(d_q, d_k, d_v, d_mask, d_mask_off, d_out, d_dout, d_lse, d_delta, d_dq, d_dk, d_dv,
+                                   dtype, B, T, H, head_dim, token_stride, scaling, (hipStream_t)stream);
 }
 
 size_t bf_add_layernorm_bwd_workspace_bytes(int64_t rows, int N) { return bf_add_layernorm_bwd_ws_bytes(rows, N); }

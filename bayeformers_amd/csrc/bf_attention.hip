@@ -59,6 +59,7 @@ struct AttnParams {
     const float* mask;  // [B][T] additive, nullable
     const unsigned char* mask_off;  // nullable device flag: non-zero = the mask is all zeros, skip it
     void* out;
+    float* lse;  // nullable: [B][H][T] log2-sum-exp2 of the scaled, masked scores (for the backward kernels)
     long long tok_stride;  // elements between consecutive tokens of q / k / v (H * 64 for packed heads)
     int B, T, H;
     float scale_log2e;  // scaling * log2(e)
@@ -189,6 +190,10 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams 
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
         const float inv = run_sum[qi] > 0.f ? 1.0f / run_sum[qi] : 0.f;
+        // a fully masked query has no probabilities: +inf makes exp2(score - lse) = 0 in the backward kernels
+        if (p.lse && lg == 0)
+            p.lse[((long long)b * p.H + h) * p.T + q0 + qi * 16 + li] =
+                run_sum[qi] > 0.f ? run_max[qi] + __builtin_amdgcn_logf(run_sum[qi]) : INFINITY;
         T* orow = ob + (long long)(q0 + qi * 16 + li) * p.H * HD;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
@@ -201,8 +206,8 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams 
 }  // namespace
 
 int bf_launch_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask,
-                            const unsigned char* d_mask_off, void* d_out, int dtype, int B, int T, int H, int head_dim,
-                            long long token_stride, float scaling, hipStream_t stream) {
+                            const unsigned char* d_mask_off, void* d_out, float* d_lse, int dtype, int B, int T, int H,
+                            int head_dim, long long token_stride, float scaling, hipStream_t stream) {
     if (!d_q || !d_k || !d_v || !d_out) BF_FAIL("bf_attention_fwd: NULL argument");
     if (dtype != BF_DT_BF16 && dtype != BF_DT_F16) BF_FAIL("bf_attention_fwd: dtype must be bf16 or fp16");
     if (head_dim != HD) BF_FAIL("bf_attention_fwd: head size %d (only %d)", head_dim, HD);
@@ -217,6 +222,7 @@ int bf_launch_attention_fwd(const void* d_q, const void* d_k, const void* d_v, c
     p.mask = d_mask;
     p.mask_off = d_mask_off;
     p.out = d_out;
+    p.lse = d_lse;
     p.tok_stride = token_stride;
     p.B = B;
     p.T = T;

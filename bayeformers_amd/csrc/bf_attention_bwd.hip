@@ -1,0 +1,347 @@
+// bf_attention_bwd.hip — backward of bf_attention_fwd (csrc/bf_attention.hip): autograd through the attention
+// block between the Bayesian query/key/value projections and the Bayesian output projection in the reference's
+// training loop (/root/reference/examples/bert_glue.py:239, `loss.backward()` through HF BertSelfAttention).
+//
+// With P = softmax(scale Q K^T + mask) (recomputed from Q, K and the log-sum-exp rows the forward saved),
+// delta_q = sum_d dO[q][d] O[q][d] and dS = P o (dO V^T - delta):
+//     dV = P^T dO,   dK = scale dS^T Q,   dQ = scale dS K.
+// Two kernels, no atomics (deterministic), head size 64, queries / keys in tiles of 128, bf16 or fp16:
+//   * dq kernel — one workgroup per (128 queries, head, sequence), each of its 4 waves owns 32 queries and walks the
+//     key tiles.  Same orientation as the forward: S^T = K Q^T and dP^T = V dO^T on v_mfma_f32_16x16x32 with the key
+//     operand as rows, so a lane holds 4 consecutive keys of ONE query per 16-key block; dS^T of two neighbouring
+//     blocks is the column operand of dQ^T = K^T dS^T, and the K^T fragments come out of a row-major K tile through the
+//     LDS transpose read (ds_read_b64_tr_b16), exactly as V^T does in the forward.  Also leaves delta for the second kernel.
+//   * dk/dv kernel — one workgroup per (128 keys, head, sequence), each of its 8 waves owns 16 keys and walks the query tiles
+//     with the roles swapped: S = Q K^T and dP = dO V^T with the QUERY operand as rows, so a lane holds 4 consecutive
+//     queries of one key; P and dS are the column operands of dV^T = dO^T P and dK^T = Q^T dS, with dO^T / Q^T through
+//     the transpose read.
+// Algorithmic HBM bytes: dq kernel 5 reads (Q, K, V, O, dO) + 1 write; dk/dv kernel 4 reads + 2 writes, x B*T*H*64*2 B.
+#include "bf_common.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int TT = 128;                 // queries / keys per tile
+constexpr int S_ROW = HD * 2;           // 128 B: swizzled image for direct 16-byte fragment reads (chunk ^= row & 7)
+constexpr int P_ROW = HD * 2 + 32;      // 160 B: padded image for the transpose reads (see bf_attention.hip)
+constexpr int S_BYTES = TT * S_ROW;     // 16 KiB
+constexpr int P_BYTES = TT * P_ROW;     // 20 KiB
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+
+template <typename T>
+struct Mfma;
+template <>
+struct Mfma<__bf16> {
+    using frag = bf16x8_t;
+    using half4 = bf16x4_t;
+    static __device__ __forceinline__ f32x4_t run(frag a, frag b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct Mfma<_Float16> {
+    using frag = f16x8_t;
+    using half4 = f16x4_t;
+    static __device__ __forceinline__ f32x4_t run(frag a, frag b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+struct BwdParams {
+    const void* q;
+    const void* k;
+    const void* v;
+    const float* mask;              // [B][T] additive over the keys, nullable
+    const unsigned char* mask_off;  // nullable device flag: non-zero = skip the mask
+    const void* o;                  // [B][T][H][64]
+    const void* dout;               // [B][T][H][64]
+    const float* lse;               // [B][H][T], log2 units
+    float* delta;                   // [B][H][T]
+    void* dq;                       // [B][T][H][64]
+    void* dk;
+    void* dv;
+    long long tok_stride;           // elements between consecutive tokens of q / k / v
+    int B, T, H;
+    float scale, scale_log2e;
+};
+
+// stage a [128][64] tile (rows `row0`.. of a [tokens][stride] tensor) into the swizzled and / or the padded image
+template <typename T, int NT = 256>
+__device__ __forceinline__ void stage_tile(const T* base, long long stride, int row0, char* swz, char* pad, int tid) {
+#pragma unroll
+    for (int i = 0; i < 1024 / NT; ++i) {
+        const int c = tid + NT * i, row = c >> 3, c8 = c & 7;
+        const f32x4_t x = *reinterpret_cast<const f32x4_t*>(base + (long long)(row0 + row) * stride + c8 * 8);
+        if (swz) *reinterpret_cast<f32x4_t*>(swz + row * S_ROW + ((c8 ^ (row & 7)) << 4)) = x;
+        if (pad) *reinterpret_cast<f32x4_t*>(pad + row * P_ROW + (c8 << 4)) = x;
+    }
+}
+
+// row-operand fragment (16 rows x 32 features) of block `blk` of a swizzled tile: lane (row li, k group lg)
+template <typename T>
+__device__ __forceinline__ typename Mfma<T>::frag row_frag(const char* swz, int blk, int dh, int li, int lg) {
+    const int row = blk * 16 + li;
+    return *reinterpret_cast<const typename Mfma<T>::frag*>(swz + row * S_ROW + (((dh * 4 + lg) ^ (row & 7)) << 4));
+}
+
+// transposed fragment: rows = features db*16 + li, k = the 32 tile rows {(2c)*16 + 4 lg + 0..3, (2c+1)*16 + 4 lg + 0..3}
+// of a padded tile, by two LDS transpose reads (the 16 lanes of a group point at a [4 rows][16 features] block)
+template <typename T>
+__device__ __forceinline__ typename Mfma<T>::frag tr_frag(const char* pad, int c, int db, int li, int lg) {
+    const char* blk = pad + (lg * 4 + (li >> 2)) * P_ROW + (db * 16 + (li & 3) * 4) * 2;
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(blk + (2 * c) * 16 * P_ROW));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(blk + (2 * c + 1) * 16 * P_ROW));
+    const s16x8_t ab = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(typename Mfma<T>::frag, ab);
+}
+
+template <typename T>
+__device__ __forceinline__ typename Mfma<T>::frag pack2(const f32x4_t a, const f32x4_t b) {
+    const f32x8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_convertvector(v, typename Mfma<T>::frag);
+}
+
+// ---------------------------------------------------------------------------------------------------- dQ (+ delta)
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attention_bwd_dq_kernel(const BwdParams p) {
+    using frag = typename Mfma<T>::frag;
+    using half4 = typename Mfma<T>::half4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * S_BYTES + P_BYTES + TT * 4];
+    char* const ks = smem;                     // K, swizzled: row operand of S^T
+    char* const vs = smem + S_BYTES;           // V, swizzled: row operand of dP^T
+    char* const kp = smem + 2 * S_BYTES;       // K, padded: K^T through the transpose read
+    float* const ms = reinterpret_cast<float*>(smem + 2 * S_BYTES + P_BYTES);
+    const float* const mask = (p.mask && !(p.mask_off && *p.mask_off)) ? p.mask : nullptr;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int q0 = blockIdx.x * TT + wid * 32, h = blockIdx.y, b = blockIdx.z;
+    const long long hoff = (long long)h * HD;
+    const T* qb = reinterpret_cast<const T*>(p.q) + (long long)b * p.T * p.tok_stride + hoff;
+    const T* kb = reinterpret_cast<const T*>(p.k) + (long long)b * p.T * p.tok_stride + hoff;
+    const T* vb = reinterpret_cast<const T*>(p.v) + (long long)b * p.T * p.tok_stride + hoff;
+    const long long ostride = (long long)p.H * HD;
+    const T* ob = reinterpret_cast<const T*>(p.o) + (long long)b * p.T * ostride + hoff;
+    const T* dob = reinterpret_cast<const T*>(p.dout) + (long long)b * p.T * ostride + hoff;
+
+    // column operands: lane (query li, k group lg) holds 8 consecutive features of its query, per 32-feature half
+    frag qf[2][2], dof[2][2];
+    float delta[2], lse[2];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        const long long q = q0 + qi * 16 + li;
+        float part = 0.f;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+            qf[qi][dh] = *reinterpret_cast<const frag*>(qb + q * p.tok_stride + dh * 32 + lg * 8);
+            dof[qi][dh] = *reinterpret_cast<const frag*>(dob + q * ostride + dh * 32 + lg * 8);
+            const frag of = *reinterpret_cast<const frag*>(ob + q * ostride + dh * 32 + lg * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part = fmaf((float)dof[qi][dh][e], (float)of[e], part);
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        delta[qi] = part;
+        lse[qi] = p.lse[((long long)b * p.H + h) * p.T + q];
+        if (lg == 0) p.delta[((long long)b * p.H + h) * p.T + q] = part;
+    }
+
+    f32x4_t dq[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dq[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int key0 = 0; key0 < p.T; key0 += TT) {
+        if (key0) __syncthreads();
+        stage_tile<T>(kb, p.tok_stride, key0, ks, kp, tid);
+        stage_tile<T>(vb, p.tok_stride, key0, vs, nullptr, tid);
+        if (mask && tid < TT / 4)
+            *reinterpret_cast<f32x4_t*>(ms + tid * 4) =
+                *reinterpret_cast<const f32x4_t*>(mask + (long long)b * p.T + key0 + tid * 4) * 1.4426950408889634f;
+        __syncthreads();
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            // S^T and dP^T [key][query]: lane (query li, group lg) holds keys kbk*16 + 4 lg + 0..3 of each block
+            f32x4_t s[8], dp[8];
+#pragma unroll
+            for (int kbk = 0; kbk < 8; ++kbk) {
+                s[kbk] = dp[kbk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh) {
+                    s[kbk] = Mfma<T>::run(row_frag<T>(ks, kbk, dh, li, lg), qf[qi][dh], s[kbk]);
+                    dp[kbk] = Mfma<T>::run(row_frag<T>(vs, kbk, dh, li, lg), dof[qi][dh], dp[kbk]);
+                }
+            }
+#pragma unroll
+            for (int kbk = 0; kbk < 8; ++kbk) {
+                f32x4_t mk = {0.f, 0.f, 0.f, 0.f};
+                if (mask) mk = *reinterpret_cast<const f32x4_t*>(ms + kbk * 16 + lg * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[kbk][j], p.scale_log2e, mk[j]) - lse[qi]);
+                    s[kbk][j] = pr * (dp[kbk][j] - delta[qi]);  // dS^T
+                }
+            }
+            // dQ^T[d][query] += K^T[d][k] dS^T[k][query], k walking 32 keys at a time in the order the blocks give
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const frag dsf = pack2<T>(s[2 * c], s[2 * c + 1]);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) dq[qi][db] = Mfma<T>::run(tr_frag<T>(kp, c, db, li, lg), dsf, dq[qi][db]);
+            }
+        }
+    }
+    // lane (query li, group lg) holds features db*16 + 4 lg + 0..3 of its query
+    T* dqb = reinterpret_cast<T*>(p.dq) + (long long)b * p.T * ostride + hoff;
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        T* row = dqb + (long long)(q0 + qi * 16 + li) * ostride;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+            *reinterpret_cast<half4*>(row + db * 16 + lg * 4) = __builtin_convertvector(dq[qi][db] * p.scale, half4);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- dK, dV
+// 8 waves, each owning 16 keys of the workgroup's 128 (32 keys per wave need 117 spilled registers).
+template <typename T>
+__global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdParams p) {
+    using frag = typename Mfma<T>::frag;
+    using half4 = typename Mfma<T>::half4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * S_BYTES + 2 * P_BYTES + 2 * TT * 4];
+    char* const qs = smem;                               // Q, swizzled: row operand of S
+    char* const dos = smem + S_BYTES;                    // dO, swizzled: row operand of dP
+    char* const qp = smem + 2 * S_BYTES;                 // Q, padded: Q^T through the transpose read
+    char* const dop = smem + 2 * S_BYTES + P_BYTES;      // dO, padded: dO^T through the transpose read
+    float* const lse_s = reinterpret_cast<float*>(smem + 2 * S_BYTES + 2 * P_BYTES);
+    float* const del_s = lse_s + TT;
+    const float* const mask = (p.mask && !(p.mask_off && *p.mask_off)) ? p.mask : nullptr;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const long long key = blockIdx.x * TT + wid * 16 + li;
+    const long long hoff = (long long)h * HD;
+    const T* qb = reinterpret_cast<const T*>(p.q) + (long long)b * p.T * p.tok_stride + hoff;
+    const T* kb = reinterpret_cast<const T*>(p.k) + (long long)b * p.T * p.tok_stride + hoff;
+    const T* vb = reinterpret_cast<const T*>(p.v) + (long long)b * p.T * p.tok_stride + hoff;
+    const long long ostride = (long long)p.H * HD;
+    const T* dob = reinterpret_cast<const T*>(p.dout) + (long long)b * p.T * ostride + hoff;
+    const float* lse_g = p.lse + ((long long)b * p.H + h) * p.T;
+    const float* del_g = p.delta + ((long long)b * p.H + h) * p.T;
+
+    // column operands: lane (key li, k group lg) holds 8 consecutive features of its key
+    frag kf[2], vf[2];
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh) {
+        kf[dh] = *reinterpret_cast<const frag*>(kb + key * p.tok_stride + dh * 32 + lg * 8);
+        vf[dh] = *reinterpret_cast<const frag*>(vb + key * p.tok_stride + dh * 32 + lg * 8);
+    }
+    const float mk = mask ? mask[(long long)b * p.T + key] * 1.4426950408889634f : 0.f;
+    f32x4_t dk[4], dv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dk[j] = dv[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int q0 = 0; q0 < p.T; q0 += TT) {
+        if (q0) __syncthreads();
+        stage_tile<T, 512>(qb, p.tok_stride, q0, qs, qp, tid);
+        stage_tile<T, 512>(dob, ostride, q0, dos, dop, tid);
+        if (tid < TT / 4) {
+            *reinterpret_cast<f32x4_t*>(lse_s + tid * 4) = *reinterpret_cast<const f32x4_t*>(lse_g + q0 + tid * 4);
+            *reinterpret_cast<f32x4_t*>(del_s + tid * 4) = *reinterpret_cast<const f32x4_t*>(del_g + q0 + tid * 4);
+        }
+        __syncthreads();
+        // S and dP [query][key]: lane (key li, group lg) holds queries qbk*16 + 4 lg + 0..3 of each block
+        f32x4_t s[8], dp[8];
+#pragma unroll
+        for (int qbk = 0; qbk < 8; ++qbk) {
+            s[qbk] = dp[qbk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh) {
+                s[qbk] = Mfma<T>::run(row_frag<T>(qs, qbk, dh, li, lg), kf[dh], s[qbk]);
+                dp[qbk] = Mfma<T>::run(row_frag<T>(dos, qbk, dh, li, lg), vf[dh], dp[qbk]);
+            }
+        }
+#pragma unroll
+        for (int qbk = 0; qbk < 8; ++qbk) {
+            const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_s + qbk * 16 + lg * 4);
+            const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(del_s + qbk * 16 + lg * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pr = __builtin_amdgcn_exp2f(fmaf(s[qbk][j], p.scale_log2e, mk) - l4[j]);
+                s[qbk][j] = pr;                          // P
+                dp[qbk][j] = pr * (dp[qbk][j] - d4[j]);  // dS
+            }
+        }
+        // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const frag pf = pack2<T>(s[2 * c], s[2 * c + 1]);
+            const frag dsf = pack2<T>(dp[2 * c], dp[2 * c + 1]);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                dv[db] = Mfma<T>::run(tr_frag<T>(dop, c, db, li, lg), pf, dv[db]);
+                dk[db] = Mfma<T>::run(tr_frag<T>(qp, c, db, li, lg), dsf, dk[db]);
+            }
+        }
+    }
+    T* dkb = reinterpret_cast<T*>(p.dk) + (long long)b * p.T * ostride + hoff;
+    T* dvb = reinterpret_cast<T*>(p.dv) + (long long)b * p.T * ostride + hoff;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        *reinterpret_cast<half4*>(dkb + key * ostride + db * 16 + lg * 4) = __builtin_convertvector(dk[db] * p.scale, half4);
+        *reinterpret_cast<half4*>(dvb + key * ostride + db * 16 + lg * 4) = __builtin_convertvector(dv[db], half4);
+    }
+}
+
+}  // namespace
+
+int bf_launch_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask,
+                            const unsigned char* d_mask_off, const void* d_out, const void* d_dout, const float* d_lse,
+                            float* d_delta, void* d_dq, void* d_dk, void* d_dv, int dtype, int B, int T, int H,
+                            int head_dim, long long token_stride, float scaling, hipStream_t stream) {
+    if (!d_q || !d_k || !d_v || !d_out || !d_dout || !d_lse || !d_delta || !d_dq || !d_dk || !d_dv)
+        BF_FAIL("bf_attention_bwd: NULL argument");
+    if (dtype != BF_DT_BF16 && dtype != BF_DT_F16) BF_FAIL("bf_attention_bwd: dtype must be bf16 or fp16");
+    if (head_dim != HD) BF_FAIL("bf_attention_bwd: head size %d (only %d)", head_dim, HD);
+    if (B < 1 || H < 1 || T < TT || T % TT) BF_FAIL("bf_attention_bwd: T=%d must be a positive multiple of %d", T, TT);
+    if (B > 65535 || H > 65535) BF_FAIL("bf_attention_bwd: B or H exceeds the grid");
+    if (token_stride < (long long)H * HD || token_stride % 8) BF_FAIL("bf_attention_bwd: bad token stride %lld", token_stride);
+    const uintptr_t al = (uintptr_t)d_q | (uintptr_t)d_k | (uintptr_t)d_v | (uintptr_t)d_out | (uintptr_t)d_dout |
+                         (uintptr_t)d_dq | (uintptr_t)d_dk | (uintptr_t)d_dv | (uintptr_t)d_lse | (uintptr_t)d_delta;
+    if (al & 15) BF_FAIL("bf_attention_bwd: pointers must be 16-byte aligned");
+    if (d_mask && ((uintptr_t)d_mask & 15)) BF_FAIL("bf_attention_bwd: mask must be 16-byte aligned");
+    BwdParams p;
+    p.q = d_q;
+    p.k = d_k;
+    p.v = d_v;
+    p.mask = d_mask;
+    p.mask_off = d_mask_off;
+    p.o = d_out;
+    p.dout = d_dout;
+    p.lse = d_lse;
+    p.delta = d_delta;
+    p.dq = d_dq;
+    p.dk = d_dk;
+    p.dv = d_dv;
+    p.tok_stride = token_stride;
+    p.B = B;
+    p.T = T;
+    p.H = H;
+    p.scale = scaling;
+    p.scale_log2e = scaling * 1.4426950408889634f;
+    const dim3 grid(T / TT, H, B);
+    if (dtype == BF_DT_BF16) {
+        hipLaunchKernelGGL(attention_bwd_dq_kernel<__bf16>, grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(attention_bwd_dkv_kernel<__bf16>, grid, dim3(512), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL(attention_bwd_dq_kernel<_Float16>, grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(attention_bwd_dkv_kernel<_Float16>, grid, dim3(512), 0, stream, p);
+    }
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}

@@ -133,8 +133,12 @@ int bf_launch_embed_layernorm(const long long* d_ids, const long long* d_type_id
                               const void* d_beta, int param_dtype, void* d_out, int dtype, long long rows, int N,
                               int seq_len, long long pos_rows, float eps, hipStream_t stream);
 int bf_launch_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask,
-                            const unsigned char* d_mask_off, void* d_out, int dtype, int B, int T, int H, int head_dim,
-                            long long token_stride, float scaling, hipStream_t stream);
+                            const unsigned char* d_mask_off, void* d_out, float* d_lse, int dtype, int B, int T, int H,
+                            int head_dim, long long token_stride, float scaling, hipStream_t stream);
+int bf_launch_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask,
+                            const unsigned char* d_mask_off, const void* d_out, const void* d_dout, const float* d_lse,
+                            float* d_delta, void* d_dq, void* d_dk, void* d_dv, int dtype, int B, int T, int H,
+                            int head_dim, long long token_stride, float scaling, hipStream_t stream);
 size_t bf_add_layernorm_bwd_ws_bytes(long long rows, int N);
 int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
                                 const void* d_dy, void* d_dz, float* d_dgamma, float* d_dbeta, void* d_workspace,

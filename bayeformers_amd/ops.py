@@ -392,18 +392,56 @@ def attention_supported(q: Tensor, k: Tensor, v: Tensor) -> bool:
 
 
 def attention_forward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tensor], scaling: float,
-                      mask_off: Optional[Tensor] = None) -> Tensor:
+                      mask_off: Optional[Tensor] = None, want_lse: bool = False):
     """softmax(q k^T * scaling + key_mask) v (bf_attention_fwd).  q, k, v: [B, H, T, 64] views as described by
     attention_supported; key_mask: additive fp32 [B, T] or None; mask_off: optional 1-element bool/uint8 device tensor,
-    true = the mask is all zeros (the kernel then skips it).  Returns [B, T, H, 64] contiguous."""
+    true = the mask is all zeros (the kernel then skips it).  Returns [B, T, H, 64] contiguous — and, with want_lse, the
+    [B, H, T] fp32 log-sum-exp rows bf_attention_bwd needs."""
     B, H, T, D = q.shape
     out = torch.empty((B, T, H, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device) if want_lse else None
     _C.check(_C.lib().bf_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                        key_mask.data_ptr() if key_mask is not None else None,
                                        mask_off.data_ptr() if mask_off is not None else None, out.data_ptr(),
+                                       lse.data_ptr() if lse is not None else None,
                                        _TORCH2BF[q.dtype], B, T, H, D, H * D, float(scaling), _stream_ptr()),
              "bf_attention_fwd")
-    return out
+    return (out, lse) if want_lse else out
+
+
+def attention_backward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tensor], mask_off: Optional[Tensor],
+                       out: Tensor, grad_out: Tensor, lse: Tensor, scaling: float):
+    """Gradients of attention_forward (bf_attention_bwd).  Returns (dq, dk, dv), each [B, T, H, 64] contiguous."""
+    B, H, T, D = q.shape
+    go = grad_out if (grad_out.dtype == q.dtype and grad_out.is_contiguous()) else grad_out.to(q.dtype).contiguous()
+    dq, dk, dv = (torch.empty((B, T, H, D), dtype=q.dtype, device=q.device) for _ in range(3))
+    delta = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+    _C.check(_C.lib().bf_attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                       key_mask.data_ptr() if key_mask is not None else None,
+                                       mask_off.data_ptr() if mask_off is not None else None, out.data_ptr(),
+                                       go.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                       dv.data_ptr(), _TORCH2BF[q.dtype], B, T, H, D, H * D, float(scaling),
+                                       _stream_ptr()), "bf_attention_bwd")
+    return dq, dk, dv
+
+
+class AttentionFn(torch.autograd.Function):
+    """bf_attention_fwd with bf_attention_bwd as its backward: nothing but q, k, v, the output and one fp32 row
+    statistic per query is kept; the probabilities are recomputed in the backward kernels."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_mask, mask_off, scaling):
+        out, lse = attention_forward(q, k, v, key_mask, scaling, mask_off, want_lse=True)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.key_mask, ctx.mask_off, ctx.scaling = key_mask, mask_off, scaling
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q, k, v, out, lse = ctx.saved_tensors
+        dq, dk, dv = attention_backward(q, k, v, ctx.key_mask, ctx.mask_off, out, grad_out, lse, ctx.scaling)
+        # q, k, v came in as [B, H, T, 64] views of [B, T, H*64] projections: hand the gradients back in that view
+        return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2), None, None, None
 
 
 def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor, grad_out: Tensor, eps: float):

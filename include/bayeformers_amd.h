@@ -237,11 +237,24 @@ int bf_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_
  * reference runs whatever the wrapped model runs there).  Inference-time forward.  q, k, v: element (b, t, h, d) at
  * ((b*T + t) * token_stride + h*head_dim + d) of `dtype` (BF16 | F16) — i.e. the [B*T, H*head_dim] outputs of the
  * projections as they are; d_mask: additive fp32 [B][T] over the keys (-inf = masked), nullable; d_out: [B][T][H][head_dim]
- * contiguous.  d_mask_off (nullable): one device byte; non-zero means "the mask hides nothing" and the kernel skips it —
+ * contiguous.  d_lse (nullable): [B][H][T] fp32, receives log2(sum_keys 2^(score log2 e)) per query for
+ * bf_attention_bwd.  d_mask_off (nullable): one device byte; non-zero means "the mask hides nothing" and the kernel skips it —
  * lets a caller that builds the additive mask from a padding mask on the device avoid a host round trip to find out.
  * head_dim == 64, T a multiple of 128, 16-byte aligned pointers; anything else is refused (status 1). */
 int bf_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
-                     void* d_out, int dtype, int B, int T, int H, int head_dim, int64_t token_stride, float scaling,
+                     void* d_out, float* d_lse, int dtype, int B, int T, int H, int head_dim, int64_t token_stride,
+                     float scaling, void* stream);
+
+/* Backward of bf_attention_fwd (autograd through the attention block in the training loop,
+ * /root/reference/examples/bert_glue.py:239): given the forward's inputs, its output, the gradient of the output
+ * ([B][T][H][head_dim] contiguous) and the log-sum-exp rows the forward wrote (d_lse, [B][H][T] fp32; pass a buffer as
+ * d_lse to bf_attention_fwd), computes dq, dk, dv ([B][T][H][head_dim] contiguous each).  Two kernels, both
+ * recomputing the probabilities from q, k and d_lse: one workgroup per 128 queries walks the key tiles for dq (and
+ * leaves delta[b][h][t] = sum_d dout * out in d_delta, [B][H][T] fp32 scratch), one per 128 keys walks the query
+ * tiles for dk and dv.  No atomics: deterministic.  Same shape limits as the forward. */
+int bf_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
+                     const void* d_out, const void* d_dout, const float* d_lse, float* d_delta, void* d_dq, void* d_dk,
+                     void* d_dv, int dtype, int B, int T, int H, int head_dim, int64_t token_stride, float scaling,
                      void* stream);
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).

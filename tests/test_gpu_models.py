@@ -529,6 +529,46 @@ def test_attention_kernel_matches_sdpa(dtype, tol, B, T, H, masked):
     assert err <= tol, err
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 3e-2), (torch.float16, 4e-3)])
+@pytest.mark.parametrize("B,T,H", [(3, 128, 2), (2, 384, 3), (1, 256, 12)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attention_backward_matches_sdpa_autograd(dtype, tol, B, T, H, masked):
+    """bf_attention_bwd (through ops.AttentionFn) against torch autograd of scaled_dot_product_attention in fp32 on
+    the same 16-bit inputs: dq, dk, dv, with and without a key-padding mask, one to three key / query tiles."""
+    from bayeformers_amd import ops
+
+    g = torch.Generator().manual_seed(B * 977 + T + H)
+    base = [torch.randn(B, T, H * 64, generator=g).cuda().to(dtype).requires_grad_(True) for _ in range(3)]
+    q, k, v = (t.view(B, T, H, 64).transpose(1, 2) for t in base)
+    go = torch.randn(B, T, H, 64, generator=g).cuda().to(dtype)
+    key_mask = mask_off = None
+    if masked:
+        lens = torch.randint(T // 3, T, (B,), generator=g)
+        lens[0] = T - 1
+        keep = torch.arange(T)[None, :] < lens[:, None]
+        key_mask = torch.zeros(B, T).masked_fill_(~keep, float("-inf")).cuda()
+        mask_off = torch.zeros(1, dtype=torch.bool, device="cuda")
+    out = ops.AttentionFn.apply(q, k, v, key_mask, mask_off, 0.125)
+    out.backward(go)
+    got = [t.grad.float().clone() for t in base]
+    ref_in = [t.detach().float().requires_grad_(True) for t in base]
+    rq, rk, rv = (t.view(B, T, H, 64).transpose(1, 2) for t in ref_in)
+    am = key_mask[:, None, None, :] if masked else None
+    ref = torch.nn.functional.scaled_dot_product_attention(rq, rk, rv, attn_mask=am, scale=0.125)
+    ref.transpose(1, 2).backward(go.float())
+    assert (out.float() - ref.transpose(1, 2)).abs().max().item() <= tol
+    for name, a, r in zip("qkv", got, ref_in):
+        scale = max(1.0, r.grad.abs().max().item())
+        assert (a - r.grad).abs().max().item() <= tol * scale, name
+    # the mask-off flag: a mask that hides nothing may be skipped
+    if masked:
+        zero_mask = torch.zeros(B, T, device="cuda")
+        on = torch.ones(1, dtype=torch.bool, device="cuda")
+        a = ops.attention_forward(q.detach(), k.detach(), v.detach(), zero_mask, 0.125, on)
+        b = ops.attention_forward(q.detach(), k.detach(), v.detach(), None, 0.125)
+        assert torch.equal(a, b)
+
+
 def test_fused_attention_in_bert_matches_framework_attention():
     """fuse_attention(): the HuggingFace attention hook — same logits as the framework's attention up to bf16
     rounding, identical log-probs, with an all-ones mask and with real padding; gradients still flow (fallback)."""
