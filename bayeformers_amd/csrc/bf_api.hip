@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "bf_common.h"
+#include "bf_gemm_params.h"
 #include "bf_philox.h"
 
 static thread_local char g_err[512] = "";
@@ -396,6 +397,13 @@ int bf_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_
                                        workspace_bytes, dtype, rows, N, eps, (hipStream_t)stream);
 }
 
+int bf_gemm_tn(const void* d_a, const void* d_bm, float* d_out, int dtype, int batch, int Mc, int N, int K, void* stream) {
+    if (!d_a || !d_bm || !d_out) BF_FAIL("bf_gemm_tn: null pointer");
+    if (!bf_gemm256_tn_supported(dtype, batch, Mc, N, K, d_a, d_bm, d_out))
+        BF_FAIL("bf_gemm_tn: needs a 16-bit dtype, Mc % 64 == 0, N % 8 == 0, K % 8 == 0 and 16-byte aligned pointers");
+    return bf_launch_gemm256_tn(d_a, d_bm, d_out, dtype, batch, Mc, N, K, (hipStream_t)stream);
+}
+
 // workspace layout of bf_linear_bwd
 struct BwdLayout {
     size_t w, wt, dyt, xt, dw, db, dbp, lp, part, total;
@@ -491,29 +499,37 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
         if ((rc = bf_launch_gemm_nt(d_dy, dtype, (int64_t)M * N, ws + L.wt, dtype, nullptr, d_dx, dtype, S, M, K, N, stream)))
             return rc;
     }
-    // 3. dW_s = dy[s]^T x[s] = (dy^T [N][M]) x (x^T [K][M])^T, fp32 out.  With split-K the M axis is cut into `sp`
-    //    chunks that are transposed (and multiplied) as sp * S batch entries of M / sp rows each.
+    // 3. dW_s = dy[s]^T x[s], fp32 out.  With split-K the M axis is cut into `sp` chunks that are multiplied as sp * S
+    //    batch entries of M / sp rows each.  The TN form of the 256-wide kernel reads dy and x as they are
+    //    (contraction-major, fragments through the LDS transpose read); shapes it does not take go through transposed
+    //    copies and the NT kernel.
     const int sp = x_sample_stride == 0 ? 1 : L.splits;
     const int Mc = M / sp;
-    const bool fused_colsum = bias && bf_transpose_colsum_supported(dtype, S * sp, Mc, N, d_dy, ws + L.dyt);
-    if (fused_colsum) {  // the bias gradient's column sums ride along with the transpose of dy
-        if ((rc = bf_launch_transpose_colsum(d_dy, ws + L.dyt, dtype, S * sp, Mc, N, sp, reinterpret_cast<float*>(ws + L.dbp),
-                                             reinterpret_cast<float*>(ws + L.db), stream)))
+    bool fused_colsum = false;
+    if (x_sample_stride != 0 && bf_gemm256_tn_supported(dtype, S * sp, Mc, N, K, d_dy, d_x, ws + L.dw)) {
+        if ((rc = bf_launch_gemm256_tn(d_dy, d_x, reinterpret_cast<float*>(ws + L.dw), dtype, S * sp, Mc, N, K, stream)))
             return rc;
-    } else if ((rc = bf_launch_transpose(d_dy, ws + L.dyt, es, S * sp, Mc, N, stream))) {
-        return rc;
-    }
-    const int xs_batch = x_sample_stride == 0 ? 1 : S * sp;
-    if ((rc = bf_launch_transpose(d_x, ws + L.xt, es, xs_batch, Mc, K, stream))) return rc;
-    // operands: "x" = dy^T [S][N][M] (stride N*M), "w" = x^T [S][K][M]; a shared x is broadcast by passing it S times
-    if (x_sample_stride == 0) {
-        for (int s = 0; s < S; ++s)
-            if ((rc = bf_launch_gemm_nt(ws + L.dyt + (size_t)s * N * M * es, dtype, 0, ws + L.xt, dtype, nullptr,
-                                        ws + L.dw + (size_t)s * N * K * sizeof(float), BF_DT_F32, 1, N, K, M, stream)))
+    } else {
+        fused_colsum = bias && bf_transpose_colsum_supported(dtype, S * sp, Mc, N, d_dy, ws + L.dyt);
+        if (fused_colsum) {  // the bias gradient's column sums ride along with the transpose of dy
+            if ((rc = bf_launch_transpose_colsum(d_dy, ws + L.dyt, dtype, S * sp, Mc, N, sp, reinterpret_cast<float*>(ws + L.dbp),
+                                                 reinterpret_cast<float*>(ws + L.db), stream)))
                 return rc;
-    } else if ((rc = bf_launch_gemm_nt(ws + L.dyt, dtype, (int64_t)N * Mc, ws + L.xt, dtype, nullptr, ws + L.dw, BF_DT_F32,
-                                       S * sp, N, K, Mc, stream))) {
-        return rc;
+        } else if ((rc = bf_launch_transpose(d_dy, ws + L.dyt, es, S * sp, Mc, N, stream))) {
+            return rc;
+        }
+        const int xs_batch = x_sample_stride == 0 ? 1 : S * sp;
+        if ((rc = bf_launch_transpose(d_x, ws + L.xt, es, xs_batch, Mc, K, stream))) return rc;
+        // operands: "x" = dy^T [S][N][M] (stride N*M), "w" = x^T [S][K][M]; a shared x is broadcast by passing it S times
+        if (x_sample_stride == 0) {
+            for (int s = 0; s < S; ++s)
+                if ((rc = bf_launch_gemm_nt(ws + L.dyt + (size_t)s * N * M * es, dtype, 0, ws + L.xt, dtype, nullptr,
+                                            ws + L.dw + (size_t)s * N * K * sizeof(float), BF_DT_F32, 1, N, K, M, stream)))
+                    return rc;
+        } else if ((rc = bf_launch_gemm_nt(ws + L.dyt, dtype, (int64_t)N * Mc, ws + L.xt, dtype, nullptr, ws + L.dw, BF_DT_F32,
+                                           S * sp, N, K, Mc, stream))) {
+            return rc;
+        }
     }
     // 4. reduce over samples (and split-K partials) with eps regenerated
     if ((rc = bf_launch_param_grad(reinterpret_cast<const float*>(ws + L.dw), weight->d_rho, weight->n, S, sp, seed,

@@ -301,10 +301,21 @@ __device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&ac
 //     retires them together with that step's DMA.
 // Schedule entry (int4): x = (layer, sample) pair index into w / bias / y, y = sample index into x,
 // z = n-tile | height << 24 (height in 32-row units; 0 = no tile), w = first row.
-template <typename T, typename YT>
+// TR = true: the TN form used by the weight-gradient GEMM of the backward pass, dW[n][k] = sum_m dy[m][n] x[m][k]: both
+// operands are CONTRACTION-major in memory — p.x is [batch][K][M] (dy: rows = contraction index m, M = output rows n),
+// p.w is [batch][K][N] (x) — so no transposed copies of dy and x are ever made.  A stage then holds two [64][256]
+// tiles (64 contraction rows of 512 B); their 32-byte granules are XOR-swizzled by the row (again on the DMA source
+// address) and the MFMA fragments come out through the LDS transpose read ds_read_b64_tr_b16: two reads give a lane
+// the 8 contraction values {4 lg + 0..3, 16 + 4 lg + 0..3} of its row — a permutation of the contraction index that is
+// the same for both operands, which is all the MFMA needs.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+
+template <typename T, typename YT, bool TR = false>
 __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams p) {
     using frag = typename Mfma16<T>::frag;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -329,23 +340,42 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
         n0 = (z & 0xFFFFFF) * TN;
         t.xb = reinterpret_cast<const T*>(p.x) + (long long)__builtin_amdgcn_readfirstlane(d.y) * p.x_sstride;
         t.wb = reinterpret_cast<const T*>(p.w) + (long long)s * N * K;
+        if constexpr (TR) {
+            // piece q = i * 8 + wid = contraction rows 2 q, 2 q + 1 of the k-step; lane -> (row, 16-byte position);
+            // the position holds source chunk c = position ^ ((row & 7) << 1); columns past the edge are clamped
+            // (they only feed output rows / columns that are masked on store).  row & 7 does not depend on i, so one
+            // offset per operand serves all four pieces (piece i = + 16 i rows, added to the wave-uniform base)
+            const int r = wid * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ ((r & 7) << 1);
+            t.xo[0] = (unsigned)r * (unsigned)M + (unsigned)min(m0 + c * 8, M - 8);
+            t.wo[0] = (unsigned)r * (unsigned)N + (unsigned)min(n0 + c * 8, N - 8);
+        } else {
 #pragma unroll
-        for (int i = 0; i < XPIECES; ++i)
-            t.xo[i] = (unsigned)min(m0 + (i * 8 + wid) * 8 + prow, M - 1) * (unsigned)K + kc8;
+            for (int i = 0; i < XPIECES; ++i)
+                t.xo[i] = (unsigned)min(m0 + (i * 8 + wid) * 8 + prow, M - 1) * (unsigned)K + kc8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) t.wo[i] = (unsigned)min(n0 + (i * 8 + wid) * 8 + prow, N - 1) * (unsigned)K + kc8;
+            for (int i = 0; i < 4; ++i)
+                t.wo[i] = (unsigned)min(n0 + (i * 8 + wid) * 8 + prow, N - 1) * (unsigned)K + kc8;
+        }
     };
     // piece q = i * 8 + wid covers rows 8 q .. 8 q + 7 of the stage; only the 4 h pieces of a tile's rows are fetched
     // (inside a tile's k-loop h is the compile-time height, so a full-height tile issues its pieces without branches)
     auto stage = [&](const Src& t, int kt, int buf, auto h) {
         char* base = smem + buf * STAGE_BYTES;
-        const T* xk = t.xb + kt * TK;
-        const T* wk = t.wb + kt * TK;
+        const T* xk = t.xb + (TR ? (long long)kt * TK * M : (long long)kt * TK);
+        const T* wk = t.wb + (TR ? (long long)kt * TK * N : (long long)kt * TK);
+        if constexpr (TR) {
 #pragma unroll
-        for (int i = 0; i < XPIECES; ++i)
-            if (i * 8 + 7 < 4 * h || i * 8 + wid < 4 * h) glds16(xk + t.xo[i], base + (i * 8 + wid) * 1024);
+            for (int i = 0; i < 4; ++i) glds16(xk + (long long)i * 16 * M + t.xo[0], base + (i * 8 + wid) * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(wk + t.wo[i], base + X_BYTES + (i * 8 + wid) * 1024);
+            for (int i = 0; i < 4; ++i) glds16(wk + (long long)i * 16 * N + t.wo[0], base + X_BYTES + (i * 8 + wid) * 1024);
+        } else {
+#pragma unroll
+            for (int i = 0; i < XPIECES; ++i)
+                if (i * 8 + 7 < 4 * h || i * 8 + wid < 4 * h) glds16(xk + t.xo[i], base + (i * 8 + wid) * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(wk + t.wo[i], base + X_BYTES + (i * 8 + wid) * 1024);
+        }
     };
 
     const int fsw = (lane >> 1) & 7;
@@ -353,6 +383,28 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
     const int foff1 = (lane & 15) * ROW_BYTES + (((4 + (lane >> 4)) ^ fsw) << 4);
     const int xfrag_base = wm * 16 * ROW_BYTES;  // + j * 32 rows: wave group wm owns blocks wm, wm + 2, ...
     const int wfrag_base = X_BYTES + wn * 64 * ROW_BYTES;
+    // TR: the 16 lanes of a group point at a [4 contraction rows][16 columns] block: lane -> row lg*4 + (li>>2) of the
+    // 16-row group, 8 bytes (li & 3) of the block's 32-byte granule; granule' = granule ^ (row & 7)
+    const int tr_rl = ((lane >> 4) & 1) * 4 + ((lane & 15) >> 2);
+    const int tr_lane = ((lane >> 4) * 4 + ((lane & 15) >> 2)) * 512 + (lane & 3) * 8;
+    // LDS byte addresses of the wave's first w block (wn * 4) and first x block (wm) in buffer 0; the other blocks are
+    // one XOR with a constant away (smem is 1 KiB aligned, the granule index sits alone in address bits 5..8), so the
+    // k-loop holds two address registers instead of twelve
+    // The reads are inline asm: after an LDS DMA hipcc waits vmcnt(0) before any LDS load it can see through the
+    // builtin, which would expose the whole DMA latency in every k-step; the k-loop's own s_waitcnt lgkmcnt(0) /
+    // vmcnt(0) statements order these reads against the DMA and the MFMAs.
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned tr_w0 = lds0 + X_BYTES + tr_lane + (((wn * 4) ^ tr_rl) << 5);
+    const unsigned tr_x0 = lds0 + tr_lane + ((wm ^ tr_rl) << 5);
+    auto tr_read = [&](unsigned a0, int blk_xor, auto half) -> frag {
+        const unsigned a = a0 ^ (unsigned)(blk_xor << 5);
+        constexpr int off = decltype(half)::value * 32 * 512;
+        s16x4_t lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(off));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(off + 16 * 512));
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(frag, v);
+    };
 
     const int nk = K / TK;
     const int4* __restrict__ sched = p.sched + blockIdx.x;
@@ -382,11 +434,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
                 const char* sb = smem + (g & 1) * STAGE_BYTES;
                 dma();
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    wf[i] = *reinterpret_cast<const frag*>(sb + wfrag_base + i * 16 * ROW_BYTES + foff0);
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (TR) wf[i] = tr_read(tr_w0 + (g & 1) * STAGE_BYTES, i, std::integral_constant<int, 0>{});
+                    else wf[i] = *reinterpret_cast<const frag*>(sb + wfrag_base + i * 16 * ROW_BYTES + foff0);
+                }
 #pragma unroll
-                for (int j = 0; j < H; ++j)
-                    xf[j] = *reinterpret_cast<const frag*>(sb + xfrag_base + j * 32 * ROW_BYTES + foff0);
+                for (int j = 0; j < H; ++j) {
+                    if constexpr (TR) xf[j] = tr_read(tr_x0 + (g & 1) * STAGE_BYTES, 2 * j, std::integral_constant<int, 0>{});
+                    else xf[j] = *reinterpret_cast<const frag*>(sb + xfrag_base + j * 32 * ROW_BYTES + foff0);
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -399,11 +455,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    wf[i] = *reinterpret_cast<const frag*>(sb + wfrag_base + i * 16 * ROW_BYTES + foff1);
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (TR) wf[i] = tr_read(tr_w0 + (g & 1) * STAGE_BYTES, i, std::integral_constant<int, 1>{});
+                    else wf[i] = *reinterpret_cast<const frag*>(sb + wfrag_base + i * 16 * ROW_BYTES + foff1);
+                }
 #pragma unroll
-                for (int j = 0; j < H; ++j)
-                    xf[j] = *reinterpret_cast<const frag*>(sb + xfrag_base + j * 32 * ROW_BYTES + foff1);
+                for (int j = 0; j < H; ++j) {
+                    if constexpr (TR) xf[j] = tr_read(tr_x0 + (g & 1) * STAGE_BYTES, 2 * j, std::integral_constant<int, 1>{});
+                    else xf[j] = *reinterpret_cast<const frag*>(sb + xfrag_base + j * 32 * ROW_BYTES + foff1);
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (wm == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -648,6 +708,13 @@ int get_schedule(int S, int layers, int tiles_n, int M, int policy, hipStream_t 
 }
 
 template <typename T>
+int launch256_tn(const GemmParams& p, hipStream_t stream, int grid) {
+    hipLaunchKernelGGL((gemm256_sched_kernel<T, float, true>), dim3(grid), dim3(512), 0, stream, p);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
 int launch256(const GemmParams& p, int y_dtype, hipStream_t stream, int grid) {
     if (y_dtype == BF_DT_F32)
         hipLaunchKernelGGL((gemm256_sched_kernel<T, float>), dim3(grid), dim3(512), 0, stream, p);
@@ -714,4 +781,41 @@ int bf_launch_gemm256(const GemmParams& p0, int w_dtype, int y_dtype, hipStream_
     p.sched_rounds = sc.rounds;
     if (w_dtype == BF_DT_BF16) return launch256<__bf16>(p, y_dtype, stream, sc.grid);
     return launch256<_Float16>(p, y_dtype, stream, sc.grid);
+}
+
+// out[b][n][k] = sum_m a[b][m][n] * bmat[b][m][k]  (fp32 out): the weight-gradient GEMM dW = dy^T x of the backward pass
+// without transposed copies of its operands (kernel form TR).  a: [batch][Mc][Nl], bmat: [batch][Mc][Kl], 16-bit.
+bool bf_gemm256_tn_supported(int dtype, int batch, int Mc, int Nl, int Kl, const void* d_a, const void* d_b,
+                             const void* d_out) {
+    if (dtype != BF_DT_BF16 && dtype != BF_DT_F16) return false;
+    if (batch < 1 || batch > 65535 || Mc < TK || Mc % TK || Nl < 8 || Nl % 8 || Kl < 8 || Kl % 8) return false;
+    if (((uintptr_t)d_a | (uintptr_t)d_b | (uintptr_t)d_out) & 15) return false;
+    if ((long long)Mc * Nl >= (1ll << 32) || (long long)Mc * Kl >= (1ll << 32) || (long long)Nl * Kl >= (1ll << 31)) return false;
+    if (Nl >= (1 << 24) || (Kl + TN - 1) / TN >= (1 << 24)) return false;
+    return true;
+}
+
+int bf_launch_gemm256_tn(const void* d_a, const void* d_b, float* d_out, int dtype, int batch, int Mc, int Nl, int Kl,
+                         hipStream_t stream) {
+    GemmParams p{};
+    p.x = d_a;
+    p.w = d_b;
+    p.bias = nullptr;
+    p.y = d_out;
+    p.x_sstride = (long long)Mc * Nl;
+    p.S = batch;
+    p.M = Nl;
+    p.N = Kl;
+    p.K = Mc;
+    p.act = BF_ACT_NONE;
+    p.layers = 1;
+    p.flags = 0;
+    p.tiles_m = (p.M + TM - 1) / TM;
+    p.tiles_n = (p.N + TN - 1) / TN;
+    Sched sc;
+    if (get_schedule(p.S, 1, p.tiles_n, p.M, BF_SCHED_POLICY, stream, sc)) return 1;
+    p.sched = sc.d_table;
+    p.sched_rounds = sc.rounds;
+    if (dtype == BF_DT_BF16) return launch256_tn<__bf16>(p, stream, sc.grid);
+    return launch256_tn<_Float16>(p, stream, sc.grid);
 }

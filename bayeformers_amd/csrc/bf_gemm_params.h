@@ -25,6 +25,11 @@ struct GemmParams {
 bool bf_gemm256_supported(int x_dtype, int w_dtype, int y_dtype, int S, int M, int N, int K, const void* d_x,
                           const void* d_w, int64_t x_sample_stride);
 int bf_launch_gemm256(const GemmParams& p, int w_dtype, int y_dtype, hipStream_t stream);
+// TN form (contraction-major operands, fp32 out): out[b][n][k] = sum_m a[b][m][n] * b[b][m][k]
+bool bf_gemm256_tn_supported(int dtype, int batch, int Mc, int Nl, int Kl, const void* d_a, const void* d_b,
+                             const void* d_out);
+int bf_launch_gemm256_tn(const void* d_a, const void* d_b, float* d_out, int dtype, int batch, int Mc, int Nl, int Kl,
+                         hipStream_t stream);
 #ifdef BF_DEV
 // round-1 kernel (fixed 256x256 tiles, arithmetic tile order), kept in developer builds as the A/B baseline
 int bf_launch_gemm256_r1(const GemmParams& p, int w_dtype, int y_dtype, hipStream_t stream);

@@ -139,6 +139,20 @@ def gemm_nt_layers(x: Tensor, w: Tensor, bias: Optional[Tensor], L: int, S: int,
     return y
 
 
+def gemm_tn(a: Tensor, b: Tensor) -> Tensor:
+    """out[i] = a[i]^T b[i] in fp32 (bf_gemm_tn): the weight-gradient GEMM dW = dy^T x.  a: [batch, Mc, N],
+    b: [batch, Mc, K], 16-bit; returns [batch, N, K] float32."""
+    _require_device(a, "a")
+    batch, Mc, N = a.shape
+    K = b.shape[2]
+    if b.shape[:2] != a.shape[:2] or a.dtype != b.dtype or not (a.is_contiguous() and b.is_contiguous()):
+        raise _C.BayeFormersAMDError("gemm_tn: a [batch,Mc,N] and b [batch,Mc,K] must be contiguous, same dtype")
+    out = torch.empty((batch, N, K), dtype=torch.float32, device=a.device)
+    _C.check(_C.lib().bf_gemm_tn(a.data_ptr(), b.data_ptr(), out.data_ptr(), _TORCH2BF[a.dtype], batch, Mc, N, K,
+                                 _stream_ptr()), "bf_gemm_tn")
+    return out
+
+
 class LinearPlan:
     """Cached ctypes descriptors of one bnn.Linear (pointers are refreshed per call; structs are reused)."""
 

@@ -135,6 +135,13 @@ int bf_gemm_nt_layers(const void* d_x, int x_dtype, int64_t x_sample_stride, con
                       const float* d_bias, void* d_y, int y_dtype, int L, int S, int M, int N, int K, int act,
                       void* stream);
 
+/* Weight-gradient GEMM of the backward pass (autograd of F.linear, layers/linear.py:104), per batch entry b:
+ *   out[b][n][k] = sum_m a[b][m][n] * bm[b][m][k]        (dW = dy^T x; a = dy [Mc][N], bm = x [Mc][K])
+ * Both operands are read as they lie (contraction-major), products accumulate in fp32, out is fp32 [batch][N][K].
+ * dtype BF_DT_BF16 | BF_DT_F16; needs Mc % 64 == 0, N % 8 == 0, K % 8 == 0 and 16-byte aligned pointers (fails with a
+ * message otherwise: bf_linear_bwd takes its transposed-copy route for such shapes). */
+int bf_gemm_tn(const void* d_a, const void* d_bm, float* d_out, int dtype, int batch, int Mc, int N, int K, void* stream);
+
 /* The host-built tile schedule the 256-wide persistent GEMM kernel runs for a problem of S samples x L layers x
  * [M, N] outputs on n_cu compute units (introspection: the library builds and caches the same table on the first
  * launch of a shape).  The output is cut into tiles of 32 h rows (h = 1..8) x 256 columns; every workgroup b of the

@@ -70,7 +70,7 @@ def test_gradients_match_reference(golden_dir, name, dtype, rtol, planned):
     assert not model.log_prior().requires_grad
 
 
-@pytest.mark.parametrize("M,N,K,S", [(1024, 320, 192, 3), (512, 200, 136, 2), (2048, 768, 768, 2)])
+@pytest.mark.parametrize("M,N,K,S", [(1024, 320, 192, 3), (512, 200, 136, 2), (2048, 768, 768, 2), (448, 776, 264, 2), (500, 96, 72, 2)])
 @pytest.mark.parametrize("planned", [False, True])
 def test_gradients_large_shapes_fast_paths(M, N, K, S, planned):
     """Shapes that take the backward's fast paths (16-byte transposes, split-K weight-gradient GEMM, vectorised
@@ -110,7 +110,9 @@ def test_gradients_large_shapes_fast_paths(M, N, K, S, planned):
     ref = [xr.grad] + [p.grad for p in ps]
     for a, r, what in zip(got, ref, ("dx", "dmu_w", "drho_w", "dmu_b", "drho_b")):
         err = (a.double().cpu() - r).abs().max().item()
-        assert err <= 3e-2 * r.abs().max().item(), (what, err, r.abs().max().item())
+        # dx leaves in bf16 through a bf16 W; the parameter gradients are exact bf16 products accumulated in fp32
+        tol = 3e-2 if what == "dx" else 1e-3
+        assert err <= tol * r.abs().max().item(), (what, err, r.abs().max().item())
 
 
 def test_backward_through_a_small_mlp_is_finite_and_deterministic():

@@ -147,6 +147,39 @@ def test_gemm_detects_transposes():
     assert torch.equal(y, ref)
 
 
+@pytest.mark.parametrize("batch,Mc,N,K", [(1, 64, 8, 8), (2, 128, 256, 256), (3, 192, 200, 136), (1, 1024, 776, 264),
+                                          (2, 64, 1032, 40), (20, 2048, 768, 768), (1, 320, 24, 520)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_gemm_tn_against_torch(batch, Mc, N, K, dt):
+    """bf_gemm_tn (dW = dy^T x, operands read contraction-major through the LDS transpose read) against an fp64 einsum
+    of the same 16-bit operands: exact products, fp32 accumulation."""
+    g = torch.Generator(device="cuda").manual_seed(batch * 7919 + Mc * 31 + N * 7 + K)
+    a = torch.randn(batch, Mc, N, device="cuda", generator=g).to(dt)
+    b = torch.randn(batch, Mc, K, device="cuda", generator=g).to(dt)
+    out = ops.gemm_tn(a, b)
+    ref = torch.einsum("bmn,bmk->bnk", a.double(), b.double())
+    assert out.shape == (batch, N, K) and out.dtype == torch.float32
+    assert (out.double() - ref).abs().max().item() <= 2e-6 * np.sqrt(Mc) * ref.abs().max().item()
+
+
+def test_gemm_tn_detects_transposes_and_rejects_shapes():
+    """Asymmetric operands (a swapped n/k mapping or a permuted contraction index on ONE side cannot pass), and the
+    shapes the kernel does not take fail with a message instead of computing something else."""
+    Mc, N, K = 128, 48, 80
+    a = torch.zeros(1, Mc, N, device="cuda")
+    b = torch.zeros(1, Mc, K, device="cuda")
+    m = torch.arange(Mc, device="cuda").float()
+    a[0] = (m[:, None] == torch.arange(N, device="cuda")[None, :] * 2).float()        # a[m][n] = [m == 2n]
+    b[0] = m[:, None] + torch.arange(K, device="cuda").float()[None, :]               # out[n][k] = 2 n + k (bf16-exact)
+    out = ops.gemm_tn(a.bfloat16(), b.bfloat16())[0]
+    ref = (2 * torch.arange(N).float()[:, None] + torch.arange(K).float()[None, :]).cuda()
+    assert torch.equal(out, ref)
+    for shape in [(1, 96, 8, 8), (1, 64, 12, 8), (1, 64, 8, 20)]:
+        with pytest.raises(bf._C.BayeFormersAMDError, match="bf_gemm_tn"):
+            ops.gemm_tn(torch.zeros(shape[0], shape[1], shape[2], device="cuda").bfloat16(),
+                        torch.zeros(shape[0], shape[1], shape[3], device="cuda").bfloat16())
+
+
 @pytest.mark.parametrize("M", [32, 4096])
 def test_full_size_layer_768(M):
     """BASELINE config 2: bnn.Linear(768, 768), S = 10, default init + mixture prior, x ~ N(0,1) [M, 768]."""
