@@ -55,6 +55,7 @@ SYMBOLS = {
     "bf_reduce_logprob": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "bf_gemm_nt": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "bf_gemm_nt_act": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "bf_gemm_nt_act_pre": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "bf_gemm_nt_layers": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "bf_gemm_tn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "bf_gemm_schedule": (_sz, [_i, _i, _i, _i, _i, _vp, _sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
@@ -62,8 +63,9 @@ SYMBOLS = {
     "bf_linear_fwd": (_i, [_vp, _i, _i64, _tp, _tp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u32, _vp, _vp, _sz, _vp]),
     "bf_linear_fwd_ws_workspace_bytes": (_sz, [_i, _i]),
     "bf_linear_fwd_ws": (_i, [_vp, _i, _i64, _tp, _tp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u32, _i, _vp, _vp, _sz, _vp]),
-    "bf_linear_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
-    "bf_linear_bwd": (_i, [_vp, _i64, _vp, _i, _tp, _tp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u64, _u32, _vp, _sz, _vp]),
+    "bf_linear_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "bf_linear_bwd": (_i, [_vp, _i64, _vp, _i, _tp, _tp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u64, _u32, _i, _vp,
+                           _vp, _sz, _vp]),
     "bf_kl_grad": (_i, [_tp, _i, _u64, _u32, _vp, _vp, _vp, _vp]),
     "bf_embedding_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i64, _i, _u64, _u32, _u32, _vp]),
     "bf_embedding_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i64, _i64, _i, _u64, _u32, _u32, _vp]),

@@ -218,6 +218,16 @@ int bf_gemm_nt_act(const void* d_x, int x_dtype, int64_t x_sample_stride, const 
                              (hipStream_t)stream, act);
 }
 
+int bf_gemm_nt_act_pre(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
+                       const float* d_bias, void* d_y, void* d_pre, int y_dtype, int S, int M, int N, int K, int act,
+                       void* stream) {
+    if (act != BF_ACT_NONE && act != BF_ACT_GELU) BF_FAIL("bf_gemm_nt_act_pre: unknown activation %d", act);
+    if (!d_pre) BF_FAIL("bf_gemm_nt_act_pre: d_pre is NULL");
+    ProfScope prof(BF_PROF_GEMM, 2.0 * S * M * (double)N * K, (hipStream_t)stream);
+    return bf_launch_gemm_nt(d_x, x_dtype, x_sample_stride, d_w, w_dtype, d_bias, d_y, y_dtype, S, M, N, K,
+                             (hipStream_t)stream, act, 1, d_pre);
+}
+
 int bf_gemm_nt_layers(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
                       const float* d_bias, void* d_y, int y_dtype, int L, int S, int M, int N, int K, int act,
                       void* stream) {
@@ -406,7 +416,7 @@ int bf_gemm_tn(const void* d_a, const void* d_bm, float* d_out, int dtype, int b
 
 // workspace layout of bf_linear_bwd
 struct BwdLayout {
-    size_t w, wt, dyt, xt, dw, db, dbp, lp, part, total;
+    size_t w, wt, dyt, xt, dw, db, dbp, dpre, lp, part, total;
     int splits;
 };
 
@@ -430,7 +440,7 @@ static int bwd_splits(int S, int M, int N, int K, int dtype) {
     return best;
 }
 
-static BwdLayout bwd_layout(int S, int M, int N, int K, int has_bias, int dtype) {
+static BwdLayout bwd_layout(int S, int M, int N, int K, int has_bias, int dtype, int act = BF_ACT_NONE) {
     const size_t es = bf_dtype_size(dtype);
     BwdLayout L;
     L.splits = bwd_splits(S, M, N, K, dtype);
@@ -445,8 +455,11 @@ static BwdLayout bwd_layout(int S, int M, int N, int K, int has_bias, int dtype)
     L.dyt = take((size_t)S * N * M * es);
     L.xt = take((size_t)S * K * M * es);
     L.dw = take((size_t)L.splits * S * N * K * sizeof(float));
-    L.db = take(has_bias ? (size_t)S * N * sizeof(float) : 0);
-    L.dbp = take(has_bias ? bf_colsum_workspace_bytes(S, M, N) : 0);
+    // a fused activation's backward writes dpre = dy * act'(pre) here and its column sums into db (bias or not)
+    const bool sums = has_bias || act != BF_ACT_NONE;
+    L.db = take(sums ? (size_t)S * N * sizeof(float) : 0);
+    L.dbp = take(sums ? bf_colsum_workspace_bytes(S, M, N) : 0);
+    L.dpre = take(act != BF_ACT_NONE ? (size_t)S * M * N * es : 0);
     L.lp = take((size_t)S * 2 * sizeof(double));
     bf_tensor_t t;
     memset(&t, 0, sizeof(t));
@@ -456,31 +469,43 @@ static BwdLayout bwd_layout(int S, int M, int N, int K, int has_bias, int dtype)
     return L;
 }
 
-size_t bf_linear_bwd_workspace_bytes(int S, int M, int N, int K, int has_bias, int dtype) {
+size_t bf_linear_bwd_workspace_bytes(int S, int M, int N, int K, int has_bias, int dtype, int act) {
     if (S < 1 || M < 1 || N < 1 || K < 1) return 0;
-    return bwd_layout(S, M, N, K, has_bias, dtype).total;
+    return bwd_layout(S, M, N, K, has_bias, dtype, act).total;
 }
 
 int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, int dtype, const bf_tensor_t* weight,
                   const bf_tensor_t* bias, void* d_dx, float* d_dmu_w, float* d_drho_w, float* d_dmu_b,
-                  float* d_drho_b, int S, int M, int N, int K, uint64_t seed, uint32_t sample_base, void* d_workspace,
-                  size_t workspace_bytes, void* stream_) {
+                  float* d_drho_b, int S, int M, int N, int K, uint64_t seed, uint32_t sample_base, int act,
+                  const void* d_act_pre, void* d_workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d_x || !d_dy || !weight || !d_drho_w) BF_FAIL("bf_linear_bwd: NULL argument");
+    if (act != BF_ACT_NONE && act != BF_ACT_GELU) BF_FAIL("bf_linear_bwd: unknown activation %d", act);
+    if (act != BF_ACT_NONE && !d_act_pre) BF_FAIL("bf_linear_bwd: a fused activation needs the forward's pre-activation");
     if (S < 1 || M < 1 || N < 1 || K < 1) BF_FAIL("bf_linear_bwd: bad shape S=%d M=%d N=%d K=%d", S, M, N, K);
     if (weight->n != (uint64_t)N * (uint64_t)K) BF_FAIL("bf_linear_bwd: weight.n != N*K");
     if (bias && (bias->n != (uint64_t)N || !d_drho_b)) BF_FAIL("bf_linear_bwd: bad bias arguments");
     if (dtype < BF_DT_F32 || dtype > BF_DT_F16) BF_FAIL("bf_linear_bwd: bad dtype %d", dtype);
     if (x_sample_stride != 0 && x_sample_stride != (int64_t)M * K) BF_FAIL("bf_linear_bwd: x_sample_stride must be 0 or M*K");
-    const BwdLayout L = bwd_layout(S, M, N, K, bias != nullptr, dtype);
+    const BwdLayout L = bwd_layout(S, M, N, K, bias != nullptr, dtype, act);
     if (!d_workspace || workspace_bytes < L.total)
         BF_FAIL("bf_linear_bwd: workspace too small (%zu < %zu bytes)", workspace_bytes, L.total);
     char* ws = reinterpret_cast<char*>(d_workspace);
     const int es = (int)bf_dtype_size(dtype);
 
+    int rc = 0;
+    // 0. the forward applied act() in its GEMM epilogue: d_dy is the gradient of act(y); dy = d_dy * act'(y_pre), and the
+    //    bias gradient's column sums of dy come out of the same pass
+    bool fused_colsum = false;
+    if (act != BF_ACT_NONE) {
+        if ((rc = bf_launch_gelu_bwd_colsum(d_dy, d_act_pre, ws + L.dpre, dtype, S, M, N, reinterpret_cast<float*>(ws + L.dbp),
+                                            reinterpret_cast<float*>(ws + L.db), stream)))
+            return rc;
+        d_dy = ws + L.dpre;
+        fused_colsum = true;
+    }
     // 1. W_s: the forward's own samples if the caller still holds them (weight->d_sample_out, same dtype), else
     //    regenerated from the same counters; no prior term needed
-    int rc = 0;
     const char* w_s = ws + L.w;
     if (weight->d_sample_out && weight->out_dtype == dtype) {
         w_s = reinterpret_cast<const char*>(weight->d_sample_out);
@@ -505,13 +530,13 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
     //    copies and the NT kernel.
     const int sp = x_sample_stride == 0 ? 1 : L.splits;
     const int Mc = M / sp;
-    bool fused_colsum = false;
     if (x_sample_stride != 0 && bf_gemm256_tn_supported(dtype, S * sp, Mc, N, K, d_dy, d_x, ws + L.dw)) {
         if ((rc = bf_launch_gemm256_tn(d_dy, d_x, reinterpret_cast<float*>(ws + L.dw), dtype, S * sp, Mc, N, K, stream)))
             return rc;
     } else {
-        fused_colsum = bias && bf_transpose_colsum_supported(dtype, S * sp, Mc, N, d_dy, ws + L.dyt);
-        if (fused_colsum) {  // the bias gradient's column sums ride along with the transpose of dy
+        const bool with_t = !fused_colsum && bias && bf_transpose_colsum_supported(dtype, S * sp, Mc, N, d_dy, ws + L.dyt);
+        if (with_t) {  // the bias gradient's column sums ride along with the transpose of dy
+            fused_colsum = true;
             if ((rc = bf_launch_transpose_colsum(d_dy, ws + L.dyt, dtype, S * sp, Mc, N, sp, reinterpret_cast<float*>(ws + L.dbp),
                                                  reinterpret_cast<float*>(ws + L.db), stream)))
                 return rc;

@@ -13,6 +13,8 @@
 // Kernels here are the glue around the two MFMA GEMMs (bf_gemm_nt): a batched 16-bit transpose (the NT kernel wants
 // both operands contiguous along the reduction axis), the column sum for the bias, and the eps-weighted reduction
 // over samples.  All HBM-bound streaming kernels.
+#include <algorithm>
+
 #include "bf_common.h"
 #include "bf_philox.h"
 
@@ -138,6 +140,64 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
             o[i] = (sh[0][threadIdx.x][i] + sh[1][threadIdx.x][i]) + (sh[2][threadIdx.x][i] + sh[3][threadIdx.x][i]);
     }
 }
+// The backward of a GELU fused into the forward GEMM's epilogue, merged with the bias gradient of that layer:
+// dpre = dy * gelu'(pre) (fp32 arithmetic, rounded to T as the unfused GeluBackward would) and the column sums of the
+// ROUNDED dpre (what the weight-gradient GEMM consumes).  Same blocking as colsum_partial_kernel.
+template <typename T, typename V8>
+__global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const T* __restrict__ dy, const T* __restrict__ pre,
+                                                              T* __restrict__ dpre, float* __restrict__ partial, int M,
+                                                              int N, int chunks) {
+    __shared__ float sh[4][64][8];
+    const int s = blockIdx.z, ch = blockIdx.y, cv = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const long long base = (long long)s * M * N;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int m1 = min(M, (ch + 1) * kColsumRows);
+    if (cv * 8 < N) {
+        for (int m = ch * kColsumRows + rl; m < m1; m += 4) {
+            const long long o = base + (long long)m * N + cv * 8;
+            const V8 g = __builtin_nontemporal_load(reinterpret_cast<const V8*>(dy + o));
+            const V8 x = __builtin_nontemporal_load(reinterpret_cast<const V8*>(pre + o));
+            V8 r;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                r[i] = (T)((float)g[i] * bf_gelu_grad((float)x[i]));
+                acc[i] += (float)r[i];
+            }
+            *reinterpret_cast<V8*>(dpre + o) = r;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sh[rl][threadIdx.x & 63][i] = acc[i];
+    __syncthreads();
+    if (rl == 0 && cv * 8 < N) {
+        float* o = partial + ((long long)s * chunks + ch) * N + cv * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            o[i] = (sh[0][threadIdx.x][i] + sh[1][threadIdx.x][i]) + (sh[2][threadIdx.x][i] + sh[3][threadIdx.x][i]);
+    }
+}
+
+template <typename T, typename V8>
+__global__ __launch_bounds__(256) void gelu_kernel(const T* __restrict__ in, T* __restrict__ out, unsigned long long n8) {
+    for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < n8; i += (unsigned long long)gridDim.x * 256ull) {
+        const V8 x = reinterpret_cast<const V8*>(in)[i];
+        V8 r;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const f32x2_t v = bf_gelu2(f32x2_t{(float)x[j], (float)x[j + 1]});
+            r[j] = (T)v[0];
+            r[j + 1] = (T)v[1];
+        }
+        reinterpret_cast<V8*>(out)[i] = r;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_tail_kernel(const T* __restrict__ in, T* __restrict__ out, unsigned long long lo,
+                                                        unsigned long long n) {
+    const unsigned long long i = lo + blockIdx.x * 256ull + threadIdx.x;
+    if (i < n) out[i] = (T)bf_gelu((float)in[i]);
+}
+
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                             int N, int chunks) {
     // block = 64 columns x 4 chunk lanes (the chunk axis is 64-128 long: one serial thread per column was
@@ -444,6 +504,57 @@ int bf_launch_transpose_colsum(const void* d_in, void* d_out, int dtype, int bat
     const int groups = batch / batch_per_group, chunks = batch_per_group * (rows / 64);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 63) / 64, groups), dim3(256), 0, stream, d_partial, d_out_sums,
                        cols, chunks);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int bf_launch_gelu(const void* d_in, void* d_out, int dtype, uint64_t n, hipStream_t stream) {
+    if (!d_in || !d_out) BF_FAIL("bf_gelu: NULL argument");
+    const bool vec = (((uintptr_t)d_in | (uintptr_t)d_out) & 15) == 0 && dtype != BF_DT_F32;
+    const unsigned long long n8 = vec ? n / 8 : 0;
+    if (n8) {
+        const unsigned grid = (unsigned)std::min<unsigned long long>((n8 + 255) / 256, 256ull * 16);
+        if (dtype == BF_DT_BF16)
+            hipLaunchKernelGGL((gelu_kernel<__bf16, bf16x8_t>), dim3(grid), dim3(256), 0, stream, (const __bf16*)d_in,
+                               (__bf16*)d_out, n8);
+        else
+            hipLaunchKernelGGL((gelu_kernel<_Float16, f16x8_t>), dim3(grid), dim3(256), 0, stream, (const _Float16*)d_in,
+                               (_Float16*)d_out, n8);
+    }
+    const unsigned long long lo = n8 * 8;
+    if (lo < n) {
+        const unsigned grid = (unsigned)((n - lo + 255) / 256);
+        if (dtype == BF_DT_BF16)
+            hipLaunchKernelGGL(gelu_tail_kernel<__bf16>, dim3(grid), dim3(256), 0, stream, (const __bf16*)d_in, (__bf16*)d_out, lo, n);
+        else if (dtype == BF_DT_F16)
+            hipLaunchKernelGGL(gelu_tail_kernel<_Float16>, dim3(grid), dim3(256), 0, stream, (const _Float16*)d_in,
+                               (_Float16*)d_out, lo, n);
+        else
+            hipLaunchKernelGGL(gelu_tail_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)d_in, (float*)d_out, lo, n);
+    }
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+bool bf_gelu_bwd_colsum_supported(int dtype, int S, int M, int N, const void* d_dy, const void* d_pre, const void* d_out) {
+    return dtype != BF_DT_F32 && N % 8 == 0 && S >= 1 && S <= 65535 && M >= 1 &&
+           (((uintptr_t)d_dy | (uintptr_t)d_pre | (uintptr_t)d_out) & 15) == 0;
+}
+
+int bf_launch_gelu_bwd_colsum(const void* d_dy, const void* d_pre, void* d_dpre, int dtype, int S, int M, int N,
+                              float* d_partial, float* d_colsum, hipStream_t stream) {
+    if (!d_dy || !d_pre || !d_dpre || !d_partial || !d_colsum) BF_FAIL("bf_gelu_bwd_colsum: NULL argument");
+    if (!bf_gelu_bwd_colsum_supported(dtype, S, M, N, d_dy, d_pre, d_dpre))
+        BF_FAIL("bf_gelu_bwd_colsum: needs 16-bit tensors, N %% 8 == 0 and 16-byte aligned pointers");
+    const int chunks = (M + kColsumRows - 1) / kColsumRows;
+    dim3 pgrid((N / 8 + 63) / 64, chunks, S);
+    if (dtype == BF_DT_BF16)
+        hipLaunchKernelGGL((gelu_bwd_colsum_kernel<__bf16, bf16x8_t>), pgrid, dim3(256), 0, stream, (const __bf16*)d_dy,
+                           (const __bf16*)d_pre, (__bf16*)d_dpre, d_partial, M, N, chunks);
+    else
+        hipLaunchKernelGGL((gelu_bwd_colsum_kernel<_Float16, f16x8_t>), pgrid, dim3(256), 0, stream, (const _Float16*)d_dy,
+                           (const _Float16*)d_pre, (_Float16*)d_dpre, d_partial, M, N, chunks);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64, S), dim3(256), 0, stream, d_partial, d_colsum, N, chunks);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -50,7 +50,14 @@ int bf_launch_reduce_groups(const double* d_partials, const uint32_t* d_rows, in
                             hipStream_t stream);
 int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
                       const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, hipStream_t stream,
-                      int act = BF_ACT_NONE, int layers = 1);
+                      int act = BF_ACT_NONE, int layers = 1, void* d_pre = nullptr);
+// out = gelu(in) elementwise (16-bit or fp32 tensors of n elements)
+int bf_launch_gelu(const void* d_in, void* d_out, int dtype, uint64_t n, hipStream_t stream);
+// dpre = dy * gelu'(pre) elementwise on [S][M][N] 16-bit tensors, with the column sums of dpre per sample
+// (d_colsum [S][N] fp32; d_partial: bf_colsum_workspace_bytes of scratch)
+bool bf_gelu_bwd_colsum_supported(int dtype, int S, int M, int N, const void* d_dy, const void* d_pre, const void* d_out);
+int bf_launch_gelu_bwd_colsum(const void* d_dy, const void* d_pre, void* d_dpre, int dtype, int S, int M, int N,
+                              float* d_partial, float* d_colsum, hipStream_t stream);
 
 // erf-GELU x/2 (1 + erf(x / sqrt 2)), the activation of HF BERT's intermediate layer, on the fp32 accumulators.
 // With q = 1/2 erfc(|x| / sqrt 2) = Phi(-|x|):  gelu(x) = x (1 - q) for x >= 0 and x q for x < 0, i.e. in one
@@ -83,6 +90,19 @@ __device__ __forceinline__ f32x2_t bf_gelu2(f32x2_t x) {
     p = __builtin_elementwise_fma(t, p, (f32x2_t)(-0.5f * 0.254829592f));
     const f32x2_t r = __builtin_elementwise_fma(p * t, e, (f32x2_t)(0.5f));  // 1/2 - q
     return __builtin_elementwise_fma(ax, r, hx);
+}
+// d/dx of the erf-GELU: Phi(x) + x phi(x), from the same erfc approximation (r = 1/2 - q = Phi(|x|) - 1/2):
+// Phi(x) = 1/2 + sign(x) r,  phi(x) = exp(-x^2/2) / sqrt(2 pi).
+__device__ __forceinline__ float bf_gelu_grad(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752f, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(x * -0.72134752044448170f * x);
+    float p = fmaf(t, -0.5f * 1.061405429f, -0.5f * -1.453152027f);
+    p = fmaf(t, p, -0.5f * 1.421413741f);
+    p = fmaf(t, p, -0.5f * -0.284496736f);
+    p = fmaf(t, p, -0.5f * 0.254829592f);
+    const float r = fmaf(p * t, e, 0.5f);
+    return fmaf(x * 0.39894228040143268f, e, 0.5f + copysignf(r, x));
 }
 __device__ __forceinline__ float bf_gelu(float x) {
     const f32x2_t v = {x, x};

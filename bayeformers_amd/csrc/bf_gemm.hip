@@ -285,8 +285,26 @@ int launch_16_xy(const GemmParams& p, int x_dtype, int y_dtype, int t_dtype, boo
 
 int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
                       const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, hipStream_t stream,
-                      int act, int layers) {
+                      int act, int layers, void* d_pre) {
     if (layers < 1) BF_FAIL("bf_gemm_nt: layers must be >= 1 (got %d)", layers);
+    if (d_pre) {
+        // pre-activation wanted next to act(y) (the forward of a training step): one launch with two outputs when the
+        // 256-wide kernel takes the shape, else the GEMM into d_pre followed by the elementwise activation
+        const bool fast = layers == 1 && gemm_variant() != 0 && w_dtype != BF_DT_F32 && (long long)M * N >= 128 * 128 &&
+                          ((uintptr_t)d_bias & 15) == 0 && ((uintptr_t)d_pre & 15) == 0 &&
+                          bf_gemm256_supported(x_dtype, w_dtype, y_dtype, S, M, N, K, d_x, d_w, x_sample_stride);
+        if (!fast || act == BF_ACT_NONE) {
+            int rc = bf_launch_gemm_nt(d_x, x_dtype, x_sample_stride, d_w, w_dtype, d_bias, d_pre, y_dtype, S, M, N, K,
+                                       stream, BF_ACT_NONE, layers, nullptr);
+            if (rc) return rc;
+            if (act == BF_ACT_NONE)
+                BF_HIP_CHECK(hipMemcpyAsync(d_y, d_pre, (size_t)layers * S * M * N * bf_dtype_size(y_dtype),
+                                            hipMemcpyDeviceToDevice, stream));
+            else
+                rc = bf_launch_gelu(d_pre, d_y, y_dtype, (uint64_t)layers * S * M * N, stream);
+            return rc;
+        }
+    }
     if (layers > 1) {
         // L layers sharing x: one launch of the 256x256 kernel when it applies, else one launch per layer
         const bool fast = gemm_variant() != 0 && w_dtype != BF_DT_F32 && (long long)M * N >= 128 * 128 &&
@@ -298,7 +316,7 @@ int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, con
                 const int rc = bf_launch_gemm_nt(
                     d_x, x_dtype, x_sample_stride, (const char*)d_w + (size_t)l * S * N * K * ws, w_dtype,
                     d_bias ? d_bias + (size_t)l * S * N : nullptr, (char*)d_y + (size_t)l * S * M * N * ys, y_dtype, S,
-                    M, N, K, stream, act, 1);
+                    M, N, K, stream, act, 1, nullptr);
                 if (rc) return rc;
             }
             return 0;
@@ -312,6 +330,7 @@ int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, con
     p.w = d_w;
     p.bias = d_bias;
     p.y = d_y;
+    p.y2 = d_pre;
     p.x_sstride = x_sample_stride;
     p.S = S;
     p.M = M;

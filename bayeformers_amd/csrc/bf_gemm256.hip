@@ -202,6 +202,23 @@ __device__ __forceinline__ void epilogue_pipelined(char* region, const f32x4_t (
 
 #endif  // BF_DEV
 
+// act() of a 16-byte chunk of YT outputs (8 x 16-bit or 4 x fp32), computed in fp32
+template <typename YT>
+__device__ __forceinline__ f32x4_t act_chunk(f32x4_t c, int act) {
+    if constexpr (sizeof(YT) == 4) {
+        return bf_apply_act(c, act);
+    } else {
+        typedef __attribute__((ext_vector_type(8))) YT yt8;
+        typedef __attribute__((ext_vector_type(4))) YT yt4;
+        const yt8 h = __builtin_bit_cast(yt8, c);
+        const f32x4_t lo = bf_apply_act(f32x4_t{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}, act);
+        const f32x4_t hi = bf_apply_act(f32x4_t{(float)h[4], (float)h[5], (float)h[6], (float)h[7]}, act);
+        const yt4 a = __builtin_convertvector(lo, yt4), b = __builtin_convertvector(hi, yt4);
+        const yt8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        return __builtin_bit_cast(f32x4_t, r);
+    }
+}
+
 // Epilogue: accumulators -> LDS as row-major rows of YT, in passes of 64 rows (32 for fp32 outputs) through the
 // just-consumed stage buffer -> whole-row 16-byte global stores.  A lane's fragment registers are 4 consecutive n of
 // one m (8 B for 16-bit outputs): written with ds_write_b64 into rows padded by 16 B (2-way bank aliasing only), then
@@ -211,8 +228,8 @@ __device__ __forceinline__ void epilogue_pipelined(char* region, const f32x4_t (
 // write in every pass.  Wave group 0 leaves the k-loop one slot before group 1: `rejoin` pairs with group 1's last
 // k-step barrier.
 template <typename YT, int H>
-__device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&acc)[4][H], YT* y, int m0, int m_end,
-                                                int n0, int N, int wm, int wn, int wid, int lane, int act) {
+__device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&acc)[4][H], YT* y, YT* y2, int m0,
+                                                int m_end, int n0, int N, int wm, int wn, int wid, int lane, int act) {
     constexpr int ROW = TN * (int)sizeof(YT) + 16;
     constexpr int PASS_ROWS = sizeof(YT) == 4 ? 32 : 64;
     constexpr int MBP = PASS_ROWS / 32;
@@ -240,7 +257,9 @@ __device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&ac
             if (mb < H) {
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) {
-                    const f32x4_t v = bf_apply_act(acc[nb][mb < H ? mb : 0], act);
+                    // with a pre-activation output the rows go through LDS unactivated (in YT, as an unfused
+                    // Linear -> GELU would round them) and the activation is applied to the row chunks on their way out
+                    const f32x4_t v = y2 ? acc[nb][mb < H ? mb : 0] : bf_apply_act(acc[nb][mb < H ? mb : 0], act);
                     char* dst = region + wr_off + t * 32 * ROW + nb * 16 * (int)sizeof(YT);
                     if constexpr (sizeof(YT) == 4)
                         *reinterpret_cast<f32x4_t*>(dst) = v;
@@ -263,7 +282,19 @@ __device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&ac
         for (int it = 0; it < INSTS; ++it) {
             const int m = mrow + it * ROWS_PER_INST;
             if (m < m_end && n_ok) {
-                const f32x4_t v = rows[it];
+                f32x4_t v = rows[it];
+                if (y2) {
+                    YT* o2 = y2 + (unsigned)(m * N + n);
+                    if (n_full) {
+                        if (NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(o2));
+                        else *reinterpret_cast<f32x4_t*>(o2) = v;
+                    } else {
+                        const YT* e = reinterpret_cast<const YT*>(&v);
+                        for (int j = 0; j < EPC; ++j)
+                            if (n + j < N) o2[j] = e[j];
+                    }
+                    v = act_chunk<YT>(v, act);
+                }
                 YT* o = y + (unsigned)(m * N + n);
                 if (n_full) {
                     // streaming store: y is not re-read by this kernel, keep it from evicting operand panels in L2
@@ -519,7 +550,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
                                           lane, p.act, skip);
             else if (!skip)
 #endif
-            epilogue_passes<YT, H>(smem + ((g - 1) & 1) * STAGE_BYTES, acc, y, m0, m_end, n0, N, wm, wn, wid, lane, p.act);
+            epilogue_passes<YT, H>(smem + ((g - 1) & 1) * STAGE_BYTES, acc, y,
+                                   p.y2 ? reinterpret_cast<YT*>(p.y2) + (long long)s * M * N : nullptr, m0, m_end, n0, N, wm,
+                                   wn, wid, lane, p.act);
         };
         switch (h) {
             case 8: body(std::integral_constant<int, 8>{}); break;

@@ -8,6 +8,7 @@ struct GemmParams {
     const void* w;
     const float* bias;
     void* y;
+    void* y2;  // 256-wide kernel only: when set, act(y) goes to y and the pre-activation y (same dtype) to y2
     long long x_sstride;  // elements between samples of x (0 = one x shared by all samples)
     int S, M, N, K;
     int tiles_m, tiles_n;

@@ -26,7 +26,9 @@ from ..parameters.initializations import DEFAULT_UNIFORM, Initialization
 
 def _backward(ctx, grad):
     """Shared backward of the per-layer and the planned forward: one bf_linear_bwd call."""
-    (x,) = ctx.saved_tensors
+    x, *rest = ctx.saved_tensors
+    act = getattr(ctx, "act", 0)
+    pre = rest[0] if rest else None
     layer, S, seed, base, cdt = ctx.layer, ctx.S, ctx.seed, ctx.base, ctx.cdt
     need_x, need_mu_w, _, need_mu_b, _ = ctx.needs_input_grad[:5]
     w_samples = None
@@ -36,7 +38,8 @@ def _backward(ctx, grad):
         if plan.arena_owner[gi % len(plan.arenas)] == (gi, token):  # no later forward has overwritten the arena
             w_samples = w_s
     with bfr.counter_override(ctx.counter):
-        return ops.linear_backward(layer, x, grad, S, seed, base, cdt, need_x, need_mu_w, need_mu_b, w_samples)
+        return ops.linear_backward(layer, x, grad, S, seed, base, cdt, need_x, need_mu_w, need_mu_b, w_samples,
+                                   act if pre is not None else 0, pre)
 
 
 class _LinearFn(torch.autograd.Function):
@@ -69,6 +72,14 @@ class _PlannedLinearFn(torch.autograd.Function):
             ctx.kept = (fwd.plan, fwd.plan.group_of[id(layer)], fwd.token, w_s)  # see _backward
         ctx.counter = bfr.counter_snapshot()
         ctx.cdt = w_s.dtype
+        # an activation fused into the GEMM while gradients are recorded: the launch also stores the pre-activation,
+        # and the backward folds act' (and the bias gradient's column sums) into one pass over the output gradient
+        keep_pre = bool(act) and any(ctx.needs_input_grad[:5])
+        if keep_pre:
+            y, pre = ops.planned_linear_forward(x, w_s, b_s, S, layer.out_features, layer.in_features, act, True)
+            ctx.act = act
+            ctx.save_for_backward(x, pre)
+            return y
         ctx.save_for_backward(x)
         return ops.planned_linear_forward(x, w_s, b_s, S, layer.out_features, layer.in_features, act)
 
@@ -129,7 +140,6 @@ class Linear(KernelLayer):
             return input.new_empty(*input.shape[:-1], self.out_features)
         mu_b = self.bias.mu if isinstance(self.bias, Gaussian) else None
         rho_b = self.bias.rho if isinstance(self.bias, Gaussian) else None
-        # the fused activation has no backward: when a gradient may be needed it runs as a separate op
         want_act = self.activation == "gelu"
         need_grad = torch.is_grad_enabled() and any(
             t is not None and t.requires_grad for t in (x2, self.weight.mu, self.weight.rho, mu_b, rho_b))
@@ -144,7 +154,10 @@ class Linear(KernelLayer):
                 if y is not None:
                     self._lp_view, self._lp_dirty = slot, True
                     return y.view(*input.shape[:-1], self.out_features)
-            fused = want_act and not need_grad
+            # with gradients the fused launch also stores the pre-activation (16-bit outputs, N % 8 == 0: what the fused
+            # backward pass takes); otherwise the activation runs as a separate autograd op
+            fused = want_act and (not need_grad or (x2.dtype != torch.float32 and self.out_features % 8 == 0
+                                                    and w_s.dtype == x2.dtype))
             y = _PlannedLinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, w_s, b_s, self, S,
                                        bfr.STATE.seed, base, 1 if fused else 0)
             if want_act and not fused:

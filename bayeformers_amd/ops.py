@@ -127,6 +127,19 @@ def gemm_nt(x: Tensor, w: Tensor, bias: Optional[Tensor], S: int, M: int, N: int
     return y
 
 
+def gemm_nt_act_pre(x: Tensor, w: Tensor, bias: Optional[Tensor], S: int, M: int, N: int, K: int, x_sample_stride: int,
+                    y_dtype: torch.dtype, act: int):
+    """(act(y), y) with y[s] = x[s] w[s]^T + bias[s] (bf_gemm_nt_act_pre): the forward of a training step keeps the
+    pre-activation for the backward of the fused activation.  Both [S,M,N]."""
+    y = torch.empty((S, M, N), dtype=y_dtype, device=x.device)
+    pre = torch.empty((S, M, N), dtype=y_dtype, device=x.device)
+    _C.check(_C.lib().bf_gemm_nt_act_pre(x.data_ptr(), _TORCH2BF[x.dtype], x_sample_stride, w.data_ptr(),
+                                         _TORCH2BF[w.dtype], bias.data_ptr() if bias is not None else None,
+                                         y.data_ptr(), pre.data_ptr(), _TORCH2BF[y_dtype], S, M, N, K, act,
+                                         _stream_ptr()), "bf_gemm_nt_act_pre")
+    return y, pre
+
+
 def gemm_nt_layers(x: Tensor, w: Tensor, bias: Optional[Tensor], L: int, S: int, M: int, N: int, K: int,
                    x_sample_stride: int, y_dtype: torch.dtype, act: int = 0) -> Tensor:
     """y[l][s] = act(x[s] w[l][s]^T + bias[l][s]) for L layers sharing x, one launch (bf_gemm_nt_layers).
@@ -246,8 +259,10 @@ def _linear_forward_generic(layer, x, S, M, N, K, seed, sample_base, lp_out, cdt
     return y.view(S * M, N)
 
 
-def planned_linear_forward(x: Tensor, w_s: Tensor, b_s: Optional[Tensor], S: int, N: int, K: int, act: int = 0) -> Tensor:
-    """y[s] = x[s] W_s^T + b_s with W_s/b_s already sampled by the model's cross-layer plan (plan.SamplePlan)."""
+def planned_linear_forward(x: Tensor, w_s: Tensor, b_s: Optional[Tensor], S: int, N: int, K: int, act: int = 0,
+                           want_pre: bool = False):
+    """y[s] = act(x[s] W_s^T + b_s) with W_s/b_s already sampled by the model's cross-layer plan (plan.SamplePlan).
+    want_pre: return (y, pre-activation) — what the backward of a fused activation needs."""
     _require_device(x, "input")
     if x.dtype not in _TORCH2BF:
         raise _C.BayeFormersAMDError(f"unsupported input dtype {x.dtype}")
@@ -260,13 +275,19 @@ def planned_linear_forward(x: Tensor, w_s: Tensor, b_s: Optional[Tensor], S: int
     if rows % S:
         raise _C.BayeFormersAMDError(f"input rows ({rows}) are not a multiple of the sample count S={S}")
     M = rows // S
+    if want_pre:
+        y, pre = gemm_nt_act_pre(x, w_s, b_s, S, M, N, K, M * K, x.dtype, act)
+        return y.view(S * M, N), pre.view(S * M, N)
     return gemm_nt(x, w_s, b_s, S, M, N, K, M * K, x.dtype, act).view(S * M, N)
 
 
 def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_base: int, cdt: torch.dtype,
-                    need_x: bool, need_mu_w: bool, need_mu_b: bool, w_samples: Optional[Tensor] = None):
+                    need_x: bool, need_mu_w: bool, need_mu_b: bool, w_samples: Optional[Tensor] = None,
+                    act: int = 0, act_pre: Optional[Tensor] = None):
     """Gradients of the sampled-weight linear layer (bf_linear_bwd).  Returns (dx, dmu_w, drho_w, dmu_b, drho_b);
-    entries that are not needed are None.  x: [S*M, K] as saved by the forward; grad_y: [S*M, N]."""
+    entries that are not needed are None.  x: [S*M, K] as saved by the forward; grad_y: [S*M, N].
+    act / act_pre: the forward fused act() into its GEMM and kept the pre-activation [S*M, N]: grad_y is the gradient
+    of act(y)."""
     from .nn.parameters.base import NoneParameter
 
     K, N = layer.in_features, layer.out_features
@@ -289,13 +310,18 @@ def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_
     dmu_b = torch.empty((N,), dtype=torch.float32, device=dev) if (has_bias and need_mu_b) else None
     drho_b = torch.empty((N,), dtype=torch.float32, device=dev) if has_bias else None
     lib = _C.lib()
-    need = lib.bf_linear_bwd_workspace_bytes(S, M, N, K, int(has_bias), _TORCH2BF[cdt])
+    if act:
+        if act_pre is None or act_pre.dtype != cdt or act_pre.numel() != S * M * N:
+            raise _C.BayeFormersAMDError("linear_backward: a fused activation needs the forward's pre-activation "
+                                         f"as a [{S * M}, {N}] {cdt} tensor")
+        act_pre = act_pre.contiguous()
+    need = lib.bf_linear_bwd_workspace_bytes(S, M, N, K, int(has_bias), _TORCH2BF[cdt], act)
     ws = workspace(dev, need)
     ptr = lambda t: t.data_ptr() if t is not None else None
     _C.check(lib.bf_linear_bwd(xg.data_ptr(), M * K, dy.data_ptr(), _TORCH2BF[cdt], ctypes.byref(w),
                                ctypes.byref(b) if has_bias else None, ptr(dx), ptr(dmu_w), ptr(drho_w), ptr(dmu_b),
-                               ptr(drho_b), S, M, N, K, seed, sample_base & 0xFFFFFFFF, ws.data_ptr(), ws.numel(),
-                               _stream_ptr()), "bf_linear_bwd")
+                               ptr(drho_b), S, M, N, K, seed, sample_base & 0xFFFFFFFF, act, ptr(act_pre) if act else None,
+                               ws.data_ptr(), ws.numel(), _stream_ptr()), "bf_linear_bwd")
     if dx is not None and dx.dtype != x.dtype:
         dx = dx.to(x.dtype)
     return dx, dmu_w, drho_w, dmu_b, drho_b

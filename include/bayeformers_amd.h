@@ -126,6 +126,13 @@ enum { BF_ACT_NONE = 0, BF_ACT_GELU = 1 };
 int bf_gemm_nt_act(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
                    const float* d_bias, void* d_y, int y_dtype, int S, int M, int N, int K, int act, void* stream);
 
+/* bf_gemm_nt_act with a second output for training: d_y = act(y) and d_pre = y (the pre-activation, same dtype and
+ * shape [S][M][N]), which the backward of the fused activation needs (bf_linear_bwd's d_act_pre).  One launch with two
+ * stores when the 256-wide kernel takes the shape, else the GEMM followed by the elementwise activation. */
+int bf_gemm_nt_act_pre(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,
+                       const float* d_bias, void* d_y, void* d_pre, int y_dtype, int S, int M, int N, int K, int act,
+                       void* stream);
+
 /* L layers that consume the SAME activations (the query / key / value projections of an attention block,
  * HF BertSelfAttention around bnn.Linear.forward, bayeformers/nn/layers/linear.py:83-104) in ONE launch:
  *   y[l][s] = act(x[s] W_{l,s}^T + b_{l,s}),  d_w [L][S][N][K], d_bias [L][S][N] (nullable), d_y [L][S][M][N].
@@ -183,12 +190,15 @@ int bf_linear_fwd_ws(const void* d_x, int x_dtype, int64_t x_sample_stride, cons
  * too unless weight->d_sample_out still holds the forward's samples ([S][N][K] of `dtype`, weight->out_dtype ==
  * dtype), in which case they are read from there.  x, dy and dx share
  * one dtype, which is also the MFMA operand type (BF16 | F16 | F32).  Any of d_dx, d_dmu_w, d_dmu_b may be NULL
- * (not needed); d_drho_b/d_dmu_b are ignored when bias is NULL.  Gradients are written, not accumulated. */
-size_t bf_linear_bwd_workspace_bytes(int S, int M, int N, int K, int has_bias, int dtype);
+ * (not needed); d_drho_b/d_dmu_b are ignored when bias is NULL.  Gradients are written, not accumulated.
+ * act / d_act_pre: when the forward fused an activation into its GEMM (bf_gemm_nt_act_pre), d_dy is the gradient of
+ * act(y) and d_act_pre the forward's pre-activation y ([S][M][N] of `dtype`, 16-bit, N % 8 == 0): dy = d_dy * act'(y)
+ * is formed first, in one pass that also yields the bias gradient's column sums.  act = BF_ACT_NONE: d_act_pre unused. */
+size_t bf_linear_bwd_workspace_bytes(int S, int M, int N, int K, int has_bias, int dtype, int act);
 int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, int dtype, const bf_tensor_t* weight,
                   const bf_tensor_t* bias, void* d_dx, float* d_dmu_w, float* d_drho_w, float* d_dmu_b,
-                  float* d_drho_b, int S, int M, int N, int K, uint64_t seed, uint32_t sample_base, void* d_workspace,
-                  size_t workspace_bytes, void* stream);
+                  float* d_drho_b, int S, int M, int N, int K, uint64_t seed, uint32_t sample_base, int act,
+                  const void* d_act_pre, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Opt-in Bayes-by-Backprop gradient of the KL terms.  The reference detaches its log-probs (layers/linear.py:99-102
  * store them with `.data =`), so `loss = (lvp - log_prior)/n_batches + nll` (bert_glue.py:235) trains the likelihood

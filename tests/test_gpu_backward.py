@@ -246,3 +246,66 @@ def test_backward_after_a_later_forward_regenerates_the_samples():
 
     for a, b in zip(grads(False), grads(True)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,N,K,S", [(512, 256, 192, 2), (300, 264, 128, 3), (96, 72, 64, 2)])
+def test_fused_gelu_training_path(M, N, K, S):
+    """A layer with its GELU fused into the GEMM (bayeformers_amd.fuse_activations) under autograd: the forward's one
+    launch returns gelu(y) and keeps y, the backward folds gelu' and the bias column sums into one pass.  Against fp64
+    autograd of F.gelu(F.linear(x, W_s, b_s)) with the oracle's epsilon (linear.py:97,104)."""
+    from oracle import bayes_oracle as bo
+
+    g = torch.Generator().manual_seed(M * 7 + N)
+    layer = bnn.Linear(K, N)
+    layer.weight.mu.data = torch.randn(N, K, generator=g) * 0.05
+    layer.weight.rho.data = -3.0 + 0.3 * torch.randn(N, K, generator=g)
+    layer.bias.mu.data = torch.randn(N, generator=g) * 0.05
+    layer.bias.rho.data = -3.0 + 0.3 * torch.randn(N, generator=g)
+    layer.layer_id = 0
+    layer.activation = "gelu"
+    layer = layer.cuda()
+    model = bnn.Model(layer)
+    model.cross_layer_sampling = True
+    x = torch.randn(S * M, K, generator=g)
+    gy = torch.randn(S * M, N, generator=g)
+    xd = x.cuda().bfloat16().requires_grad_(True)
+    base = 3
+    bf.manual_seed(SEED, next_sample=base)
+    with model.monte_carlo(S):
+        y = model(xd)
+    y.backward(gy.cuda().bfloat16())
+
+    xr = x.bfloat16().double().requires_grad_(True)
+    ps = [p.detach().cpu().double().requires_grad_(True)
+          for p in (layer.weight.mu, layer.weight.rho, layer.bias.mu, layer.bias.rho)]
+    ys = []
+    for s in range(S):
+        w = ps[0] + torch.nn.functional.softplus(ps[1]) * bo.eps_tensor((N, K), SEED, base + s, 0, 0).double()
+        b = ps[2] + torch.nn.functional.softplus(ps[3]) * bo.eps_tensor((N,), SEED, base + s, 0, 1).double()
+        ys.append(torch.nn.functional.gelu(torch.nn.functional.linear(xr[s * M:(s + 1) * M], w.detach().bfloat16().double() + (w - w.detach()), b)))
+    yr = torch.cat(ys)
+    (yr * gy.bfloat16().double()).sum().backward()
+    # forward: gelu of the bf16-rounded pre-activation, rounded to bf16
+    assert (y.double().cpu() - yr.detach()).abs().max().item() <= 2.0 ** -6 * yr.abs().max().item()
+    got = [xd.grad, layer.weight.mu.grad, layer.weight.rho.grad, layer.bias.mu.grad, layer.bias.rho.grad]
+    ref = [xr.grad] + [p.grad for p in ps]
+    for a, r, what in zip(got, ref, ("dx", "dmu_w", "drho_w", "dmu_b", "drho_b")):
+        err = (a.double().cpu() - r).abs().max().item()
+        assert err <= 3e-2 * r.abs().max().item(), (what, err, r.abs().max().item())
+
+
+def test_gemm_act_pre_outputs():
+    """bf_gemm_nt_act_pre: d_pre is the plain GEMM output, d_y = gelu(d_pre) — on the 256-wide kernel's two-store
+    epilogue and on the fallback (GEMM, then the elementwise kernel) for a shape that kernel does not take."""
+    from bayeformers_amd import ops
+
+    for (S, M, N, K) in [(2, 300, 264, 128), (1, 40, 24, 72)]:
+        g = torch.Generator(device="cuda").manual_seed(5)
+        w = torch.randn(S, N, K, device="cuda", generator=g).bfloat16()
+        x = torch.randn(S, M, K, device="cuda", generator=g).bfloat16()
+        bias = torch.randn(S, N, device="cuda", generator=g)
+        y, pre = ops.gemm_nt_act_pre(x, w, bias, S, M, N, K, M * K, torch.bfloat16, 1)
+        plain = ops.gemm_nt(x, w, bias, S, M, N, K, M * K, torch.bfloat16, 0)
+        assert torch.equal(pre, plain)
+        ref = torch.nn.functional.gelu(pre.double())
+        assert (y.double() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-6
