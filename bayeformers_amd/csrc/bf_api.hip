@@ -414,6 +414,13 @@ int bf_gemm_tn(const void* d_a, const void* d_bm, float* d_out, int dtype, int b
     return bf_launch_gemm256_tn(d_a, d_bm, d_out, dtype, batch, Mc, N, K, (hipStream_t)stream);
 }
 
+int bf_gemm_nn(const void* d_x, const void* d_w, void* d_y, int dtype, int S, int M, int N, int K, void* stream) {
+    if (!d_x || !d_w || !d_y) BF_FAIL("bf_gemm_nn: null pointer");
+    if (!bf_gemm256_nn_supported(dtype, S, M, N, K, d_x, d_w, d_y))
+        BF_FAIL("bf_gemm_nn: needs a 16-bit dtype, N %% 64 == 0, K %% 8 == 0, M * K >= 16384 and 16-byte aligned pointers");
+    return bf_launch_gemm256_nn(d_x, d_w, d_y, dtype, S, M, N, K, (hipStream_t)stream);
+}
+
 // workspace layout of bf_linear_bwd
 struct BwdLayout {
     size_t w, wt, dyt, xt, dw, db, dbp, dpre, lp, part, total;
@@ -519,10 +526,15 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
         if (rc) return rc;
     }
     if (d_dx) {
-        // 2. dx[s] = dy[s] [M][N] x (W_s^T [K][N])^T : the NT kernel wants the reduction axis (n) contiguous in both
-        if ((rc = bf_launch_transpose(w_s, ws + L.wt, es, S, N, K, stream))) return rc;
-        if ((rc = bf_launch_gemm_nt(d_dy, dtype, (int64_t)M * N, ws + L.wt, dtype, nullptr, d_dx, dtype, S, M, K, N, stream)))
-            return rc;
+        // 2. dx[s] = dy[s] W_s: the NN form of the 256-wide kernel reads W_s [N][K] as it was sampled (contraction-major,
+        //    fragments through the LDS transpose read); other shapes: a transposed copy W_s^T [K][N] and the NT kernel
+        if (bf_gemm256_nn_supported(dtype, S, M, N, K, d_dy, w_s, d_dx)) {
+            if ((rc = bf_launch_gemm256_nn(d_dy, w_s, d_dx, dtype, S, M, N, K, stream))) return rc;
+        } else {
+            if ((rc = bf_launch_transpose(w_s, ws + L.wt, es, S, N, K, stream))) return rc;
+            if ((rc = bf_launch_gemm_nt(d_dy, dtype, (int64_t)M * N, ws + L.wt, dtype, nullptr, d_dx, dtype, S, M, K, N, stream)))
+                return rc;
+        }
     }
     // 3. dW_s = dy[s]^T x[s], fp32 out.  With split-K the M axis is cut into `sp` chunks that are multiplied as sp * S
     //    batch entries of M / sp rows each.  The TN form of the 256-wide kernel reads dy and x as they are

@@ -337,13 +337,17 @@ __device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&ac
 // p.w is [batch][K][N] (x) — so no transposed copies of dy and x are ever made.  A stage then holds two [64][256]
 // tiles (64 contraction rows of 512 B); their 32-byte granules are XOR-swizzled by the row (again on the DMA source
 // address) and the MFMA fragments come out through the LDS transpose read ds_read_b64_tr_b16: two reads give a lane
-// the 8 contraction values {4 lg + 0..3, 16 + 4 lg + 0..3} of its row — a permutation of the contraction index that is
-// the same for both operands, which is all the MFMA needs.
+// the 8 contraction values 8 lg + 0..7 of its row, the same ones a ds_read_b128 of a K-contiguous operand delivers, so
+// the two operand forms mix:
+//   TRX TRW
+//    0   0   NT   y = x W^T          (forward; x [M][K], W [N][K])
+//    1   1   TN   dW = dy^T x        (weight gradient; dy [m][N], x [m][K], contraction over the batch rows m)
+//    0   1   NN   dx = dy W          (input gradient; dy [M][N], W [N][K] read as it was sampled: no transposed copy)
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
 
-template <typename T, typename YT, bool TR = false>
+template <typename T, typename YT, bool TRX = false, bool TRW = false>
 __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams p) {
     using frag = typename Mfma16<T>::frag;
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
@@ -371,19 +375,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
         n0 = (z & 0xFFFFFF) * TN;
         t.xb = reinterpret_cast<const T*>(p.x) + (long long)__builtin_amdgcn_readfirstlane(d.y) * p.x_sstride;
         t.wb = reinterpret_cast<const T*>(p.w) + (long long)s * N * K;
-        if constexpr (TR) {
-            // piece q = i * 8 + wid = contraction rows 2 q, 2 q + 1 of the k-step; lane -> (row, 16-byte position);
-            // the position holds source chunk c = position ^ ((row & 7) << 1); columns past the edge are clamped
-            // (they only feed output rows / columns that are masked on store).  row & 7 does not depend on i, so one
-            // offset per operand serves all four pieces (piece i = + 16 i rows, added to the wave-uniform base)
-            const int r = wid * 2 + (lane >> 5);
-            const int c = (lane & 31) ^ ((r & 7) << 1);
-            t.xo[0] = (unsigned)r * (unsigned)M + (unsigned)min(m0 + c * 8, M - 8);
-            t.wo[0] = (unsigned)r * (unsigned)N + (unsigned)min(n0 + c * 8, N - 8);
+        // contraction-major operand: piece q = i * 8 + wid = contraction rows 2 q, 2 q + 1 of the k-step; lane -> (row,
+        // 16-byte position); the position holds source chunk c = position ^ (key(row) << 1), key = row bits {0, 1, 3};
+        // columns past the edge are clamped (they only feed output rows / columns that are masked on store).  The key
+        // does not depend on i, so one offset per operand serves all four pieces (piece i = + 16 i rows, added to the
+        // wave-uniform base)
+        const int tr_r = wid * 2 + (lane >> 5);
+        const int tr_c = (lane & 31) ^ (((tr_r & 3) | ((tr_r >> 1) & 4)) << 1);
+        if constexpr (TRX) {
+            t.xo[0] = (unsigned)tr_r * (unsigned)M + (unsigned)min(m0 + tr_c * 8, M - 8);
         } else {
 #pragma unroll
             for (int i = 0; i < XPIECES; ++i)
                 t.xo[i] = (unsigned)min(m0 + (i * 8 + wid) * 8 + prow, M - 1) * (unsigned)K + kc8;
+        }
+        if constexpr (TRW) {
+            t.wo[0] = (unsigned)tr_r * (unsigned)N + (unsigned)min(n0 + tr_c * 8, N - 8);
+        } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 t.wo[i] = (unsigned)min(n0 + (i * 8 + wid) * 8 + prow, N - 1) * (unsigned)K + kc8;
@@ -393,17 +401,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
     // (inside a tile's k-loop h is the compile-time height, so a full-height tile issues its pieces without branches)
     auto stage = [&](const Src& t, int kt, int buf, auto h) {
         char* base = smem + buf * STAGE_BYTES;
-        const T* xk = t.xb + (TR ? (long long)kt * TK * M : (long long)kt * TK);
-        const T* wk = t.wb + (TR ? (long long)kt * TK * N : (long long)kt * TK);
-        if constexpr (TR) {
+        const T* xk = t.xb + (TRX ? (long long)kt * TK * M : (long long)kt * TK);
+        const T* wk = t.wb + (TRW ? (long long)kt * TK * N : (long long)kt * TK);
+        if constexpr (TRX) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) glds16(xk + (long long)i * 16 * M + t.xo[0], base + (i * 8 + wid) * 1024);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) glds16(wk + (long long)i * 16 * N + t.wo[0], base + X_BYTES + (i * 8 + wid) * 1024);
         } else {
 #pragma unroll
             for (int i = 0; i < XPIECES; ++i)
                 if (i * 8 + 7 < 4 * h || i * 8 + wid < 4 * h) glds16(xk + t.xo[i], base + (i * 8 + wid) * 1024);
+        }
+        if constexpr (TRW) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16(wk + (long long)i * 16 * N + t.wo[0], base + X_BYTES + (i * 8 + wid) * 1024);
+        } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) glds16(wk + t.wo[i], base + X_BYTES + (i * 8 + wid) * 1024);
         }
@@ -414,10 +425,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
     const int foff1 = (lane & 15) * ROW_BYTES + (((4 + (lane >> 4)) ^ fsw) << 4);
     const int xfrag_base = wm * 16 * ROW_BYTES;  // + j * 32 rows: wave group wm owns blocks wm, wm + 2, ...
     const int wfrag_base = X_BYTES + wn * 64 * ROW_BYTES;
-    // TR: the 16 lanes of a group point at a [4 contraction rows][16 columns] block: lane -> row lg*4 + (li>>2) of the
-    // 16-row group, 8 bytes (li & 3) of the block's 32-byte granule; granule' = granule ^ (row & 7)
-    const int tr_rl = ((lane >> 4) & 1) * 4 + ((lane & 15) >> 2);
-    const int tr_lane = ((lane >> 4) * 4 + ((lane & 15) >> 2)) * 512 + (lane & 3) * 8;
+    // contraction-major tiles: the 16 lanes of a group point at a [4 contraction rows][16 columns] block: lane -> row
+    // 8 lg + (li >> 2) of the 32-row half (the second read takes the 4 rows below: + 2 KiB, same key), 8 bytes (li & 3)
+    // of the block's 32-byte granule; granule' = granule ^ key(row)
+    const int tr_rl = ((lane & 15) >> 2) | (((lane >> 4) & 1) << 2);
+    const int tr_lane = ((lane >> 4) * 8 + ((lane & 15) >> 2)) * 512 + (lane & 3) * 8;
     // LDS byte addresses of the wave's first w block (wn * 4) and first x block (wm) in buffer 0; the other blocks are
     // one XOR with a constant away (smem is 1 KiB aligned, the granule index sits alone in address bits 5..8), so the
     // k-loop holds two address registers instead of twelve
@@ -432,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
         constexpr int off = decltype(half)::value * 32 * 512;
         s16x4_t lo, hi;
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(off));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(off + 16 * 512));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(off + 4 * 512));
         const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(frag, v);
     };
@@ -466,12 +478,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
                 dma();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if constexpr (TR) wf[i] = tr_read(tr_w0 + (g & 1) * STAGE_BYTES, i, std::integral_constant<int, 0>{});
+                    if constexpr (TRW) wf[i] = tr_read(tr_w0 + (g & 1) * STAGE_BYTES, i, std::integral_constant<int, 0>{});
                     else wf[i] = *reinterpret_cast<const frag*>(sb + wfrag_base + i * 16 * ROW_BYTES + foff0);
                 }
 #pragma unroll
                 for (int j = 0; j < H; ++j) {
-                    if constexpr (TR) xf[j] = tr_read(tr_x0 + (g & 1) * STAGE_BYTES, 2 * j, std::integral_constant<int, 0>{});
+                    if constexpr (TRX) xf[j] = tr_read(tr_x0 + (g & 1) * STAGE_BYTES, 2 * j, std::integral_constant<int, 0>{});
                     else xf[j] = *reinterpret_cast<const frag*>(sb + xfrag_base + j * 32 * ROW_BYTES + foff0);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -487,12 +499,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
                 __builtin_amdgcn_s_barrier();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if constexpr (TR) wf[i] = tr_read(tr_w0 + (g & 1) * STAGE_BYTES, i, std::integral_constant<int, 1>{});
+                    if constexpr (TRW) wf[i] = tr_read(tr_w0 + (g & 1) * STAGE_BYTES, i, std::integral_constant<int, 1>{});
                     else wf[i] = *reinterpret_cast<const frag*>(sb + wfrag_base + i * 16 * ROW_BYTES + foff1);
                 }
 #pragma unroll
                 for (int j = 0; j < H; ++j) {
-                    if constexpr (TR) xf[j] = tr_read(tr_x0 + (g & 1) * STAGE_BYTES, 2 * j, std::integral_constant<int, 1>{});
+                    if constexpr (TRX) xf[j] = tr_read(tr_x0 + (g & 1) * STAGE_BYTES, 2 * j, std::integral_constant<int, 1>{});
                     else xf[j] = *reinterpret_cast<const frag*>(sb + xfrag_base + j * 32 * ROW_BYTES + foff1);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -742,7 +754,14 @@ int get_schedule(int S, int layers, int tiles_n, int M, int policy, hipStream_t 
 
 template <typename T>
 int launch256_tn(const GemmParams& p, hipStream_t stream, int grid) {
-    hipLaunchKernelGGL((gemm256_sched_kernel<T, float, true>), dim3(grid), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL((gemm256_sched_kernel<T, float, true, true>), dim3(grid), dim3(512), 0, stream, p);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+int launch256_nn(const GemmParams& p, hipStream_t stream, int grid) {
+    hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, true>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -851,4 +870,41 @@ int bf_launch_gemm256_tn(const void* d_a, const void* d_b, float* d_out, int dty
     p.sched_rounds = sc.rounds;
     if (dtype == BF_DT_BF16) return launch256_tn<__bf16>(p, stream, sc.grid);
     return launch256_tn<_Float16>(p, stream, sc.grid);
+}
+
+// y[s][m][k] = sum_n x[s][m][n] * w[s][n][k]  (16-bit in and out): the input-gradient GEMM dx = dy W of the backward pass
+// with W_s [Nl][Kl] read as the sampling kernel wrote it (kernel form NN).  x: [S][M][Nl], w: [S][Nl][Kl], y: [S][M][Kl].
+bool bf_gemm256_nn_supported(int dtype, int S, int M, int Nl, int Kl, const void* d_x, const void* d_w, const void* d_y) {
+    if (dtype != BF_DT_BF16 && dtype != BF_DT_F16) return false;
+    if (S < 1 || S > 65535 || M < 1 || Nl < TK || Nl % TK || Kl < 8 || Kl % 8) return false;
+    if (((uintptr_t)d_x | (uintptr_t)d_w | (uintptr_t)d_y) & 15) return false;
+    if ((long long)M * Nl >= (1ll << 32) || (long long)Nl * Kl >= (1ll << 32) || (long long)M * Kl >= (1ll << 31)) return false;
+    if (M >= (1 << 24) || (Kl + TN - 1) / TN >= (1 << 24)) return false;
+    return (long long)M * Kl >= 128 * 128;
+}
+
+int bf_launch_gemm256_nn(const void* d_x, const void* d_w, void* d_y, int dtype, int S, int M, int Nl, int Kl,
+                         hipStream_t stream) {
+    GemmParams p{};
+    p.x = d_x;
+    p.w = d_w;
+    p.bias = nullptr;
+    p.y = d_y;
+    p.y2 = nullptr;
+    p.x_sstride = (long long)M * Nl;
+    p.S = S;
+    p.M = M;
+    p.N = Kl;
+    p.K = Nl;
+    p.act = BF_ACT_NONE;
+    p.layers = 1;
+    p.flags = 0;
+    p.tiles_m = (p.M + TM - 1) / TM;
+    p.tiles_n = (p.N + TN - 1) / TN;
+    Sched sc;
+    if (get_schedule(p.S, 1, p.tiles_n, p.M, BF_SCHED_POLICY, stream, sc)) return 1;
+    p.sched = sc.d_table;
+    p.sched_rounds = sc.rounds;
+    if (dtype == BF_DT_BF16) return launch256_nn<__bf16>(p, stream, sc.grid);
+    return launch256_nn<_Float16>(p, stream, sc.grid);
 }

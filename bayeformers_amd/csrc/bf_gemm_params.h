@@ -31,6 +31,10 @@ bool bf_gemm256_tn_supported(int dtype, int batch, int Mc, int Nl, int Kl, const
                              const void* d_out);
 int bf_launch_gemm256_tn(const void* d_a, const void* d_b, float* d_out, int dtype, int batch, int Mc, int Nl, int Kl,
                          hipStream_t stream);
+// NN form (x K-contiguous, w contraction-major, 16-bit out): y[s][m][k] = sum_n x[s][m][n] * w[s][n][k]
+bool bf_gemm256_nn_supported(int dtype, int S, int M, int Nl, int Kl, const void* d_x, const void* d_w, const void* d_y);
+int bf_launch_gemm256_nn(const void* d_x, const void* d_w, void* d_y, int dtype, int S, int M, int Nl, int Kl,
+                         hipStream_t stream);
 #ifdef BF_DEV
 // round-1 kernel (fixed 256x256 tiles, arithmetic tile order), kept in developer builds as the A/B baseline
 int bf_launch_gemm256_r1(const GemmParams& p, int w_dtype, int y_dtype, hipStream_t stream);

@@ -166,6 +166,20 @@ def gemm_tn(a: Tensor, b: Tensor) -> Tensor:
     return out
 
 
+def gemm_nn(x: Tensor, w: Tensor) -> Tensor:
+    """y[s] = x[s] w[s] (bf_gemm_nn): the input-gradient GEMM dx = dy W_s.  x: [S, M, N], w: [S, N, K], 16-bit;
+    returns [S, M, K] of the same dtype."""
+    _require_device(x, "x")
+    S, M, N = x.shape
+    K = w.shape[2]
+    if w.shape[:2] != (S, N) or x.dtype != w.dtype or not (x.is_contiguous() and w.is_contiguous()):
+        raise _C.BayeFormersAMDError("gemm_nn: x [S,M,N] and w [S,N,K] must be contiguous, same dtype")
+    y = torch.empty((S, M, K), dtype=x.dtype, device=x.device)
+    _C.check(_C.lib().bf_gemm_nn(x.data_ptr(), w.data_ptr(), y.data_ptr(), _TORCH2BF[x.dtype], S, M, N, K,
+                                 _stream_ptr()), "bf_gemm_nn")
+    return y
+
+
 class LinearPlan:
     """Cached ctypes descriptors of one bnn.Linear (pointers are refreshed per call; structs are reused)."""
 

@@ -149,6 +149,13 @@ int bf_gemm_nt_layers(const void* d_x, int x_dtype, int64_t x_sample_stride, con
  * message otherwise: bf_linear_bwd takes its transposed-copy route for such shapes). */
 int bf_gemm_tn(const void* d_a, const void* d_bm, float* d_out, int dtype, int batch, int Mc, int N, int K, void* stream);
 
+/* Input-gradient GEMM of the backward pass, per sample s:
+ *   y[s][m][k] = sum_n x[s][m][n] * w[s][n][k]          (dx = dy W_s; x = dy [M][N], w = W_s [N][K] as sampled)
+ * 16-bit operands and output (dtype BF_DT_BF16 | BF_DT_F16), fp32 accumulation; w is read contraction-major, so no
+ * transposed copy of the sampled weights is made.  Needs N % 64 == 0, K % 8 == 0, M * K >= 128 * 128 and 16-byte
+ * aligned pointers (fails with a message otherwise: bf_linear_bwd transposes W_s for such shapes). */
+int bf_gemm_nn(const void* d_x, const void* d_w, void* d_y, int dtype, int S, int M, int N, int K, void* stream);
+
 /* The host-built tile schedule the 256-wide persistent GEMM kernel runs for a problem of S samples x L layers x
  * [M, N] outputs on n_cu compute units (introspection: the library builds and caches the same table on the first
  * launch of a shape).  The output is cut into tiles of 32 h rows (h = 1..8) x 256 columns; every workgroup b of the

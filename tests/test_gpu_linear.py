@@ -162,6 +162,35 @@ def test_gemm_tn_against_torch(batch, Mc, N, K, dt):
     assert (out.double() - ref).abs().max().item() <= 2e-6 * np.sqrt(Mc) * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("S,M,N,K", [(1, 128, 64, 128), (2, 300, 128, 200), (3, 513, 192, 264), (10, 4096, 768, 768),
+                                      (1, 1000, 3072, 776), (2, 129, 64, 1032)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_gemm_nn_against_torch(S, M, N, K, dt):
+    """bf_gemm_nn (dx = dy W_s, W_s read contraction-major through the LDS transpose read, dy K-contiguous) against an
+    fp64 einsum of the same 16-bit operands."""
+    g = torch.Generator(device="cuda").manual_seed(S * 7919 + M * 31 + N * 7 + K)
+    x = torch.randn(S, M, N, device="cuda", generator=g).to(dt)
+    w = (torch.randn(S, N, K, device="cuda", generator=g) * 0.1).to(dt)
+    y = ops.gemm_nn(x, w)
+    ref = torch.einsum("smn,snk->smk", x.double(), w.double())
+    tol = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    assert y.shape == (S, M, K) and y.dtype == dt
+    assert (y.double() - ref).abs().max().item() <= tol * ref.abs().max().item() + 1e-5 * np.sqrt(N)
+
+
+def test_gemm_nn_detects_transposes():
+    S, M, N, K = 1, 128, 64, 256
+    x = torch.zeros(S, M, N, device="cuda")
+    w = torch.zeros(S, N, K, device="cuda")
+    x[0, :, 0] = torch.arange(M, device="cuda").float() % 16 + 1          # y[m][k] = (m % 16 + 1) * (k % 8 + 1)
+    w[0, 0, :] = torch.arange(K, device="cuda").float() % 8 + 1
+    x[0, :, 37] = 1.0                                                     # + w[37][k] = k % 3
+    w[0, 37, :] = torch.arange(K, device="cuda").float() % 3
+    y = ops.gemm_nn(x.bfloat16(), w.bfloat16())[0].float()
+    ref = torch.outer(torch.arange(M).float() % 16 + 1, torch.arange(K).float() % 8 + 1) + (torch.arange(K).float() % 3)[None, :]
+    assert torch.equal(y, ref.cuda())
+
+
 def test_gemm_tn_detects_transposes_and_rejects_shapes():
     """Asymmetric operands (a swapped n/k mapping or a permuted contraction index on ONE side cannot pass), and the
     shapes the kernel does not take fail with a message instead of computing something else."""

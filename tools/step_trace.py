@@ -21,13 +21,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--filter", default="copy,elementwise,Memcpy,Memset,fill,cat,reduce")
+    ap.add_argument("--train", action="store_true", help="the training step (bert_base_train) instead of fwd+ELBO")
     args = ap.parse_args()
     import bayeformers_amd as bf
 
     dev = torch.device("cuda", 0)
     bf.set_compute_dtype("bf16")
     bf.manual_seed(0x5EED)
-    step, _, _, _ = bench.make_bert(dev, 10, "bf16")
+    step, _, _, _ = bench.make_bert(dev, 10, "bf16", train=args.train)
     for _ in range(3):
         step()
     torch.cuda.synchronize()
