@@ -213,8 +213,14 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
         out[(long long)s * N + n] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
-// dmu[e] = sum_s dw[s][e];  drho[e] = (sum_s dw[s][e] * eps(s, e)) * softplus'(rho[e]).  thread = 4 scalars.
-// dw is [S][splits][n]: the split-K partial products of one sample are summed first.
+// dmu[e] = sum_s dw[s][e];  drho[e] = (sum_s dw[s][e] * eps(s, e)) * softplus'(rho[e]).  thread = 4 scalars = one Philox
+// block per sample.  dw is [S][splits][n]: the split-K partial products of one sample are summed first.
+// A launch has only ~9 waves per CU (n / 4 threads), so the kernel lives on loads in flight: the 16-byte loads of
+// kPgBatch samples (x splits) are issued together before any arithmetic (VEC: n % 4 == 0 and 16-byte aligned dw; one
+// load per thread and sample-split otherwise runs at 1.7 TB/s), and the sample-independent half of the Philox rounds
+// is computed once per thread (bf_philox_prepare).
+constexpr int kPgBatch = 5;
+template <bool VEC>
 __global__ __launch_bounds__(256) void param_grad_kernel(const float* __restrict__ dw, const float* __restrict__ rho,
                                                          unsigned long long n, int S, int splits, uint32_t k0, uint32_t k1,
                                                          uint32_t sample_base, const uint32_t* __restrict__ counter,
@@ -225,20 +231,56 @@ __global__ __launch_bounds__(256) void param_grad_kernel(const float* __restrict
     const unsigned long long e0 = g * 4;
     if (e0 >= n) return;
     const int nv = n - e0 >= 4 ? 4 : (int)(n - e0);
+    const bf_philox_inv inv = bf_philox_prepare((uint32_t)g, (uint32_t)(g >> 32), stream, k0, k1);
     float sm[4] = {0.f, 0.f, 0.f, 0.f}, se[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < S; ++s) {
-        float z[4];
-        bf_normal4_dev((uint32_t)g, (uint32_t)(g >> 32), sample_base + (uint32_t)s, stream, k0, k1, z);
-        const float* p = dw + (unsigned long long)s * splits * n + e0;
-        float d[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int j = 0; j < splits; ++j, p += n) {
+    if constexpr (VEC) {
+        const unsigned long long sstride = (unsigned long long)splits * n;
+        for (int s0 = 0; s0 < S; s0 += kPgBatch) {
+            f32x4_t d[kPgBatch];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) d[i] += i < nv ? p[i] : 0.f;
+            for (int b = 0; b < kPgBatch; ++b) {
+                d[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (s0 + b < S) d[b] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(dw + (s0 + b) * sstride + e0));
+            }
+            for (int j = 1; j < splits; ++j) {
+                f32x4_t t[kPgBatch];
+#pragma unroll
+                for (int b = 0; b < kPgBatch; ++b) {
+                    t[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if (s0 + b < S)
+                        t[b] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(dw + (s0 + b) * sstride + j * n + e0));
+                }
+#pragma unroll
+                for (int b = 0; b < kPgBatch; ++b) d[b] += t[b];
+            }
+#pragma unroll
+            for (int b = 0; b < kPgBatch; ++b) {
+                if (s0 + b < S) {
+                    float z[4];
+                    bf_normal4_split_dev(inv, sample_base + (uint32_t)(s0 + b), stream, k0, k1, z);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        sm[i] += d[b][i];
+                        se[i] = fmaf(d[b][i], z[i], se[i]);
+                    }
+                }
+            }
         }
+    } else {
+        for (int s = 0; s < S; ++s) {
+            float z[4];
+            bf_normal4_split_dev(inv, sample_base + (uint32_t)s, stream, k0, k1, z);
+            const float* p = dw + (unsigned long long)s * splits * n + e0;
+            float d[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < splits; ++j, p += n) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            sm[i] += d[i];
-            se[i] = fmaf(d[i], z[i], se[i]);
+                for (int i = 0; i < 4; ++i) d[i] += i < nv ? p[i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sm[i] += d[i];
+                se[i] = fmaf(d[i], z[i], se[i]);
+            }
         }
     }
     for (int i = 0; i < nv; ++i) {
@@ -591,9 +633,13 @@ int bf_launch_param_grad(const float* d_dw, const float* d_rho, uint64_t n, int 
     if (!d_dw || !d_rho || !d_drho) BF_FAIL("bf_param_grad: NULL argument");
     if (n == 0 || S < 1 || splits < 1) BF_FAIL("bf_param_grad: empty");
     const uint64_t groups = (n + 3) / 4;
-    hipLaunchKernelGGL(param_grad_kernel, dim3((uint32_t)((groups + 255) / 256)), dim3(256), 0, stream, d_dw, d_rho,
-                       (unsigned long long)n, S, splits, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, bf_sample_counter(), stream_id, d_dmu,
-                       d_drho);
+    const dim3 grid((uint32_t)((groups + 255) / 256));
+    if (n % 4 == 0 && ((uintptr_t)d_dw & 15) == 0)
+        hipLaunchKernelGGL(param_grad_kernel<true>, grid, dim3(256), 0, stream, d_dw, d_rho, (unsigned long long)n, S, splits,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, bf_sample_counter(), stream_id, d_dmu, d_drho);
+    else
+        hipLaunchKernelGGL(param_grad_kernel<false>, grid, dim3(256), 0, stream, d_dw, d_rho, (unsigned long long)n, S, splits,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, bf_sample_counter(), stream_id, d_dmu, d_drho);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -225,7 +225,10 @@ __global__ __launch_bounds__(1024) void layernorm_param_grad_kernel(const float*
     }
 }
 
-constexpr int kBwdBlocks = 512;  // 2 workgroups per CU; each leaves one [2][N] partial row
+#ifndef BF_LN_BWD_BLOCKS
+#define BF_LN_BWD_BLOCKS 1024
+#endif
+constexpr int kBwdBlocks = BF_LN_BWD_BLOCKS;  // workgroups (each leaves one [2][N] partial row)
 
 template <typename T, typename GT>
 int launch_bwd_vpl(const void* x, const void* res, const void* gamma, const void* dy, void* dz, float* partial,
