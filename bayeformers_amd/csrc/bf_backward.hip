@@ -124,7 +124,20 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int m1 = min(M, (ch + 1) * kColsumRows);
     if (cv * 8 < N) {
-        for (int m = ch * kColsumRows + rl; m < m1; m += 4) {
+        // (a launch is only a few waves per CU: 8 row loads are in flight per thread before any is consumed)
+        constexpr int U = 8;
+        int m = ch * kColsumRows + rl;
+        for (; m + 4 * (U - 1) < m1; m += 4 * U) {
+            V8 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                v[u] = __builtin_nontemporal_load(reinterpret_cast<const V8*>(p + (long long)(m + 4 * u) * N + cv * 8));
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += (float)v[u][i];
+        }
+        for (; m < m1; m += 4) {
             const V8 v = *reinterpret_cast<const V8*>(p + (long long)m * N + cv * 8);
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
