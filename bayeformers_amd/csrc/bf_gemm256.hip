@@ -99,108 +99,11 @@ __device__ __forceinline__ void init_acc(f32x4_t (&acc)[4][H], const float* bias
     }
 }
 
-// DEVELOPER BUILDS ONLY (BF_GEMM_ABLATE bit 32): the epilogue as a software pipeline over passes through TWO unpadded,
-// XOR-swizzled 32 KiB regions with ONE barrier per pass (pass p: convert + ds_write into region p & 1 -> global stores
-// of pass p-1's rows -> barrier -> ds_read of this pass's rows) and wave group 0 starting its first pass one slot
-// early.  Measured in the BERT-base step against the two-barrier epilogue below, same schedule, same box: 7.18 vs
-// 7.11 ms of GEMM time per step, i.e. 1 % SLOWER — the epilogue is bound by the store burst, not by its barriers.
 #ifndef BF_NT_STORES
 #define BF_NT_STORES 1
 #endif
 constexpr bool NT_STORES = BF_NT_STORES;
 
-#ifdef BF_DEV
-template <typename YT, int H>
-__device__ __forceinline__ void epilogue_pipelined(char* region, const f32x4_t (&acc)[4][H], YT* y, int m0, int m_end,
-                                                   int n0, int N, int wm, int wn, int wid, int lane, int act,
-                                                   bool skip) {
-    constexpr int ROWB = TN * (int)sizeof(YT);          // 512 or 1024
-    constexpr int PASS_ROWS = sizeof(YT) == 4 ? 32 : 64;
-    constexpr int REGION = PASS_ROWS * ROWB;            // 32 KiB
-    constexpr int MBP = PASS_ROWS / 32;                 // fragment row-blocks per wave per pass: 1 or 2
-    constexpr int PASSES = (H + MBP - 1) / MBP;
-    constexpr int CHUNKS = ROWB / 16;                   // 16-byte chunks per row: 32 or 64
-    constexpr int EPC = 16 / (int)sizeof(YT);
-    constexpr int RPI = CHUNKS < 64 ? 64 / CHUNKS : 1;  // rows per wave instruction: 2 or 1
-    constexpr int INSTS = PASS_ROWS / 8 / RPI;          // per wave per pass: 4
-    static_assert(2 * REGION <= STAGE_BYTES, "epilogue regions must fit the consumed stage buffer");
-    const bool vec_ok = (N % EPC) == 0 && ((uintptr_t)y % 16) == 0;
-    // write side: row = (2 t + wm) 16 + (lane & 15); chunk swizzle depends on lane & 15 only
-    const int q = lane >> 4;
-    const int sw_w = sizeof(YT) == 2 ? ((lane & 15) >> 1) & 7 : lane & 7;
-    int wr_off[4];
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        const int c = sizeof(YT) == 2 ? wn * 8 + nb * 2 + (q >> 1) : wn * 16 + nb * 4 + q;
-        wr_off[nb] = (wm * 16 + (lane & 15)) * ROWB + ((c ^ sw_w) << 4) + (sizeof(YT) == 2 ? (q & 1) * 8 : 0);
-    }
-    // read side: row = wid (PASS_ROWS / 8) + it RPI + lane / CHUNKS, chunk = lane % CHUNKS; swizzle = (4 wid + it) & 7
-    const int rd_row = wid * (PASS_ROWS / 8) + (CHUNKS < 64 ? lane / CHUNKS : 0);
-    const int cq = CHUNKS < 64 ? lane % CHUNKS : lane;
-    const int n = n0 + cq * EPC;
-    const bool n_ok = n < N, n_full = vec_ok && n + EPC <= N;
-    f32x4_t rows[INSTS];
-    auto store_rows = [&](int pass) {
-        const int mrow = m0 + pass * PASS_ROWS + rd_row;
-#pragma unroll
-        for (int it = 0; it < INSTS; ++it) {
-            const int m = mrow + it * RPI;
-            if (m < m_end && n_ok) {
-                const f32x4_t v = rows[it];
-                YT* o = y + (unsigned)(m * N + n);
-                if (n_full) {
-                    // streaming store: y is not re-read by this kernel, keep it from evicting operand panels in L2
-                    if (NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(o));
-                    else *reinterpret_cast<f32x4_t*>(o) = v;
-                } else {
-                    const YT* e = reinterpret_cast<const YT*>(&v);
-                    for (int j = 0; j < EPC; ++j)
-                        if (n + j < N) o[j] = e[j];
-                }
-            }
-        }
-    };
-#pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-        char* R = region + (pass & 1) * REGION;
-        if (!skip) {
-#pragma unroll
-            for (int t = 0; t < MBP; ++t) {
-                const int mb = pass * MBP + t;
-                if (mb < H) {
-#pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) {
-                        const f32x4_t v = bf_apply_act(acc[nb][mb < H ? mb : 0], act);
-                        char* dst = R + wr_off[nb] + t * 32 * ROWB;
-                        if constexpr (sizeof(YT) == 4)
-                            *reinterpret_cast<f32x4_t*>(dst) = v;
-                        else if constexpr (__is_same(YT, __bf16))
-                            *reinterpret_cast<bf16x4_t*>(dst) = __builtin_convertvector(v, bf16x4_t);
-                        else
-                            *reinterpret_cast<f16x4_t*>(dst) = __builtin_convertvector(v, f16x4_t);
-                    }
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own writes landed; the previous pass's rows arrived
-        if (pass == 0) {
-            if (wm == 0) __builtin_amdgcn_s_barrier();  // rejoin: pairs with group 1's last k-step barrier
-        } else if (!skip) {
-            store_rows(pass - 1);
-        }
-        __builtin_amdgcn_s_barrier();  // every wave's blocks of this pass are in the region
-        if (!skip) {
-#pragma unroll
-            for (int it = 0; it < INSTS; ++it)
-                rows[it] = *reinterpret_cast<const f32x4_t*>(R + (rd_row + it * RPI) * ROWB +
-                                                             ((cq ^ ((wid * 4 + it) & 7)) << 4));
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (!skip) store_rows(PASSES - 1);
-}
-
-#endif  // BF_DEV
 
 // act() of a 16-byte chunk of YT outputs (8 x 16-bit or 4 x fp32), computed in fp32
 template <typename YT>
@@ -219,7 +122,7 @@ __device__ __forceinline__ f32x4_t act_chunk(f32x4_t c, int act) {
     }
 }
 
-// Epilogue: accumulators -> LDS as row-major rows of YT, in passes of 64 rows (32 for fp32 outputs) through the
+// The round-1 / early round-2 epilogue, kept for A/B builds (-DBF_EPI_WAVE=0): accumulators -> LDS as row-major rows of YT, in passes of 64 rows (32 for fp32 outputs) through the
 // just-consumed stage buffer -> whole-row 16-byte global stores.  A lane's fragment registers are 4 consecutive n of
 // one m (8 B for 16-bit outputs): written with ds_write_b64 into rows padded by 16 B (2-way bank aliasing only), then
 // every wave reads whole rows back — all row reads of a pass before its first store, one LDS round trip instead of one
@@ -310,6 +213,101 @@ __device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&ac
     }
 }
 
+
+// Wave-private epilogue (BF_EPI_WAVE, the product's): a wave's part of the tile is 16 h rows x 64 features — for every
+// 16-row block a full 128-byte line (256 bytes of fp32) per row.  The block goes through a 2 / 4 KiB slice of LDS that
+// only this wave touches (XOR-swizzled like the operand rows: conflict-free ds_write_b64 / ds_read_b128) and leaves as
+// 16-byte stores of whole lines, 8 (4) rows per instruction.  Nothing is exchanged between waves, so the epilogue has
+// no barrier at all: wave group 0 starts it a slot before group 1, and every wave runs it at its own pace.
+// `scratch` = this wave's 8 KiB of the stage buffer the k-loop consumed last (every fragment read of it is complete
+// when a wave gets here, see the kernel).
+#ifndef BF_EPI_WAVE
+#define BF_EPI_WAVE 1
+#endif
+template <typename YT, int H>
+__device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc)[4][H], YT* y, YT* y2, int m0,
+                                              int m_end, int n0, int N, int wm, int wn, int lane, int act) {
+    constexpr int ROWB = 64 * (int)sizeof(YT);   // 128 or 256
+    constexpr int BLK = 16 * ROWB;               // 2 or 4 KiB
+    constexpr int CH = ROWB / 16;                // 16-byte chunks per row: 8 or 16
+    constexpr int RPI = 64 / CH;                 // rows per store instruction: 8 or 4
+    constexpr int NI = 16 / RPI;                 // store instructions per block: 2 or 4
+    constexpr int EPC = 16 / (int)sizeof(YT);
+    asm volatile("" : "+v"(lane));               // offsets recomputed per tile, not hoisted into the k-loop's registers
+    const bool vec_ok = (N % EPC) == 0 && ((uintptr_t)y % 16) == 0 && (!y2 || ((uintptr_t)y2 % 16) == 0);
+    const int m_l = lane & 15, q = lane >> 4;
+    // write side: lane holds 4 consecutive features 16 nb + 4 q of row m_l
+    const int wsw = sizeof(YT) == 2 ? (m_l >> 1) & 7 : m_l;
+    int wr_off[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int c = sizeof(YT) == 2 ? nb * 2 + (q >> 1) : nb * 4 + q;
+        wr_off[nb] = m_l * ROWB + ((c ^ wsw) << 4) + (sizeof(YT) == 2 ? (q & 1) * 8 : 0);
+    }
+    // read side: instruction it covers rows it * RPI + lane / CH, chunk lane % CH
+    const int rr = lane / CH, rc = lane % CH;
+    const int n = n0 + wn * 64 + rc * EPC;
+    const bool n_ok = n < N, n_full = vec_ok && n + EPC <= N;
+    auto write_block = [&](int mb) {
+        char* R = scratch + (mb & 1) * BLK;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const f32x4_t v = y2 ? acc[nb][mb] : bf_apply_act(acc[nb][mb], act);
+            char* dst = R + wr_off[nb];
+            if constexpr (sizeof(YT) == 4)
+                *reinterpret_cast<f32x4_t*>(dst) = v;
+            else if constexpr (__is_same(YT, __bf16))
+                *reinterpret_cast<bf16x4_t*>(dst) = __builtin_convertvector(v, bf16x4_t);
+            else
+                *reinterpret_cast<f16x4_t*>(dst) = __builtin_convertvector(v, f16x4_t);
+        }
+    };
+    // software pipeline over the blocks: block mb + 1 is converted and written (other slice) behind the row reads of
+    // block mb — one LDS round trip per block instead of two
+    write_block(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int mb = 0; mb < H; ++mb) {
+        const char* R = scratch + (mb & 1) * BLK;
+        f32x4_t rows[NI];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int r = it * RPI + rr;
+            const int rsw = sizeof(YT) == 2 ? (r >> 1) & 7 : r;
+            rows[it] = *reinterpret_cast<const f32x4_t*>(R + r * ROWB + ((rc ^ rsw) << 4));
+        }
+        if (mb + 1 < H) write_block(mb + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int m = m0 + (2 * mb + wm) * 16 + it * RPI + rr;
+            if (m < m_end && n_ok) {
+                f32x4_t v = rows[it];
+                if (y2) {
+                    YT* o2 = y2 + (unsigned)(m * N + n);
+                    if (n_full) {
+                        if (NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(o2));
+                        else *reinterpret_cast<f32x4_t*>(o2) = v;
+                    } else {
+                        const YT* e = reinterpret_cast<const YT*>(&v);
+                        for (int j = 0; j < EPC; ++j)
+                            if (n + j < N) o2[j] = e[j];
+                    }
+                    v = act_chunk<YT>(v, act);
+                }
+                YT* o = y + (unsigned)(m * N + n);
+                if (n_full) {
+                    if (NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(o));
+                    else *reinterpret_cast<f32x4_t*>(o) = v;
+                } else {
+                    const YT* e = reinterpret_cast<const YT*>(&v);
+                    for (int j = 0; j < EPC; ++j)
+                        if (n + j < N) o[j] = e[j];
+                }
+            }
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // The kernel: persistent ping-pong over a host-built tile schedule.
@@ -473,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
             f32x4_t acc[4][H];
             frag wf[4], xf[H];
             // the four slots of one k-step; `dma()` issues this step's LDS DMA at the top of L0
-            auto kstep = [&](auto&& dma) {
+            auto kstep = [&](auto&& dma, auto last) {
                 const char* sb = smem + (g & 1) * STAGE_BYTES;
                 dma();
 #pragma unroll
@@ -519,7 +517,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
                 __builtin_amdgcn_s_setprio(0);
                 if (wm == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
+                // (with the wave-private epilogue group 1 does not meet group 0 again before the tile-end barrier: its
+                // last slot ends without one, which also keeps the two groups' barrier counts equal)
+                if (!(BF_EPI_WAVE && decltype(last)::value && wm == 1)) __builtin_amdgcn_s_barrier();
                 ++g;
             };
 
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
 #else
                     stage(cur, kt + 1, (g & 1) ^ 1, hc);
 #endif
-                });
+                }, std::false_type{});
             // last k-step: its DMA slot fetches k-step 0 of this workgroup's next tile
             kstep([&] {
 #ifdef BF_DEV
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
                     tile_setup(dn, nxt, s2, m2, n2, h2);
                     stage(nxt, 0, (g & 1) ^ 1, h2);
                 }
-            });
+            }, std::true_type{});
             // the last consumed buffer is (g-1)&1; buffer g&1 already holds k-step 0 of the next tile.  Group 0 is one
             // slot ahead here; it rejoins group 1 inside the epilogue (after the first pass's VALU work)
             YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
@@ -554,17 +554,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
 #ifdef BF_DEV
             if (p.flags & 16) m_end = 0;
             const bool skip = (p.flags & 8) != 0;
-            if (skip && !(p.flags & 32) && wm == 0) __builtin_amdgcn_s_barrier();  // the skipped epilogue's rejoin barrier
+#else
+            constexpr bool skip = false;
 #endif
-#ifdef BF_DEV
-            if (p.flags & 32)
-                epilogue_pipelined<YT, H>(smem + ((g - 1) & 1) * STAGE_BYTES, acc, y, m0, m_end, n0, N, wm, wn, wid,
-                                          lane, p.act, skip);
-            else if (!skip)
+            YT* y2 = p.y2 ? reinterpret_cast<YT*>(p.y2) + (long long)s * M * N : nullptr;
+#if BF_EPI_WAVE
+            // every fragment read of buffer (g - 1) & 1 is complete: group 0 passed its last barrier together with the
+            // end of group 1's last LDS slot, group 1 comes from its last MFMA slot
+            if (!skip)
+                epilogue_wave<YT, H>(smem + ((g - 1) & 1) * STAGE_BYTES + wid * 8192, acc, y, y2, m0, m_end, n0, N, wm, wn,
+                                     lane, p.act);
+#else
+            if (skip) {
+                if (wm == 0) __builtin_amdgcn_s_barrier();  // the skipped epilogue's rejoin barrier
+            } else {
+                epilogue_passes<YT, H>(smem + ((g - 1) & 1) * STAGE_BYTES, acc, y, y2, m0, m_end, n0, N, wm, wn, wid, lane,
+                                       p.act);
+            }
 #endif
-            epilogue_passes<YT, H>(smem + ((g - 1) & 1) * STAGE_BYTES, acc, y,
-                                   p.y2 ? reinterpret_cast<YT*>(p.y2) + (long long)s * M * N : nullptr, m0, m_end, n0, N, wm,
-                                   wn, wid, lane, p.act);
         };
         switch (h) {
             case 8: body(std::integral_constant<int, 8>{}); break;
