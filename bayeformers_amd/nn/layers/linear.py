@@ -65,7 +65,7 @@ class _PlannedLinearFn(torch.autograd.Function):
     """Forward of a layer whose weights were sampled by the model's cross-layer plan: only the MFMA GEMM is left."""
 
     @staticmethod
-    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, w_s, b_s, layer, S, seed, base, act):
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, w_s, b_s, layer, S, seed, base, act, keep_pre=False):
         ctx.layer, ctx.S, ctx.seed, ctx.base = layer, S, seed, base
         fwd = bfr.STATE.ctx
         if fwd is not None and fwd.plan is not None and id(layer) in fwd.plan.group_of:
@@ -74,8 +74,9 @@ class _PlannedLinearFn(torch.autograd.Function):
         ctx.cdt = w_s.dtype
         # an activation fused into the GEMM while gradients are recorded: the launch also stores the pre-activation,
         # and the backward folds act' (and the bias gradient's column sums) into one pass over the output gradient
-        keep_pre = bool(act) and any(ctx.needs_input_grad[:5])
-        if keep_pre:
+        # (keep_pre is decided by the caller from torch.is_grad_enabled(): inside forward() grad mode is always off and
+        # needs_input_grad reflects requires_grad even under no_grad — an inference step must not pay the second store)
+        if act and keep_pre:
             y, pre = ops.planned_linear_forward(x, w_s, b_s, S, layer.out_features, layer.in_features, act, True)
             ctx.act = act
             ctx.save_for_backward(x, pre)
@@ -86,7 +87,7 @@ class _PlannedLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         dx, dmu_w, drho_w, dmu_b, drho_b = _backward(ctx, grad)
-        return dx, dmu_w, drho_w, dmu_b, drho_b, None, None, None, None, None, None, None
+        return dx, dmu_w, drho_w, dmu_b, drho_b, None, None, None, None, None, None, None, None
 
 
 class Linear(KernelLayer):
@@ -159,7 +160,7 @@ class Linear(KernelLayer):
             fused = want_act and (not need_grad or (x2.dtype != torch.float32 and self.out_features % 8 == 0
                                                     and w_s.dtype == x2.dtype))
             y = _PlannedLinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, w_s, b_s, self, S,
-                                       bfr.STATE.seed, base, 1 if fused else 0)
+                                       bfr.STATE.seed, base, 1 if fused else 0, fused and need_grad)
             if want_act and not fused:
                 y = torch.nn.functional.gelu(y)
             self._lp_view, self._lp_dirty = slot, True

@@ -309,3 +309,26 @@ def test_gemm_act_pre_outputs():
         assert torch.equal(pre, plain)
         ref = torch.nn.functional.gelu(pre.double())
         assert (y.double() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-6
+
+
+def test_inference_forward_does_not_store_the_pre_activation(monkeypatch):
+    """Under no_grad the fused-GELU layer must take the one-output launch: the second (pre-activation) store belongs to
+    training steps only (trainable parameters alone must not switch it on)."""
+    from bayeformers_amd import ops
+
+    layer = bnn.Linear(128, 256)
+    layer.layer_id = 0
+    layer.activation = "gelu"
+    layer = layer.cuda()
+    model = bnn.Model(layer)
+    model.cross_layer_sampling = True
+    x = torch.randn(2 * 256, 128, device="cuda").bfloat16()
+
+    def boom(*a, **k):
+        raise AssertionError("bf_gemm_nt_act_pre called in an inference forward")
+
+    monkeypatch.setattr(ops, "gemm_nt_act_pre", boom)
+    bf.manual_seed(SEED, next_sample=0)
+    with torch.no_grad(), model.monte_carlo(2):
+        y = model(x)
+    assert y.shape == (512, 256)
