@@ -122,108 +122,13 @@ __device__ __forceinline__ f32x4_t act_chunk(f32x4_t c, int act) {
     }
 }
 
-// The round-1 / early round-2 epilogue, kept for A/B builds (-DBF_EPI_WAVE=0): accumulators -> LDS as row-major rows of YT, in passes of 64 rows (32 for fp32 outputs) through the
-// just-consumed stage buffer -> whole-row 16-byte global stores.  A lane's fragment registers are 4 consecutive n of
-// one m (8 B for 16-bit outputs): written with ds_write_b64 into rows padded by 16 B (2-way bank aliasing only), then
-// every wave reads whole rows back — all row reads of a pass before its first store, one LDS round trip instead of one
-// per row — and stores them with dwordx4 (512 contiguous bytes per row for bf16).  Pass p holds the tile's 16-row
-// blocks [p BPP, (p+1) BPP): block b belongs to wave group b & 1 as its fragment row-block b >> 1, so both groups
-// write in every pass.  Wave group 0 leaves the k-loop one slot before group 1: `rejoin` pairs with group 1's last
-// k-step barrier.
-template <typename YT, int H>
-__device__ __forceinline__ void epilogue_passes(char* region, const f32x4_t (&acc)[4][H], YT* y, YT* y2, int m0,
-                                                int m_end, int n0, int N, int wm, int wn, int wid, int lane, int act) {
-    constexpr int ROW = TN * (int)sizeof(YT) + 16;
-    constexpr int PASS_ROWS = sizeof(YT) == 4 ? 32 : 64;
-    constexpr int MBP = PASS_ROWS / 32;
-    constexpr int PASSES = (H + MBP - 1) / MBP;
-    constexpr int CHUNKS = TN * (int)sizeof(YT) / 16;
-    constexpr int EPC = 16 / (int)sizeof(YT);
-    constexpr int ROWS_PER_INST = 64 / CHUNKS > 0 ? 64 / CHUNKS : 1;
-    constexpr int INSTS = PASS_ROWS / 8 / ROWS_PER_INST;
-    const bool vec_ok = (N % EPC) == 0 && ((uintptr_t)y % 16) == 0;
-    const int wr_off = (wm * 16 + (lane & 15)) * ROW + (wn * 64 + (lane >> 4) * 4) * (int)sizeof(YT);
-    const int rd_row = wid * (PASS_ROWS / 8) + (CHUNKS < 64 ? lane / CHUNKS : 0);
-    const int rd_q = CHUNKS < 64 ? lane % CHUNKS : lane;
-    const int rd_off = rd_row * ROW + rd_q * 16;
-    const int n = n0 + rd_q * EPC;
-    const bool n_ok = n < N, n_full = vec_ok && n + EPC <= N;
-    // (letting group 0 write its first pass during the slot it is ahead of group 1, and dropping pass 0's leading
-    // barrier, was measured in the BERT-base step: no difference, 7.20 vs 7.20 ms of GEMM time)
-    if (wm == 0) __builtin_amdgcn_s_barrier();  // rejoin
-#pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int t = 0; t < MBP; ++t) {
-            const int mb = pass * MBP + t;
-            if (mb < H) {
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    // with a pre-activation output the rows go through LDS unactivated (in YT, as an unfused
-                    // Linear -> GELU would round them) and the activation is applied to the row chunks on their way out
-                    const f32x4_t v = y2 ? acc[nb][mb < H ? mb : 0] : bf_apply_act(acc[nb][mb < H ? mb : 0], act);
-                    char* dst = region + wr_off + t * 32 * ROW + nb * 16 * (int)sizeof(YT);
-                    if constexpr (sizeof(YT) == 4)
-                        *reinterpret_cast<f32x4_t*>(dst) = v;
-                    else if constexpr (__is_same(YT, __bf16))
-                        *reinterpret_cast<bf16x4_t*>(dst) = __builtin_convertvector(v, bf16x4_t);
-                    else
-                        *reinterpret_cast<f16x4_t*>(dst) = __builtin_convertvector(v, f16x4_t);
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const int mrow = m0 + pass * PASS_ROWS + rd_row;
-        f32x4_t rows[INSTS];
-#pragma unroll
-        for (int it = 0; it < INSTS; ++it)
-            rows[it] = *reinterpret_cast<const f32x4_t*>(region + rd_off + it * ROWS_PER_INST * ROW);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < INSTS; ++it) {
-            const int m = mrow + it * ROWS_PER_INST;
-            if (m < m_end && n_ok) {
-                f32x4_t v = rows[it];
-                if (y2) {
-                    YT* o2 = y2 + (unsigned)(m * N + n);
-                    if (n_full) {
-                        if (NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(o2));
-                        else *reinterpret_cast<f32x4_t*>(o2) = v;
-                    } else {
-                        const YT* e = reinterpret_cast<const YT*>(&v);
-                        for (int j = 0; j < EPC; ++j)
-                            if (n + j < N) o2[j] = e[j];
-                    }
-                    v = act_chunk<YT>(v, act);
-                }
-                YT* o = y + (unsigned)(m * N + n);
-                if (n_full) {
-                    // streaming store: y is not re-read by this kernel, keep it from evicting operand panels in L2
-                    if (NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(o));
-                    else *reinterpret_cast<f32x4_t*>(o) = v;
-                } else {
-                    const YT* e = reinterpret_cast<const YT*>(&v);
-                    for (int j = 0; j < EPC; ++j)
-                        if (n + j < N) o[j] = e[j];
-                }
-            }
-        }
-    }
-}
-
-
-// Wave-private epilogue (BF_EPI_WAVE, the product's): a wave's part of the tile is 16 h rows x 64 features — for every
+// Wave-private epilogue: a wave's part of the tile is 16 h rows x 64 features — for every
 // 16-row block a full 128-byte line (256 bytes of fp32) per row.  The block goes through a 2 / 4 KiB slice of LDS that
 // only this wave touches (XOR-swizzled like the operand rows: conflict-free ds_write_b64 / ds_read_b128) and leaves as
 // 16-byte stores of whole lines, 8 (4) rows per instruction.  Nothing is exchanged between waves, so the epilogue has
 // no barrier at all: wave group 0 starts it a slot before group 1, and every wave runs it at its own pace.
 // `scratch` = this wave's 8 KiB of the stage buffer the k-loop consumed last (every fragment read of it is complete
 // when a wave gets here, see the kernel).
-#ifndef BF_EPI_WAVE
-#define BF_EPI_WAVE 1
-#endif
 template <typename YT, int H>
 __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc)[4][H], YT* y, YT* y2, int m0,
                                               int m_end, int n0, int N, int wm, int wn, int lane, int act) {
@@ -519,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
                 __builtin_amdgcn_sched_barrier(0);
                 // (with the wave-private epilogue group 1 does not meet group 0 again before the tile-end barrier: its
                 // last slot ends without one, which also keeps the two groups' barrier counts equal)
-                if (!(BF_EPI_WAVE && decltype(last)::value && wm == 1)) __builtin_amdgcn_s_barrier();
+                if (!(decltype(last)::value && wm == 1)) __builtin_amdgcn_s_barrier();
                 ++g;
             };
 
@@ -558,20 +463,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
             constexpr bool skip = false;
 #endif
             YT* y2 = p.y2 ? reinterpret_cast<YT*>(p.y2) + (long long)s * M * N : nullptr;
-#if BF_EPI_WAVE
             // every fragment read of buffer (g - 1) & 1 is complete: group 0 passed its last barrier together with the
             // end of group 1's last LDS slot, group 1 comes from its last MFMA slot
             if (!skip)
                 epilogue_wave<YT, H>(smem + ((g - 1) & 1) * STAGE_BYTES + wid * 8192, acc, y, y2, m0, m_end, n0, N, wm, wn,
                                      lane, p.act);
-#else
-            if (skip) {
-                if (wm == 0) __builtin_amdgcn_s_barrier();  // the skipped epilogue's rejoin barrier
-            } else {
-                epilogue_passes<YT, H>(smem + ((g - 1) & 1) * STAGE_BYTES, acc, y, y2, m0, m_end, n0, N, wm, wn, wid, lane,
-                                       p.act);
-            }
-#endif
         };
         switch (h) {
             case 8: body(std::integral_constant<int, 8>{}); break;
