@@ -36,9 +36,9 @@
 namespace {
 
 // schedule policy bits (build_schedule): 1 = odd workgroups run their tiles in reverse order, 2 = fixed full-height
-// tiles (no balancing), 4 = XCD-chunked dealing
+// tiles (no balancing), 4 = XCD-chunked dealing, 8 = every XCD walks a contiguous share of each height class
 #ifndef BF_SCHED_POLICY
-#define BF_SCHED_POLICY 4
+#define BF_SCHED_POLICY 12
 #endif
 
 constexpr int TN = 256, TK = 64;
@@ -536,6 +536,14 @@ void build_schedule(int S, int layers, int tiles_n, int M, int n_cu, int policy,
                 t.h = hh;
                 // (sample, band of 1024 rows, column, row): the 32 concurrent tiles of an XCD share few panels
                 t.key = (((long long)xs * 4096 + t.m0 / 1024) * 4096 + cn) * 65536 + (t.m0 / UNIT);
+                // policy bit 8: (sample, group of 4 columns, 256-row band, column) — an XCD that walks this order keeps
+                // four W panels in its L2 while the x bands stream past them (groups of 3 / 4 / 6 / 9 / 12 columns measured
+                // in the BERT-base step on one box: GEMM 7.13 / 7.10 / 7.20 / 7.29 / 7.22 ms, L2 fills 302 / 307 / 299 / 310 /
+                // 318 MB per launch)
+                if (policy & 8) {
+                    const int cg = ((policy >> 8) & 15) ? (policy >> 8) & 15 : 4;  // columns per group (bits 8-11; 0 = 4)
+                    t.key = ((((long long)xs * 4096 + cn / cg) * 65536 + t.m0 / 256) * 4096 + cn) * 8 + (t.m0 / UNIT) % 8;
+                }
                 tiles.push_back(t);
                 u += hh;
             }
@@ -555,7 +563,45 @@ void build_schedule(int S, int layers, int tiles_n, int M, int n_cu, int policy,
         return a.h != b.h ? a.h > b.h : a.key < b.key;
     });
     const bool per_xcd = (policy & 4) && grid % 8 == 0 && total >= grid;
-    if (!per_xcd) {
+    // (only when every height class fills whole rounds: then a workgroup that takes every 32nd tile of its XCD's list
+    // gets the same number of tiles of every class; otherwise the span dealing below, which balances odd classes)
+    bool whole_classes = (policy & 8) && grid % 8 == 0 && total >= grid;
+    for (int a = 0; a < total && whole_classes;) {
+        int b = a;
+        while (b < total && tiles[b].h == tiles[a].h) ++b;
+        if ((b - a) % grid) whole_classes = false;
+        a = b;
+    }
+    if (whole_classes) {
+        // Every XCD takes a CONTIGUOUS share of each height class (shares rotate so that the XCDs' tile counts stay
+        // within one of each other) and its 32 workgroups walk that share 32 tiles at a time: consecutive rounds of an
+        // XCD are neighbours in the locality order, so the panels one round pulled into the XCD's L2 serve the next
+        // (modelled L2 fills of the q/k/v launch: 3.2 -> 2.4 x the operand bytes, tools/sched_l2_sim.py).  A workgroup
+        // draws every 32nd tile of its XCD's list, i.e. the same number of tiles of every class: the unit balance of
+        // the class-by-class dealing is kept.
+        const int span = grid / 8;
+        std::vector<std::vector<int>> share(8);
+        int carry = 0;
+        for (int a = 0; a < total;) {
+            int b = a;
+            while (b < total && tiles[b].h == tiles[a].h) ++b;
+            const int n = b - a;
+            int start = a;
+            for (int i = 0; i < 8; ++i) {
+                const int x = (i + carry) % 8;
+                const int cnt = (int)(((long long)n * (i + 1)) / 8 - ((long long)n * i) / 8);
+                for (int k = start; k < start + cnt; ++k) share[x].push_back(k);
+                start += cnt;
+            }
+            carry = (carry + n % 8) % 8;
+            a = b;
+        }
+        for (int x = 0; x < 8; ++x)
+            for (size_t j = 0; j < share[x].size(); ++j) {
+                const int r = (int)(j / span), in = (int)(j % span);
+                lists[x * span + ((r & 1) ? span - 1 - in : in)].push_back(share[x][j]);
+            }
+    } else if (!per_xcd) {
         for (int k = 0; k < total; ++k) {
             const int r = k / grid, pos = k % grid;
             lists[(r & 1) ? grid - 1 - pos : pos].push_back(k);
