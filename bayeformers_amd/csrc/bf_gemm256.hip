@@ -376,9 +376,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
             f32x4_t acc[4][H];
             frag wf[4], xf[H];
             // the four slots of one k-step; `dma()` issues this step's LDS DMA at the top of L0
-            auto kstep = [&](auto&& dma, auto last) {
+            // `defer`: the first k-step of a tile that follows another one.  There is no barrier between the tiles: the
+            // DMA of this step lands in the buffer whose slices the waves used as epilogue scratch, so group 0 issues
+            // it only after the step's first barrier (every wave of both groups reaches that barrier — group 1 as
+            // its start-of-tile barrier — after its epilogue); group 1's own issue point already lies behind it.
+            auto kstep = [&](auto&& dma, auto last, bool defer) {
                 const char* sb = smem + (g & 1) * STAGE_BYTES;
-                dma();
+                if (!(defer && wm == 0)) dma();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if constexpr (TRW) wf[i] = tr_read(tr_w0 + (g & 1) * STAGE_BYTES, i, std::integral_constant<int, 0>{});
@@ -392,6 +396,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
+                if (defer && wm == 0) dma();
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
 #else
                     stage(cur, kt + 1, (g & 1) ^ 1, hc);
 #endif
-                }, std::false_type{});
+                }, std::false_type{}, round > 0 && kt == 0);
             // last k-step: its DMA slot fetches k-step 0 of this workgroup's next tile
             kstep([&] {
 #ifdef BF_DEV
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
                     tile_setup(dn, nxt, s2, m2, n2, h2);
                     stage(nxt, 0, (g & 1) ^ 1, h2);
                 }
-            }, std::true_type{});
+            }, std::true_type{}, round > 0 && nk == 1);
             // the last consumed buffer is (g-1)&1; buffer g&1 already holds k-step 0 of the next tile.  Group 0 is one
             // slot ahead here; it rejoins group 1 inside the epilogue (after the first pass's VALU work)
             YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
         d = dn;
         ++round;
         tile_setup(d, cur, s, m0, n0, h);
-        __builtin_amdgcn_s_barrier();  // every wave has left the epilogue before the region takes DMA again
+        // (no barrier between tiles: see `defer` in kstep)
     }
 }
 
