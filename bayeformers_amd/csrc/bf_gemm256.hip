@@ -114,8 +114,8 @@ __device__ __forceinline__ f32x4_t act_chunk(f32x4_t c, int act) {
         typedef __attribute__((ext_vector_type(8))) YT yt8;
         typedef __attribute__((ext_vector_type(4))) YT yt4;
         const yt8 h = __builtin_bit_cast(yt8, c);
-        const f32x4_t lo = bf_apply_act(f32x4_t{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}, act);
-        const f32x4_t hi = bf_apply_act(f32x4_t{(float)h[4], (float)h[5], (float)h[6], (float)h[7]}, act);
+        const f32x4_t lo = bf_apply_act<true>(f32x4_t{(float)h[0], (float)h[1], (float)h[2], (float)h[3]}, act);
+        const f32x4_t hi = bf_apply_act<true>(f32x4_t{(float)h[4], (float)h[5], (float)h[6], (float)h[7]}, act);
         const yt4 a = __builtin_convertvector(lo, yt4), b = __builtin_convertvector(hi, yt4);
         const yt8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
         return __builtin_bit_cast(f32x4_t, r);
@@ -157,7 +157,7 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
         char* R = scratch + (mb & 1) * BLK;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            const f32x4_t v = y2 ? acc[nb][mb] : bf_apply_act(acc[nb][mb], act);
+            const f32x4_t v = y2 ? acc[nb][mb] : bf_apply_act<sizeof(YT) == 2>(acc[nb][mb], act);
             char* dst = R + wr_off[nb];
             if constexpr (sizeof(YT) == 4)
                 *reinterpret_cast<f32x4_t*>(dst) = v;
