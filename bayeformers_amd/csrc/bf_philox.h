@@ -120,6 +120,14 @@ BF_D bf_philox_inv bf_philox_prepare(uint32_t group_lo, uint32_t group_hi, uint3
     return v;
 }
 
+// a ^ b ^ key in one instruction (gfx950's three-input bit operation; hipcc emits two v_xor for it).  `key` is the round
+// key: wave-uniform by construction (derived from the seed), hence the scalar-register constraint.
+BF_D uint32_t bf_xor3_key(uint32_t a, uint32_t b, uint32_t key) {
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "s"(key));
+    return r;
+}
+
 BF_D bf_u32x4 bf_philox_finish(const bf_philox_inv& v, uint32_t sample, uint32_t stream, uint32_t k0, uint32_t k1) {
     // round 0, the sample-dependent word (uniform across the wave: scalar arithmetic)
     const uint64_t p1s = (uint64_t)BF_PHILOX_M1 * stream;
@@ -139,9 +147,9 @@ BF_D bf_u32x4 bf_philox_finish(const bf_philox_inv& v, uint32_t sample, uint32_t
     for (int r = 3; r < BF_PHILOX_ROUNDS; ++r) {
         const uint64_t p0 = (uint64_t)BF_PHILOX_M0 * c0;
         const uint64_t p1 = (uint64_t)BF_PHILOX_M1 * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ ka;
+        const uint32_t n0 = bf_xor3_key((uint32_t)(p1 >> 32), c1, ka);
         const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ kb;
+        const uint32_t n2 = bf_xor3_key((uint32_t)(p0 >> 32), c3, kb);
         const uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         ka += BF_PHILOX_W0;
