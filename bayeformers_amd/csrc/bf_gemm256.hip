@@ -11,14 +11,15 @@
 //     destination is lane-linear, so the swizzle is applied to the per-lane SOURCE address and again on the
 //     fragment read, which makes every ds_read_b128 of an MFMA fragment bank-conflict-free;
 //   * the MFMA runs with swapped operands (D rows = n, cols = m) so each lane owns 4 consecutive output features
-//     of one row of y and the epilogue stores 8 B (bf16/fp16) or 16 B (fp32) per lane;
+//     of one row of y; the epilogue moves a wave's 16 h x 64 part through a private LDS slice and stores whole
+//     128-byte lines (epilogue_wave below);
 //   * WHICH tiles a workgroup runs is decided on the host (build_schedule below): the output is cut into columns
 //     (sample, layer, n-tile) of ceil(M/32) units of 32 rows, every column into tiles of near-equal height, and the
 //     tiles are dealt to the 256 persistent workgroups so that all of them carry the same number of units.  With
 //     fixed 256-row tiles BERT-base's launches have 480 k tiles = 1.875 k rounds of 256 CUs — 1/16 of the CU-time is
-//     a partial last round; with heights {8, 7} every CU gets exactly 15 k units.  Tiles of one round form a
-//     contiguous run per XCD in (sample, m-band, column) order, so the W_s n-panel and the x m-panels an XCD's 32
-//     CUs re-read stay in its private 4 MiB L2.
+//     a partial last round; with heights {8, 7} every CU gets exactly 15 k units.  Every XCD walks a contiguous
+//     share of each height class in (sample, column group, m-band, column) order, so the W_s n-panels and the x
+//     m-bands its 32 CUs re-read stay in its private 4 MiB L2 from one round to the next.
 // Requirements: K % 64 == 0, 16-byte aligned operands; M and N are arbitrary (edge rows are clamped on load and
 // masked on store).  Everything else goes to the generic kernel in bf_gemm.hip.
 #include <stdlib.h>
@@ -230,13 +231,13 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
 //   * the LDS DMA issued in the LAST k-step of a tile fetches k-step 0 of the workgroup's NEXT tile into the buffer
 //     that would otherwise idle, and is retired by the k-loop's existing waits — the next tile starts without a
 //     cold-start load;
-//   * the epilogue stages the accumulators through the just-consumed buffer in passes, so the prefetched stage in
-//     the other buffer survives it; its global stores are not waited for until the next tile's first k-step
-//     retires them together with that step's DMA.
+//   * the epilogue is wave-private (epilogue_wave): no barrier between a tile's last k-step and the next tile's
+//     first slot barrier; the next tile's first DMA (into the buffer whose slices were epilogue scratch) waits for
+//     that barrier (`defer` in kstep).
 // Schedule entry (int4): x = (layer, sample) pair index into w / bias / y, y = sample index into x,
 // z = n-tile | height << 24 (height in 32-row units; 0 = no tile), w = first row.
-// TR = true: the TN form used by the weight-gradient GEMM of the backward pass, dW[n][k] = sum_m dy[m][n] x[m][k]: both
-// operands are CONTRACTION-major in memory — p.x is [batch][K][M] (dy: rows = contraction index m, M = output rows n),
+// TRX / TRW = the operand is contraction-major.  Both: the TN form used by the weight-gradient GEMM of the backward pass,
+// dW[n][k] = sum_m dy[m][n] x[m][k]: both operands are CONTRACTION-major in memory — p.x is [batch][K][M] (dy: rows = contraction index m, M = output rows n),
 // p.w is [batch][K][N] (x) — so no transposed copies of dy and x are ever made.  A stage then holds two [64][256]
 // tiles (64 contraction rows of 512 B); their 32-byte granules are XOR-swizzled by the row (again on the DMA source
 // address) and the MFMA fragments come out through the LDS transpose read ds_read_b64_tr_b16: two reads give a lane
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
                 }
             }, std::true_type{}, round > 0 && nk == 1);
             // the last consumed buffer is (g-1)&1; buffer g&1 already holds k-step 0 of the next tile.  Group 0 is one
-            // slot ahead here; it rejoins group 1 inside the epilogue (after the first pass's VALU work)
+            // slot ahead here and stays ahead through its epilogue
             YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
             int m_end = min(M, m0 + h * UNIT);
 #ifdef BF_DEV
