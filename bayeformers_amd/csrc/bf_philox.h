@@ -98,7 +98,7 @@ BF_D void bf_box_muller_dev(uint32_t a, uint32_t b, float& z0, float& z1) {
 // to bf_philox4x32 by construction (tests/test_gpu_philox.py compares the kernels that use it with the oracle).
 struct bf_philox_inv {
     uint32_t c3a;   // round 0: lo(M0 * group_lo)                              -> c3 entering round 1
-    uint32_t x1;    // round 1: lo(M1 * c2a) ^ (k0 + 2 W0)   (c1 entering round 2, pre-xored with that round's key)
+    uint32_t x1;    // round 1: lo(M1 * c2a)                 (c1 entering round 2; that round's key joins in bf_philox_finish)
     uint32_t h0k;   // round 2: hi(M0 * c0b) ^ (k1 + 2 W1)   (c0b = c0 entering round 2, sample-independent)
     uint32_t l0;    // round 2: lo(M0 * c0b)                                  -> c3 entering round 3
 };
@@ -114,7 +114,7 @@ BF_D bf_philox_inv bf_philox_prepare(uint32_t group_lo, uint32_t group_hi, uint3
     const uint64_t r0 = (uint64_t)BF_PHILOX_M0 * c0b;                         // round 2
     bf_philox_inv v;
     v.c3a = (uint32_t)p0;
-    v.x1 = (uint32_t)q1 ^ (k0 + 2u * BF_PHILOX_W0);
+    v.x1 = (uint32_t)q1;
     v.h0k = (uint32_t)(r0 >> 32) ^ (k1 + 2u * BF_PHILOX_W1);
     v.l0 = (uint32_t)r0;
     return v;
@@ -138,7 +138,7 @@ BF_D bf_u32x4 bf_philox_finish(const bf_philox_inv& v, uint32_t sample, uint32_t
     const uint32_t c3b = (uint32_t)q0;                                        // c3 entering round 2 (uniform)
     // round 2: one product left
     const uint64_t r1 = (uint64_t)BF_PHILOX_M1 * c2b;
-    uint32_t c0 = (uint32_t)(r1 >> 32) ^ v.x1;
+    uint32_t c0 = bf_xor3_key((uint32_t)(r1 >> 32), v.x1, k0 + 2u * BF_PHILOX_W0);
     uint32_t c1 = (uint32_t)r1;
     uint32_t c2 = v.h0k ^ c3b;
     uint32_t c3 = v.l0;
