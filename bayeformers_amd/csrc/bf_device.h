@@ -36,6 +36,13 @@ __device__ __forceinline__ float dpp_add(float v) {
     const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true);
     return v + __builtin_bit_cast(float, t);
 }
+// the four DPP steps inside a row of 16 lanes: lanes 15, 31, 47 and 63 end up with their row's sum
+__device__ __forceinline__ float row_sum(float v) {
+    v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+    return dpp_add<0x118, 0xf>(v);  // row_shr:8
+}
 __device__ __forceinline__ float wave_sum(float v) {
     v = dpp_add<0x111, 0xf>(v);  // row_shr:1
     v = dpp_add<0x112, 0xf>(v);  // row_shr:2

@@ -125,7 +125,7 @@ struct BodyArgs {
 // block: 16-byte loads stay contiguous across the wave) x the samples of chunk blockIdx.y.  Several groups per thread
 // amortise the two wave reductions a sample needs (about a quarter of the per-sample instructions at one group).
 template <int PRIOR, int OUT_DT>
-__device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[kMaxSChunk][2], float (*cst)[2]) {
+__device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][kMaxSChunk][2], float (*cst)[2]) {
     constexpr int G = kGPT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -222,12 +222,12 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[kMax
                     else *reinterpret_cast<f32x4_t*>(outp + idx * 4) = w4;
                 }
             }
-            const float lq = wave_sum(-0.5f * (q2[0] + q2[1]));
-            const float lp = wave_sum(p2[0] + p2[1]);
-            if (lane == 0) {
-                red[wid][s - s_begin][0] = lp;
-                red[wid][s - s_begin][1] = lq;
-            }
+            // per sample only the four in-row DPP steps: the row sums of lanes 15/31/47/63 go to LDS and the block's
+            // final fp64 pass adds 16 terms per scalar instead of 4 (the two cross-row steps, the readlane and their
+            // moves were ~10 of the ~150 instructions a wave spends per sample)
+            const float lq = row_sum(-0.5f * (q2[0] + q2[1]));
+            const float lp = row_sum(p2[0] + p2[1]);
+            if ((lane & 15) == 15) *reinterpret_cast<f32x2_t*>(&red[wid][lane >> 4][s - s_begin][0]) = f32x2_t{lp, lq};
         }
     } else
     for (int s = s_begin; s < s_end; ++s) {
@@ -275,10 +275,7 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[kMax
         }
         lq = wave_sum(lq);
         lp = wave_sum(lp);
-        if (lane == 0) {
-            red[wid][s - s_begin][0] = lp;
-            red[wid][s - s_begin][1] = lq;
-        }
+        if (lane < 4) *reinterpret_cast<f32x2_t*>(&red[wid][lane][s - s_begin][0]) = lane == 0 ? f32x2_t{lp, lq} : f32x2_t{0.f, 0.f};
     }
     // sample-independent parts: sum_e(-c - log sigma_e) for q, sum_e(-c - log sigma_p,e) for a Gaussian prior
     constq = wave_sum(constq);
@@ -292,7 +289,11 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[kMax
         const int sl = tid >> 1, j = tid & 1;
         double acc = 0.0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) acc += (double)red[w][sl][j] + (double)cst[w][j];
+        for (int w = 0; w < 4; ++w) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc += (double)red[w][r][sl][j];
+            acc += (double)cst[w][j];
+        }
         a.partial_row[(s_begin + sl) * 2 + j] = acc;
     }
 }
@@ -300,7 +301,7 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[kMax
 // Per-layer launch: grid = (nblk, ny).  Segment 0 (the weight) is written as OUT_DT, segment 1 (the bias) as fp32.
 template <int PRIOR, int OUT_DT>
 __global__ __launch_bounds__(kThreads) void bf_sample_logprob_kernel(const SampleParams p) {
-    __shared__ float red[4][kMaxSChunk][2];
+    __shared__ float red[4][4][kMaxSChunk][2];
     __shared__ float cst[4][2];
     const int si = (p.nseg > 1 && blockIdx.x >= p.seg[1].block_begin) ? 1 : 0;
     const SegDesc& sg = p.seg[si];
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(kThreads) void bf_sample_table_kernel(const TableEn
                                                                    uint32_t k1, uint32_t sample_base,
                                                                    const uint32_t* __restrict__ counter,
                                                                    double* __restrict__ partials) {
-    __shared__ float red[4][kMaxSChunk][2];
+    __shared__ float red[4][4][kMaxSChunk][2];
     __shared__ float cst[4][2];
     const uint32_t gb = block0 + blockIdx.x;
     const TableEntry& e = table[entry_of_block[gb]];
