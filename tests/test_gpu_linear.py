@@ -110,7 +110,9 @@ def test_batched_equals_serial_and_is_deterministic(cases):
 GEMM_SHAPES = [(1, 1, 1, 8), (2, 5, 3, 8), (1, 128, 128, 32), (3, 130, 70, 72), (2, 33, 129, 40), (1, 257, 2, 768),
                (2, 64, 10, 512), (1, 17, 9, 33), (2, 31, 65, 100), (1, 300, 256, 264),
                # K % 64 == 0 and M*N >= 128*128: the 256x256x64 LDS-DMA kernel, with ragged M and N edges
-               (1, 256, 256, 64), (2, 300, 200, 128), (3, 513, 259, 192), (1, 1000, 130, 768), (2, 129, 1030, 64)]
+               (1, 256, 256, 64), (2, 300, 200, 128), (3, 513, 259, 192), (1, 1000, 130, 768), (2, 129, 1030, 64),
+               # one k-step per tile and two tiles per workgroup: the tile-to-tile hand-over with nothing in between
+               (12, 4096, 512, 64)]
 
 
 @pytest.mark.parametrize("S,M,N,K", GEMM_SHAPES)
@@ -148,7 +150,7 @@ def test_gemm_detects_transposes():
 
 
 @pytest.mark.parametrize("batch,Mc,N,K", [(1, 64, 8, 8), (2, 128, 256, 256), (3, 192, 200, 136), (1, 1024, 776, 264),
-                                          (2, 64, 1032, 40), (20, 2048, 768, 768), (1, 320, 24, 520)])
+                                          (2, 64, 1032, 40), (20, 2048, 768, 768), (1, 320, 24, 520), (40, 64, 768, 768)])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_gemm_tn_against_torch(batch, Mc, N, K, dt):
     """bf_gemm_tn (dW = dy^T x, operands read contraction-major through the LDS transpose read) against an fp64 einsum
@@ -163,7 +165,7 @@ def test_gemm_tn_against_torch(batch, Mc, N, K, dt):
 
 
 @pytest.mark.parametrize("S,M,N,K", [(1, 128, 64, 128), (2, 300, 128, 200), (3, 513, 192, 264), (10, 4096, 768, 768),
-                                      (1, 1000, 3072, 776), (2, 129, 64, 1032)])
+                                      (1, 1000, 3072, 776), (2, 129, 64, 1032), (12, 4096, 64, 512)])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_gemm_nn_against_torch(S, M, N, K, dt):
     """bf_gemm_nn (dx = dy W_s, W_s read contraction-major through the LDS transpose read, dy K-contiguous) against an
