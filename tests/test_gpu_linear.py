@@ -137,6 +137,31 @@ def test_gemm_nt_against_torch(S, M, N, K, wdt):
     assert (y.double() - ref).abs().max().item() <= 1e-5 * (ref.abs().max().item() + np.sqrt(K))
 
 
+@pytest.mark.parametrize("S,L,M,N,K,act", [(10, 3, 4096, 768, 768, 0), (10, 1, 4096, 3072, 768, 1), (12, 1, 4096, 512, 64, 0),
+                                            (3, 1, 1000, 520, 192, 1)])
+def test_gemm_forms_are_repeatable(S, L, M, N, K, act):
+    """The persistent kernel hands LDS buffers from one tile to the next without a workgroup barrier in between and its
+    epilogue runs per wave: a missing dependency would show as run-to-run differences.  Every form, many launches,
+    bit for bit."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(S, M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(L, S, N, K, device="cuda", generator=g) * 0.05).bfloat16()
+    b = torch.randn(L, S, N, device="cuda", generator=g)
+    ref = ops.gemm_nt_layers(x, w, b, L, S, M, N, K, M * K, torch.bfloat16, act).clone()
+    for _ in range(40):
+        assert torch.equal(ops.gemm_nt_layers(x, w, b, L, S, M, N, K, M * K, torch.bfloat16, act), ref)
+    a = torch.randn(S, M, N, device="cuda", generator=g).bfloat16()
+    if M % 64 == 0 and N % 8 == 0 and K % 8 == 0:
+        r = ops.gemm_tn(a, x).clone()
+        for _ in range(20):
+            assert torch.equal(ops.gemm_tn(a, x), r)
+    if N % 64 == 0 and K % 8 == 0:
+        w1 = w[0].contiguous()
+        r = ops.gemm_nn(a, w1).clone()
+        for _ in range(20):
+            assert torch.equal(ops.gemm_nn(a, w1), r)
+
+
 def test_gemm_detects_transposes():
     """Asymmetric operands: a swapped row/col mapping in the MFMA epilogue cannot pass."""
     M, N, K = 48, 80, 64
