@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams 
 
     for (int key0 = 0; key0 < p.T; key0 += TKEY) {
         if (key0) __syncthreads();  // the previous tile's fragment reads are done
+#ifdef BF_DEV
         if (!((p.ablate & 2) && (blockIdx.x | blockIdx.y | blockIdx.z)))
+#endif
         // stage K ([key][d], chunk ^= key & 7) and V ([key][d], 160-byte rows), 16 bytes per lane
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -186,7 +188,9 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams 
 
     // lane (query li, group lg) holds features db*16 + 4*lg + 0..3 of its query: 8-byte stores
     T* ob = reinterpret_cast<T*>(p.out) + ((long long)b * p.T * p.H + h) * HD;
+#ifdef BF_DEV
     if (!(p.ablate & 1) || run_sum[0] == 12345.f)
+#endif
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
         const float inv = run_sum[qi] > 0.f ? 1.0f / run_sum[qi] : 0.f;
