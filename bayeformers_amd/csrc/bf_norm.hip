@@ -209,18 +209,19 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_bwd_kernel(
 
 __global__ __launch_bounds__(1024) void layernorm_param_grad_kernel(const float* __restrict__ partial, int nblocks, int N,
                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    // block = 64 columns x 16 lanes over the workgroup axis; fixed order -> deterministic
-    __shared__ float sh[16][64];
-    const int which = blockIdx.y, n = blockIdx.x * 64 + (threadIdx.x & 63), cl = threadIdx.x >> 6;
+    // block = 16 columns x 64 lanes over the workgroup axis (2 N / 16 blocks: 96 for N = 768 — with 64 columns per
+    // block the 24 blocks of a launch took 21 us for 6 MB of partials); fixed order -> deterministic
+    __shared__ float sh[64][16];
+    const int which = blockIdx.y, c = threadIdx.x & 15, n = blockIdx.x * 16 + c, cl = threadIdx.x >> 4;
     float acc = 0.f;
     if (n < N)
-        for (int b = cl; b < nblocks; b += 16) acc += partial[((long long)b * 2 + which) * N + n];
-    sh[cl][threadIdx.x & 63] = acc;
+        for (int b = cl; b < nblocks; b += 64) acc += partial[((long long)b * 2 + which) * N + n];
+    sh[cl][c] = acc;
     __syncthreads();
     if (cl == 0 && n < N) {
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) t += sh[i][threadIdx.x];
+        for (int i = 0; i < 64; ++i) t += sh[i][c];
         (which ? dbeta : dgamma)[n] = t;
     }
 }
@@ -448,7 +449,7 @@ int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const v
     }
 #undef BF_LNB_DISPATCH
     if (rc) return rc;
-    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((N + 63) / 64, 2), dim3(1024), 0, stream, partial, nb, N, d_dgamma,
+    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((N + 15) / 16, 2), dim3(1024), 0, stream, partial, nb, N, d_dgamma,
                        d_dbeta);
     BF_HIP_CHECK(hipGetLastError());
     return 0;

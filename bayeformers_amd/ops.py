@@ -511,8 +511,8 @@ def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor,
     g2 = grad_out.reshape(-1, N)
     g2 = (g2 if g2.dtype == x.dtype else g2.to(x.dtype)).contiguous()
     dz = torch.empty_like(x2)
-    dgamma = torch.empty(N, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(N, dtype=torch.float32, device=x.device)
+    dgb = torch.empty((2, N), dtype=torch.float32, device=x.device)  # one buffer: one cast for both in the caller
+    dgamma, dbeta = dgb[0], dgb[1]
     lib = _C.lib()
     need = lib.bf_add_layernorm_bwd_workspace_bytes(x2.shape[0], N)
     ws = workspace(x.device, need)
@@ -537,8 +537,12 @@ class AddLayerNormFn(torch.autograd.Function):
         x, residual, gamma = ctx.saved_tensors
         dz, dgamma, dbeta = add_layernorm_backward(x, residual if ctx.has_res else None, gamma, grad_out, ctx.eps)
         need = ctx.needs_input_grad
+        if gamma.dtype != torch.float32 and (need[2] or need[3]):
+            # dgamma and dbeta are the two rows of one fp32 buffer: cast them with one launch
+            both = dgamma._base.to(gamma.dtype) if dgamma._base is not None else torch.stack((dgamma, dbeta)).to(gamma.dtype)
+            dgamma, dbeta = both[0], both[1]
         return (dz if need[0] else None, dz if (ctx.has_res and need[1]) else None,
-                dgamma.to(gamma.dtype) if need[2] else None, dbeta.to(gamma.dtype) if need[3] else None, None)
+                dgamma if need[2] else None, dbeta if need[3] else None, None)
 
 
 def layernorm_supported(x: Tensor, residual: Optional[Tensor], ln) -> bool:

@@ -49,14 +49,15 @@ def main():
     for k, c in kernels.most_common():
         print(f"{c / n:8.1f}  {k[:110]}")
     print("\n== host ops with device time, grouped by innermost stack frames (per step)")
-    ka = prof.key_averages(group_by_stack_n=6)
+    ka = prof.key_averages(group_by_stack_n=12)
     rows = []
     for a in ka:
         if a.device_time_total <= 0:
             continue
         if not any(p.lower() in a.key.lower() for p in pats):
             continue
-        rows.append((a.count / n, a.device_time_total / n, a.key, [s for s in a.stack if "site-packages/torch/" not in s][:4]))
+        rows.append((a.count / n, a.device_time_total / n, a.key,
+                     [s for s in a.stack if "site-packages/torch/" not in s and "dist-packages/torch/" not in s][:4]))
     rows.sort(key=lambda r: -r[0])
     for cnt, us, key, stack in rows[:60]:
         print(f"{cnt:7.1f} x  {us:8.1f} us  {key}")
