@@ -43,6 +43,14 @@ __device__ __forceinline__ float row_sum(float v) {
     v = dpp_add<0x114, 0xf>(v);  // row_shr:4
     return dpp_add<0x118, 0xf>(v);  // row_shr:8
 }
+// sum over each 32-lane half of the wave, returned to every lane of that half
+__device__ __forceinline__ float half_sum(float v, int lane) {
+    v = row_sum(v);
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3: lanes 31 / 63 hold their half's sum
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    return lane < 32 ? lo : hi;
+}
 __device__ __forceinline__ float wave_sum(float v) {
     v = dpp_add<0x111, 0xf>(v);  // row_shr:1
     v = dpp_add<0x112, 0xf>(v);  // row_shr:2

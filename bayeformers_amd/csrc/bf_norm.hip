@@ -107,6 +107,60 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_kernel(
     }
 }
 
+// Rows of 32 V vectors (N = 256 V: 768, 1024): HALF a wave per row, V vectors per lane, so every lane of every load,
+// store and arithmetic instruction is busy (one wave per row leaves a quarter of the lanes of N = 768 idle), two rows
+// per wave.
+template <typename T, typename GT, int V>
+__global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_half_kernel(
+    const T* __restrict__ x, const T* __restrict__ res, const GT* __restrict__ gamma, const GT* __restrict__ beta,
+    T* __restrict__ out, long long rows, int N, float eps) {
+    const int lane = threadIdx.x & 63, hl = lane & 31;
+    const long long row_raw = ((long long)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    if (row_raw - (lane >> 5) >= rows) return;           // the whole wave is past the end
+    const bool live = row_raw < rows;
+    const long long row = live ? row_raw : rows - 1;      // the idle half of the last wave reads a valid row
+    const T* xr = x + row * N;
+    const T* rr = res ? res + row * N : nullptr;
+    float v[V][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < V; ++c) {
+        const int vi = hl + 32 * c;
+        load8(xr + vi * 8, v[c]);
+        if (rr) {
+            float r[8];
+            load8(rr + vi * 8, r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[c][i] += r[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += v[c][i];
+    }
+    const float inv_n = 1.0f / (float)N;
+    const float mean = half_sum(sum, lane) * inv_n;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < V; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float d = v[c][i] - mean;
+            sq = fmaf(d, d, sq);
+        }
+    const float rstd = 1.0f / sqrtf(half_sum(sq, lane) * inv_n + eps);
+    if (!live) return;
+    T* orow = out + row * N;
+#pragma unroll
+    for (int c = 0; c < V; ++c) {
+        const int vi = hl + 32 * c;
+        float g[8], b[8], o[8];
+        load8(gamma + vi * 8, g);
+        load8(beta + vi * 8, b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = fmaf((v[c][i] - mean) * rstd, g[i], b[i]);
+        store8(orow + vi * 8, o);
+    }
+}
+
 // Backward of out = LayerNorm(x + residual) * gamma + beta.  z = x + residual and its row statistics are recomputed
 // (nothing but the forward's inputs is kept), then with zh = (z - mean) * rstd and a = dy * gamma:
 //     dz = rstd * (a - mean_row(a) - zh * mean_row(a * zh))      (= dx = dresidual)
@@ -253,6 +307,21 @@ template <typename T, typename GT>
 int launch_vpl(const void* x, const void* res, const void* gamma, const void* beta, void* out, long long rows, int N,
                float eps, hipStream_t stream) {
     const int nvec = N >> 3;
+    if (nvec % 32 == 0 && nvec <= 128) {  // N = 256, 512, 768, 1024: half a wave per row
+        const dim3 hgrid((unsigned)((rows + 2 * kRowsPerBlock - 1) / (2 * kRowsPerBlock))), hblock(64 * kRowsPerBlock);
+#define BF_LNH_LAUNCH(V)                                                                                          \
+    hipLaunchKernelGGL((add_layernorm_half_kernel<T, GT, V>), hgrid, hblock, 0, stream, (const T*)x, (const T*)res, \
+                       (const GT*)gamma, (const GT*)beta, (T*)out, rows, N, eps)
+        switch (nvec / 32) {
+            case 1: BF_LNH_LAUNCH(1); break;
+            case 2: BF_LNH_LAUNCH(2); break;
+            case 3: BF_LNH_LAUNCH(3); break;
+            default: BF_LNH_LAUNCH(4); break;
+        }
+#undef BF_LNH_LAUNCH
+        BF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     const dim3 grid((unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock)), block(64 * kRowsPerBlock);
 #define BF_LN_LAUNCH(VPL)                                                                                        \
     hipLaunchKernelGGL((add_layernorm_kernel<T, GT, VPL>), grid, block, 0, stream, (const T*)x, (const T*)res,    \
