@@ -57,6 +57,7 @@ SYMBOLS = {
     "bf_gemm_nt_act": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "bf_gemm_nt_act_pre": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "bf_gemm_nt_layers": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "bf_gemm_nn_layers": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "bf_gemm_nn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "bf_gemm_tn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "bf_gemm_schedule": (_sz, [_i, _i, _i, _i, _i, _vp, _sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),

@@ -421,6 +421,15 @@ int bf_gemm_nn(const void* d_x, const void* d_w, void* d_y, int dtype, int S, in
     return bf_launch_gemm256_nn(d_x, d_w, d_y, dtype, S, M, N, K, (hipStream_t)stream);
 }
 
+int bf_gemm_nn_layers(const void* d_x, const void* d_w, void* d_y, int dtype, int L, int S, int M, int N, int K,
+                      void* stream) {
+    if (!d_x || !d_w || !d_y) BF_FAIL("bf_gemm_nn_layers: null pointer");
+    if (L < 1 || L > 4) BF_FAIL("bf_gemm_nn_layers: L must be 1..4 (got %d)", L);
+    if (!bf_gemm256_nn_supported(dtype, S, M, N, K, d_x, d_w, d_y) || (long long)L * S * M * N >= (1ll << 40))
+        BF_FAIL("bf_gemm_nn_layers: needs a 16-bit dtype, N %% 64 == 0, K %% 8 == 0, M * K >= 16384 and 16-byte aligned pointers");
+    return bf_launch_gemm256_nn(d_x, d_w, d_y, dtype, S, M, N, K, (hipStream_t)stream, L);
+}
+
 // workspace layout of bf_linear_bwd
 struct BwdLayout {
     size_t w, wt, dyt, xt, dw, db, dbp, dpre, lp, part, total;

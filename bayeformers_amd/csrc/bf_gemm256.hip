@@ -251,7 +251,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
 
-template <typename T, typename YT, bool TRX = false, bool TRW = false>
+template <typename T, typename YT, bool TRX = false, bool TRW = false, bool SEG = false>
 __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams p) {
     using frag = typename Mfma16<T>::frag;
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
@@ -305,8 +305,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
     // (inside a tile's k-loop h is the compile-time height, so a full-height tile issues its pieces without branches)
     auto stage = [&](const Src& t, int kt, int buf, auto h) {
         char* base = smem + buf * STAGE_BYTES;
-        const T* xk = t.xb + (TRX ? (long long)kt * TK * M : (long long)kt * TK);
-        const T* wk = t.wb + (TRW ? (long long)kt * TK * N : (long long)kt * TK);
+        const T* xk = t.xb;
+        const T* wk = t.wb;
+        if constexpr (SEG) {
+            // segmented contraction (NN form): k-step kt lies in segment kt / (K / TK), all wave-uniform arithmetic
+            const int nks = K / TK;
+            const int seg = (kt >= nks ? 1 : 0) + (kt >= 2 * nks ? 1 : 0) + (kt >= 3 * nks ? 1 : 0);
+            kt -= seg * nks;
+            xk += (long long)seg * p.x_seg_stride;
+            wk += (long long)seg * p.w_seg_stride;
+        }
+        xk += TRX ? (long long)kt * TK * M : (long long)kt * TK;
+        wk += TRW ? (long long)kt * TK * N : (long long)kt * TK;
         if constexpr (TRX) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) glds16(xk + (long long)i * 16 * M + t.xo[0], base + (i * 8 + wid) * 1024);
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
         return __builtin_bit_cast(frag, v);
     };
 
-    const int nk = K / TK;
+    const int nk = SEG ? p.segs * (K / TK) : K / TK;
     const int4* __restrict__ sched = p.sched + blockIdx.x;
     const unsigned G = gridDim.x;
     int4 d = sched[0];
@@ -716,7 +726,8 @@ int launch256_tn(const GemmParams& p, hipStream_t stream, int grid) {
 
 template <typename T>
 int launch256_nn(const GemmParams& p, hipStream_t stream, int grid) {
-    hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, true>), dim3(grid), dim3(512), 0, stream, p);
+    if (p.segs > 1) hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, true, true>), dim3(grid), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, true>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -839,7 +850,8 @@ bool bf_gemm256_nn_supported(int dtype, int S, int M, int Nl, int Kl, const void
 }
 
 int bf_launch_gemm256_nn(const void* d_x, const void* d_w, void* d_y, int dtype, int S, int M, int Nl, int Kl,
-                         hipStream_t stream) {
+                         hipStream_t stream, int segs) {
+    if (segs < 1 || segs > 4) BF_FAIL("bf_gemm_nn: 1 to 4 layers (got %d)", segs);
     GemmParams p{};
     p.x = d_x;
     p.w = d_w;
@@ -851,6 +863,9 @@ int bf_launch_gemm256_nn(const void* d_x, const void* d_w, void* d_y, int dtype,
     p.M = M;
     p.N = Kl;
     p.K = Nl;
+    p.segs = segs;
+    p.x_seg_stride = (long long)S * M * Nl;
+    p.w_seg_stride = (long long)S * Nl * Kl;
     p.act = BF_ACT_NONE;
     p.layers = 1;
     p.flags = 0;

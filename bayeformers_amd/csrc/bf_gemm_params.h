@@ -18,6 +18,10 @@ struct GemmParams {
     // j = 0 .. sched_rounds - 1, until an entry with height 0
     const int4* sched;
     int sched_rounds;
+    // NN form only: the contraction runs over `segs` segments of K each (x: [segs][S][M][K], w: [segs][S][K][N]) — the
+    // input gradient of `segs` layers that read the same activations, dx = sum_l dy_l W_l, in one launch
+    int segs;
+    long long x_seg_stride, w_seg_stride;
     int flags;  // developer ablation bits, honoured by -DBF_DEV builds only (tools/): 1 = no DMA in the k-loop,
                 // 8 = no epilogue, 16 = no row mask, 64 = every k-step's DMA re-reads k-step 0 (operands L2-hot)
 };
@@ -34,7 +38,7 @@ int bf_launch_gemm256_tn(const void* d_a, const void* d_b, float* d_out, int dty
 // NN form (x K-contiguous, w contraction-major, 16-bit out): y[s][m][k] = sum_n x[s][m][n] * w[s][n][k]
 bool bf_gemm256_nn_supported(int dtype, int S, int M, int Nl, int Kl, const void* d_x, const void* d_w, const void* d_y);
 int bf_launch_gemm256_nn(const void* d_x, const void* d_w, void* d_y, int dtype, int S, int M, int Nl, int Kl,
-                         hipStream_t stream);
+                         hipStream_t stream, int segs = 1);
 #ifdef BF_DEV
 // round-1 kernel (fixed 256x256 tiles, arithmetic tile order), kept in developer builds as the A/B baseline
 int bf_launch_gemm256_r1(const GemmParams& p, int w_dtype, int y_dtype, hipStream_t stream);

@@ -180,6 +180,20 @@ def gemm_nn(x: Tensor, w: Tensor) -> Tensor:
     return y
 
 
+def gemm_nn_layers(x: Tensor, w: Tensor) -> Tensor:
+    """y[s] = sum_l x[l][s] w[l][s] (bf_gemm_nn_layers): the one input gradient of L layers that read the same
+    activations.  x: [L, S, M, N], w: [L, S, N, K], 16-bit; returns [S, M, K]."""
+    _require_device(x, "x")
+    L, S, M, N = x.shape
+    K = w.shape[3]
+    if w.shape[:3] != (L, S, N) or x.dtype != w.dtype or not (x.is_contiguous() and w.is_contiguous()):
+        raise _C.BayeFormersAMDError("gemm_nn_layers: x [L,S,M,N] and w [L,S,N,K] must be contiguous, same dtype")
+    y = torch.empty((S, M, K), dtype=x.dtype, device=x.device)
+    _C.check(_C.lib().bf_gemm_nn_layers(x.data_ptr(), w.data_ptr(), y.data_ptr(), _TORCH2BF[x.dtype], L, S, M, N, K,
+                                        _stream_ptr()), "bf_gemm_nn_layers")
+    return y
+
+
 class LinearPlan:
     """Cached ctypes descriptors of one bnn.Linear (pointers are refreshed per call; structs are reused)."""
 

@@ -155,6 +155,11 @@ int bf_gemm_tn(const void* d_a, const void* d_bm, float* d_out, int dtype, int b
  * transposed copy of the sampled weights is made.  Needs N % 64 == 0, K % 8 == 0, M * K >= 128 * 128 and 16-byte
  * aligned pointers (fails with a message otherwise: bf_linear_bwd transposes W_s for such shapes). */
 int bf_gemm_nn(const void* d_x, const void* d_w, void* d_y, int dtype, int S, int M, int N, int K, void* stream);
+/* The same for L (1..4) layers that read the SAME activations (query / key / value): their input gradients add up,
+ *   y[s][m][k] = sum_l sum_n x[l][s][m][n] * w[l][s][n][k]      (x [L][S][M][N], w [L][S][N][K] as bf_gemm_nt_layers lays them out),
+ * as ONE contraction of length L*N: one launch and one output instead of L launches and L - 1 additions. */
+int bf_gemm_nn_layers(const void* d_x, const void* d_w, void* d_y, int dtype, int L, int S, int M, int N, int K,
+                      void* stream);
 
 /* The host-built tile schedule the 256-wide persistent GEMM kernel runs for a problem of S samples x L layers x
  * [M, N] outputs on n_cu compute units (introspection: the library builds and caches the same table on the first

@@ -205,6 +205,19 @@ def test_gemm_nn_against_torch(S, M, N, K, dt):
     assert (y.double() - ref).abs().max().item() <= tol * ref.abs().max().item() + 1e-5 * np.sqrt(N)
 
 
+@pytest.mark.parametrize("L,S,M,N,K", [(3, 2, 300, 128, 200), (2, 1, 513, 64, 264), (3, 10, 4096, 768, 768), (4, 2, 1000, 192, 72)])
+def test_gemm_nn_layers_against_torch(L, S, M, N, K):
+    """bf_gemm_nn_layers: the contraction over L stacked layers (dx = sum_l dy_l W_l) against an fp64 einsum."""
+    g = torch.Generator(device="cuda").manual_seed(L * 7919 + M * 31 + N * 7 + K)
+    x = torch.randn(L, S, M, N, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(L, S, N, K, device="cuda", generator=g) * 0.1).bfloat16()
+    y = ops.gemm_nn_layers(x, w)
+    ref = torch.einsum("lsmn,lsnk->smk", x.double(), w.double())
+    assert (y.double() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item() + 1e-5 * np.sqrt(L * N)
+    one = ops.gemm_nn_layers(x[:1].contiguous(), w[:1].contiguous())
+    assert torch.equal(one, ops.gemm_nn(x[0], w[0]))
+
+
 def test_gemm_nn_detects_transposes():
     S, M, N, K = 1, 128, 64, 256
     x = torch.zeros(S, M, N, device="cuda")
