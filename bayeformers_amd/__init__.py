@@ -195,8 +195,8 @@ def fuse_shared_inputs(model: torch.nn.Module, names=("query", "key", "value")) 
     (bf_gemm_nt_layers): marks modules that hold `names` as bnn.Linear children of one shape (HF BertSelfAttention
     and its relatives, which call them on the same hidden states).  The sampling plan then lays their sampled
     weights out back to back, and whichever of the layers runs first computes all outputs; a layer that is handed a
-    different input simply runs on its own.  Inference-time optimisation: with gradients enabled every layer runs
-    separately.  Returns the number of fused blocks."""
+    different input simply runs on its own.  With gradients enabled the launch sits in one autograd node whose backward
+    computes ONE input gradient for the three layers (bf_gemm_nn_layers).  Returns the number of fused blocks."""
     fused = 0
     for m in model.modules():
         group = tuple(getattr(m, n, None) for n in names)

@@ -90,6 +90,61 @@ class _PlannedLinearFn(torch.autograd.Function):
         return dx, dmu_w, drho_w, dmu_b, drho_b, None, None, None, None, None, None, None, None
 
 
+class _StackedLinearFn(torch.autograd.Function):
+    """Layers that read the same activations (query / key / value) under autograd: forward = ONE bf_gemm_nt_layers launch
+    over their stacked sampled weights, backward = the parameter gradients of every layer (bf_linear_bwd without dx)
+    and ONE input gradient dx = sum_l dy_l W_l as a single contraction over the stacked layers (bf_gemm_nn_layers) —
+    autograd would otherwise run L input-gradient GEMMs and add their results."""
+
+    @staticmethod
+    def forward(ctx, x, w_stack, b_stack, run, S, seed, base, *params):
+        L = len(run)
+        N, K = run[0].out_features, run[0].in_features
+        M = x.shape[0] // S
+        ctx.run, ctx.S, ctx.seed, ctx.base, ctx.cdt = run, S, seed, base, w_stack.dtype
+        fwd = bfr.STATE.ctx
+        ctx.kept = (fwd.plan, fwd.plan.group_of[id(run[0])], fwd.token, w_stack)
+        ctx.counter = bfr.counter_snapshot()
+        ctx.save_for_backward(x)
+        y = ops.gemm_nt_layers(x, w_stack, b_stack, L, S, M, N, K, M * K, x.dtype)
+        return tuple(y[l].view(S * M, N) for l in range(L))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (x,) = ctx.saved_tensors
+        run, S, seed, base, cdt = ctx.run, ctx.S, ctx.seed, ctx.base, ctx.cdt
+        L, N = len(run), run[0].out_features
+        M = x.shape[0] // S
+        grads = [g if g is not None else torch.zeros((S * M, N), dtype=cdt, device=x.device) for g in grads]
+        grads = [(g if g.dtype == cdt else g.to(cdt)) for g in grads]
+        grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
+        plan, gi, token, w_stack = ctx.kept
+        arena_alive = plan.arena_owner[gi % len(plan.arenas)] == (gi, token)  # no later forward overwrote the samples
+        need = ctx.needs_input_grad
+        out = [None] * (7 + 4 * L)
+        with bfr.counter_override(ctx.counter):
+            dx = None
+            if need[0] and arena_alive:
+                # the L output gradients as one [L, S, M, N] tensor: in place when they are consecutive slabs of one
+                # buffer (what ops.attention_backward returns), stacked otherwise
+                g0 = grads[0]
+                slabs = all(g.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr()
+                            and g.storage_offset() == g0.storage_offset() + l * S * M * N for l, g in enumerate(grads))
+                dy = torch.as_strided(g0, (L, S, M, N), (S * M * N, M * N, N, 1)) if slabs else torch.stack(grads).view(L, S, M, N)
+                dx = ops.gemm_nn_layers(dy, w_stack).view(S * M, -1)
+            for l, layer in enumerate(run):
+                o = 7 + 4 * l
+                lone = need[0] and not arena_alive  # samples gone: this layer's own dx from regenerated weights
+                r = ops.linear_backward(layer, x, grads[l], S, seed, base, cdt, lone, need[o], need[o + 2])
+                if lone:
+                    dx = r[0] if dx is None else dx + r[0]
+                out[o], out[o + 1], out[o + 2], out[o + 3] = r[1], r[2], r[3], r[4]
+        if dx is not None and dx.dtype != x.dtype:
+            dx = dx.to(x.dtype)
+        out[0] = dx
+        return tuple(out)
+
+
 class Linear(KernelLayer):
     """Bayesian Linear layer with Gaussian weight/bias posteriors and a prior per parameter.
 
@@ -150,8 +205,8 @@ class Linear(KernelLayer):
             self._small_m = small  # the model rebuilds its sampling plan without / with this layer next forward
         if ctx is not None and ctx.plan is not None and not small and id(self) in ctx.plan.group_of:
             w_s, b_s = ctx.plan.ensure(self, ctx.token, bfr.STATE.seed, base, ctx.lp_buf)
-            if self._shared_input is not None and not need_grad and not want_act:
-                y = self._stacked_forward(ctx, x2, S)
+            if self._shared_input is not None and not want_act:
+                y = self._stacked_forward(ctx, x2, S, base, need_grad)
                 if y is not None:
                     self._lp_view, self._lp_dirty = slot, True
                     return y.view(*input.shape[:-1], self.out_features)
@@ -171,22 +226,32 @@ class Linear(KernelLayer):
         self._end(ctx, slot)
         return y.view(*input.shape[:-1], self.out_features)
 
-    def _stacked_forward(self, ctx, x2: Tensor, S: int) -> Optional[Tensor]:
+    def _stacked_forward(self, ctx, x2: Tensor, S: int, base: int = 0, need_grad: bool = False) -> Optional[Tensor]:
         """Layers that read the same activations (query / key / value): whichever of them runs first multiplies x by
         the stacked sampled weights of all of them in ONE launch (bf_gemm_nt_layers); the others pick their slab up.
+        With gradients the launch sits in _StackedLinearFn, whose backward computes ONE input gradient for the run.
         Returns None when the run is not stacked in this plan or the input is not the one the outputs came from."""
         run = self._shared_input
         entry = ctx.plan.stacked.get(id(run[0]))
         if entry is None or entry[0] != run or ctx.plan.group_of[id(run[0])] != ctx.plan.group_of[id(self)]:
             return None
-        ident = (x2.data_ptr(), tuple(x2.shape), x2.dtype, x2._version)
+        ident = (x2.data_ptr(), tuple(x2.shape), x2.dtype, x2._version, need_grad)
         cached = ctx.shared_out.get(id(run[0]))
         if cached is None or cached[0] != ident:
             if x2.dtype != entry[1].dtype or not x2.is_contiguous():
                 return None
             M = x2.shape[0] // S
-            y = ops.gemm_nt_layers(x2, entry[1], entry[2], len(run), S, M, self.out_features, self.in_features,
-                                   M * self.in_features, x2.dtype)
+            if need_grad:
+                # what bf_gemm_nn_layers takes; other shapes keep the per-layer autograd path
+                if (x2.dtype == torch.float32 or self.out_features % 64 or self.in_features % 8
+                        or M * self.in_features < 128 * 128 or len(run) > 4
+                        or any(isinstance(l.bias, NoneParameter) for l in run)):
+                    return None
+                params = [t for l in run for t in (l.weight.mu, l.weight.rho, l.bias.mu, l.bias.rho)]
+                y = _StackedLinearFn.apply(x2, entry[1], entry[2], run, S, bfr.STATE.seed, base, *params)
+            else:
+                y = ops.gemm_nt_layers(x2, entry[1], entry[2], len(run), S, M, self.out_features, self.in_features,
+                                       M * self.in_features, x2.dtype)
             # the input tensor is kept with the outputs: its storage cannot be recycled (same address, shape and
             # version) for another activation while the entry is alive, e.g. when a block runs twice in one forward
             cached = (ident, y, x2)

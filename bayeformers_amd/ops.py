@@ -482,7 +482,9 @@ def attention_backward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tenso
     """Gradients of attention_forward (bf_attention_bwd).  Returns (dq, dk, dv), each [B, T, H, 64] contiguous."""
     B, H, T, D = q.shape
     go = grad_out if (grad_out.dtype == q.dtype and grad_out.is_contiguous()) else grad_out.to(q.dtype).contiguous()
-    dq, dk, dv = (torch.empty((B, T, H, D), dtype=q.dtype, device=q.device) for _ in range(3))
+    # one buffer, three slabs: the gradients of a stacked query / key / value launch arrive as one [3, ...] tensor
+    dqkv = torch.empty((3, B, T, H, D), dtype=q.dtype, device=q.device)
+    dq, dk, dv = dqkv[0], dqkv[1], dqkv[2]
     delta = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
     _C.check(_C.lib().bf_attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                        key_mask.data_ptr() if key_mask is not None else None,

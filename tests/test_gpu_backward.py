@@ -332,3 +332,48 @@ def test_inference_forward_does_not_store_the_pre_activation(monkeypatch):
     with torch.no_grad(), model.monte_carlo(2):
         y = model(x)
     assert y.shape == (512, 256)
+
+
+def test_stacked_qkv_training_matches_per_layer_autograd(monkeypatch):
+    """Three layers that read the same activations (fuse_shared_inputs) under autograd: one stacked forward launch and ONE
+    input gradient (bf_gemm_nn_layers) against the same model run layer by layer."""
+    import copy
+
+    from bayeformers_amd import ops
+
+    calls = []
+    real = ops.gemm_nn_layers
+    monkeypatch.setattr(ops, "gemm_nn_layers", lambda *a: (calls.append(1), real(*a))[1])
+
+    class QKV(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.query, self.key, self.value = (torch.nn.Linear(128, 192) for _ in range(3))
+
+        def forward(self, x):
+            q, k, v = self.query(x), self.key(x), self.value(x)
+            return q * 0.5 + k * k.detach().sign() * 0.25 + v * 1.5
+
+    torch.manual_seed(3)
+    net = QKV()
+    S, B = 2, 384
+    x = torch.randn(B, 128)
+    results = []
+    for stacked in (False, True):
+        bmodel = bf.to_bayesian(copy.deepcopy(net), delta=0.05, freeze=True).cuda().to(torch.bfloat16)
+        if stacked:
+            assert bf.fuse_shared_inputs(bmodel) == 1
+        xd = x.cuda().bfloat16().repeat(S, 1).requires_grad_(True)
+        bf.manual_seed(SEED, next_sample=5)
+        with bmodel.monte_carlo(S):
+            y = bmodel(xd)
+        (y.float() ** 2).sum().backward()
+        grads = {n: p.grad.detach().float().cpu() for n, p in bmodel.named_parameters() if p.grad is not None}
+        results.append((y.detach().float().cpu(), xd.grad.float().cpu(), grads))
+    (y0, dx0, g0), (y1, dx1, g1) = results
+    assert len(calls) == 1                           # the stacked model took the one-input-gradient path, once
+    assert torch.equal(y0, y1)                       # same kernels' outputs, launch grouping aside
+    assert (dx0 - dx1).abs().max().item() <= 2.0 ** -7 * dx0.abs().max().item()   # one fp32 sum instead of three bf16 ones
+    assert g0.keys() == g1.keys() and len(g0) >= 6
+    for n in g0:
+        assert torch.allclose(g0[n], g1[n], rtol=1e-5, atol=1e-6 * g0[n].abs().max().item()), n
