@@ -162,6 +162,30 @@ def _embeddings_forward(self, input_ids=None, token_type_ids=None, position_ids=
                                            and position_ids.shape[1] == input_ids.shape[1]
                                            and position_ids.shape[0] in (1, input_ids.shape[0]))))
     if not plain:
+        # training: the module's own forward — but on ONE copy of the batch when the ids are sample_bayesian's S-fold
+        # repeat of it (the block is deterministic without dropout, every copy gets the same rows): the table gradients
+        # are then scattered from B*T rows instead of S*B*T, after one sum over the copies
+        rep = getattr(input_ids, "_bf_repeat", None) if input_ids is not None else None
+        if rep is not None and inputs_embeds is None and not (self.training and self.dropout.p > 0):
+            S, orig = rep
+            B = orig.shape[0]
+
+            def one_copy(t):  # a per-row companion of the ids: None, its own original, or rows that cannot differ
+                if t is None or t.shape[0] == 1:
+                    return t, True
+                r = getattr(t, "_bf_repeat", None)
+                if r is not None and r[0] == S and r[1].shape[0] == B:
+                    return r[1], True
+                if t.shape[0] == S * B and t.stride(0) == 0:
+                    return t[:B], True
+                return None, False
+
+            tt, ok1 = one_copy(token_type_ids)
+            pp, ok2 = one_copy(position_ids)
+            if ok1 and ok2 and orig.dim() == 2 and orig.shape[0] * S == input_ids.shape[0]:
+                e = self._bf_plain_forward(input_ids=orig, token_type_ids=tt, position_ids=pp, inputs_embeds=None,
+                                           past_key_values_length=past_key_values_length)
+                return e.repeat(S, *([1] * (e.dim() - 1)))
         return self._bf_plain_forward(input_ids=input_ids, token_type_ids=token_type_ids, position_ids=position_ids,
                                       inputs_embeds=inputs_embeds, past_key_values_length=past_key_values_length)
     if position_ids is None and past_key_values_length:

@@ -34,6 +34,7 @@ def _repeat_cached(v: Tensor, samples: int) -> Tensor:
     if hit is not None and hit[0] is v and hit[1] == v._version and hit[2] == samples and hit[3] == v.data_ptr():
         return hit[4]
     out = v.repeat(samples, *([1] * (v.dim() - 1)))
+    out._bf_repeat = (samples, v)  # what it is made of: consumers that are the same for every copy use the original
     if out.numel() * out.element_size() > (64 << 20):
         return out  # large inputs are not worth pinning
     if len(_REPEAT_CACHE) >= _REPEAT_CACHE_SIZE:
@@ -48,7 +49,8 @@ def repeat_inputs(inputs: Union[Tensor, Dict[str, Any], Sequence[Any]], samples:
         if isinstance(v, Tensor) and v.dim() > 0:
             if samples == 1:
                 return v
-            if not v.requires_grad and not torch.is_grad_enabled():
+            # (integer / bool inputs carry no gradient: cached in training steps too)
+            if not v.requires_grad and (not torch.is_grad_enabled() or not v.is_floating_point()):
                 return _repeat_cached(v, samples)
             return v.repeat(samples, *([1] * (v.dim() - 1)))
         return v

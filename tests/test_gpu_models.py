@@ -206,6 +206,35 @@ def test_fused_embeddings_match_the_module(dtype, tol):
         assert torch.equal(emb(inputs_embeds=e), emb._bf_plain_forward(inputs_embeds=e))
 
 
+def test_training_embeddings_run_on_one_copy_of_the_batch():
+    """With gradients the rewritten embedding block runs the module's own forward on ONE copy of sample_bayesian's S-fold
+    repeated ids and repeats the result: same outputs, same table / LayerNorm gradients as on the repeated batch."""
+    cfg, model = _bert(True)
+    res = []
+    for fuse in (False, True):
+        bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().cuda()
+        if fuse:
+            assert bf.fuse_embeddings(bmodel) == 1
+        for p in bmodel.parameters():
+            p.grad = None
+        torch.manual_seed(3)
+        ids = torch.randint(0, cfg.vocab_size, (4, 16)).cuda()
+        tt = torch.randint(0, cfg.type_vocab_size, (4, 16)).cuda()
+        bf.manual_seed(SEED)
+        raw, mean, lp, lq = sample_bayesian(bmodel, {"input_ids": ids, "token_type_ids": tt}, 3)
+        raw[0].float().pow(2).sum().backward()
+        emb = (bmodel.model if hasattr(bmodel, "model") else bmodel).bert.embeddings
+        res.append((raw[0].detach().float().cpu(),
+                    [g.grad.detach().float().cpu() for g in (emb.word_embeddings.weight, emb.token_type_embeddings.weight,
+                                                              emb.position_embeddings.weight, emb.LayerNorm.weight)]))
+        if fuse:  # the path was taken: the ids the block saw were the 4-row original
+            rep = sample_bayesian.__globals__["repeat_inputs"]({"input_ids": ids}, 3)["input_ids"]
+            assert getattr(rep, "_bf_repeat", (0, None))[0] == 3
+    assert (res[0][0] - res[1][0]).abs().max().item() <= 1e-5 * res[0][0].abs().max().item()
+    for a, b in zip(res[0][1], res[1][1]):
+        assert (a - b).abs().max().item() <= 1e-4 * a.abs().max().item() + 1e-7
+
+
 def test_fused_gelu_matches_unfused_bert():
     """fuse_activations(): dense + exact GELU in the GEMM epilogue gives the same logits as the separate GELU op."""
     cfg, model = _bert(True)
