@@ -130,7 +130,7 @@ __device__ __forceinline__ f32x4_t act_chunk(f32x4_t c, int act) {
 // no barrier at all: wave group 0 starts it a slot before group 1, and every wave runs it at its own pace.
 // `scratch` = this wave's 8 KiB of the stage buffer the k-loop consumed last (every fragment read of it is complete
 // when a wave gets here, see the kernel).
-template <typename YT, int H>
+template <typename YT, int H, int SLICES = 2>
 __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc)[4][H], YT* y, YT* y2, int m0,
                                               int m_end, int n0, int N, int wm, int wn, int lane, int act) {
     constexpr int ROWB = 64 * (int)sizeof(YT);   // 128 or 256
@@ -155,7 +155,7 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
     const int n = n0 + wn * 64 + rc * EPC;
     const bool n_ok = n < N, n_full = vec_ok && n + EPC <= N;
     auto write_block = [&](int mb) {
-        char* R = scratch + (mb & 1) * BLK;
+        char* R = scratch + (SLICES == 2 ? (mb & 1) * BLK : 0);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             const f32x4_t v = y2 ? acc[nb][mb] : bf_apply_act<sizeof(YT) == 2>(acc[nb][mb], act);
@@ -174,7 +174,7 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int mb = 0; mb < H; ++mb) {
-        const char* R = scratch + (mb & 1) * BLK;
+        const char* R = scratch + (SLICES == 2 ? (mb & 1) * BLK : 0);
         f32x4_t rows[NI];
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
@@ -182,8 +182,12 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
             const int rsw = sizeof(YT) == 2 ? (r >> 1) & 7 : r;
             rows[it] = *reinterpret_cast<const f32x4_t*>(R + r * ROWB + ((rc ^ rsw) << 4));
         }
-        if (mb + 1 < H) write_block(mb + 1);
+        if (SLICES == 2 && mb + 1 < H) write_block(mb + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (SLICES == 1 && mb + 1 < H) {  // one slice: the next block goes in once this one's rows are in registers
+            write_block(mb + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             const int m = m0 + (2 * mb + wm) * 16 + it * RPI + rr;
@@ -251,10 +255,20 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
 
-template <typename T, typename YT, bool TRX = false, bool TRW = false, bool SEG = false>
+//
+// RING (TN form only, >= 2 k-steps): the DMA of a k-step is not issued in one burst of 8 pieces per wave at L0 but as
+// four UNITS of [32 contraction rows][256] (16 KiB: X0, W0 = the halves read in L0, X1, W1 = the halves read in L1),
+// one unit per wave group per L slot, each into the half-buffer whose last read is one barrier behind:
+//      G0:  L0(t): X1(t+1)    L1(t): X0(t+2)          G1:  L0(t): W1(t+1)    L1(t): W0(t+2)
+// so a wave has at most 12 pieces in flight and never more than 4 are issued into one slot; the waits are counted
+// (vmcnt(8) = "everything but the two youngest units"): G0 at the end of its M slots, G1 at the end of its L slots.
+// The units of the next tile's first two k-steps are issued by the last two k-steps of a tile; the epilogue scratch
+// is a separate 32 KiB region, so nothing of the next tile has to wait for the epilogue.
+template <typename T, typename YT, bool TRX = false, bool TRW = false, bool SEG = false, bool RING = false>
 __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams p) {
     using frag = typename Mfma16<T>::frag;
-    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES];
+    static_assert(!RING || (TRX && TRW && !SEG), "the unit ring is the TN form's");
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES + (RING ? 32768 : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -284,6 +298,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
         // columns past the edge are clamped (they only feed output rows / columns that are masked on store).  The key
         // does not depend on i, so one offset per operand serves all four pieces (piece i = + 16 i rows, added to the
         // wave-uniform base)
+        if constexpr (RING) {
+            // a unit = 16 pieces of 2 rows; wave wn of the group fetches pieces i * 4 + wn = rows i * 8 + rb (+ lane >> 5
+            // inside rb).  key(row) = (rb & 3) | (i & 1) << 2: two lane offsets serve the four pieces.  Group 0 only ever
+            // fetches x units, group 1 w units: each wave keeps its own operand's offsets in xo[0..1].
+            const int rb = wn * 2 + (lane >> 5);
+            const int ld = wm == 0 ? M : N, c0 = wm == 0 ? m0 : n0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int c = (lane & 31) ^ (((rb & 3) | (e << 2)) << 1);
+                t.xo[e] = (unsigned)rb * (unsigned)ld + (unsigned)min(c0 + c * 8, ld - 8);
+            }
+            return;
+        }
         const int tr_r = wid * 2 + (lane >> 5);
         const int tr_c = (lane & 31) ^ (((tr_r & 3) | ((tr_r >> 1) & 4)) << 1);
         if constexpr (TRX) {
@@ -334,6 +361,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
         }
     };
 
+    // RING: this wave's four pieces of its group's unit `half` (0 / 1) of k-step kt of tile t, into buffer buf
+    auto issue_unit = [&](const Src& t, int kt, int buf, int half) {
+        const T* b = wm == 0 ? t.xb : t.wb;
+        const long long ld = wm == 0 ? M : N;
+        char* dst = smem + buf * STAGE_BYTES + (wm == 0 ? 0 : X_BYTES) + half * 16384 + wn * 1024;
+        const T* rowp = b + (long long)(kt * TK + half * 32) * ld;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(rowp + (long long)(i * 8) * ld + t.xo[i & 1], dst + i * 4096);
+    };
+    auto wait_units = [&](int younger) {  // wave-uniform: all but the `younger` most recent units have landed
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
     const int fsw = (lane >> 1) & 7;
     const int foff0 = (lane & 15) * ROW_BYTES + ((((lane >> 4)) ^ fsw) << 4);
     const int foff1 = (lane & 15) * ROW_BYTES + (((4 + (lane >> 4)) ^ fsw) << 4);
@@ -372,8 +414,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
     int s, m0, n0, h;
     tile_setup(d, cur, s, m0, n0, h);
     int g = 0;  // running k-step counter: step g lives in LDS buffer g & 1
-    stage(cur, 0, 0, h);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (RING) {
+        issue_unit(cur, 0, 0, 0);
+        issue_unit(cur, 0, 0, 1);
+        issue_unit(cur, 1, 1, 0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        stage(cur, 0, 0, h);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
 
     int round = 0;
@@ -444,9 +493,70 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
                 ++g;
             };
 
+            // the RING k-step: same slots and barriers; one unit issued per L slot, counted waits
+            // `steady`: k-steps kt and kt + 1 both have a successor in this tile — no conditions in the loop body
+            auto kstep_ring = [&](int kt, const Src& nxt, auto last, auto steady) {
+                constexpr bool ST = decltype(steady)::value;
+                const bool e1 = ST || kt + 1 < nk || has_next, e2 = ST || kt + 2 < nk || has_next;
+                const unsigned sboff = (g & 1) * STAGE_BYTES;
+                if (e1) {
+                    if (ST || kt + 1 < nk) issue_unit(cur, kt + 1, (g & 1) ^ 1, 1);
+                    else issue_unit(nxt, 0, (g & 1) ^ 1, 1);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[i] = tr_read(tr_w0 + sboff, i, std::integral_constant<int, 0>{});
+#pragma unroll
+                for (int j = 0; j < H; ++j) xf[j] = tr_read(tr_x0 + sboff, 2 * j, std::integral_constant<int, 0>{});
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (wm == 1) wait_units(e1 ? 2 : 0);  // W1(kt)
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < H; ++j) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                if (wm == 0) wait_units(e1 ? 2 : 0);  // X1(kt)
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                if (e2) {
+                    if (ST || kt + 2 < nk) issue_unit(cur, kt + 2, g & 1, 0);
+                    else issue_unit(nxt, kt + 2 - nk, g & 1, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[i] = tr_read(tr_w0 + sboff, i, std::integral_constant<int, 1>{});
+#pragma unroll
+                for (int j = 0; j < H; ++j) xf[j] = tr_read(tr_x0 + sboff, 2 * j, std::integral_constant<int, 1>{});
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (wm == 1) wait_units(e1 ? (e2 ? 2 : 1) : 0);  // W0(kt + 1)
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < H; ++j) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                if (wm == 0) wait_units(e1 ? (e2 ? 2 : 1) : 0);  // X0(kt + 1)
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(decltype(last)::value && wm == 1)) __builtin_amdgcn_s_barrier();
+                ++g;
+            };
+
             if (wm == 1) __builtin_amdgcn_s_barrier();  // G1 runs one slot behind G0
             init_acc<H>(acc, p.bias ? p.bias + (long long)s * N : nullptr, n0, N, wn, lane);
 
+            if constexpr (RING) {
+                for (int kt = 0; kt + 2 < nk; ++kt) kstep_ring(kt, cur, std::false_type{}, std::true_type{});
+                Src nxt = cur;
+                if (has_next) {
+                    int s2, m2, n2, h2;
+                    tile_setup(dn, nxt, s2, m2, n2, h2);
+                }
+                kstep_ring(nk - 2, nxt, std::false_type{}, std::false_type{});
+                kstep_ring(nk - 1, nxt, std::true_type{}, std::false_type{});
+            } else {
             for (int kt = 0; kt + 1 < nk; ++kt)
                 kstep([&] {
 #ifdef BF_DEV
@@ -468,6 +578,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
                     stage(nxt, 0, (g & 1) ^ 1, h2);
                 }
             }, std::true_type{}, round > 0 && nk == 1);
+            }
             // the last consumed buffer is (g-1)&1; buffer g&1 already holds k-step 0 of the next tile.  Group 0 is one
             // slot ahead here and stays ahead through its epilogue
             YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
@@ -481,9 +592,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
             YT* y2 = p.y2 ? reinterpret_cast<YT*>(p.y2) + (long long)s * M * N : nullptr;
             // every fragment read of buffer (g - 1) & 1 is complete: group 0 passed its last barrier together with the
             // end of group 1's last LDS slot, group 1 comes from its last MFMA slot
-            if (!skip)
-                epilogue_wave<YT, H>(smem + ((g - 1) & 1) * STAGE_BYTES + wid * 8192, acc, y, y2, m0, m_end, n0, N, wm, wn,
-                                     lane, p.act);
+            if (!skip) {
+                if constexpr (RING)
+                    epilogue_wave<YT, H, 1>(smem + 2 * STAGE_BYTES + wid * 4096, acc, y, y2, m0, m_end, n0, N, wm, wn, lane,
+                                            p.act);
+                else
+                    epilogue_wave<YT, H>(smem + ((g - 1) & 1) * STAGE_BYTES + wid * 8192, acc, y, y2, m0, m_end, n0, N, wm,
+                                         wn, lane, p.act);
+            }
         };
         switch (h) {
             case 8: body(std::integral_constant<int, 8>{}); break;
@@ -719,7 +835,13 @@ int get_schedule(int S, int layers, int tiles_n, int M, int policy, hipStream_t 
 
 template <typename T>
 int launch256_tn(const GemmParams& p, hipStream_t stream, int grid) {
-    hipLaunchKernelGGL((gemm256_sched_kernel<T, float, true, true>), dim3(grid), dim3(512), 0, stream, p);
+    // the unit ring needs two k-steps to wrap around (the contraction here is over the S * B * L batch rows: always)
+#ifndef BF_TN_NO_RING
+    if (p.K >= 2 * TK)
+        hipLaunchKernelGGL((gemm256_sched_kernel<T, float, true, true, false, true>), dim3(grid), dim3(512), 0, stream, p);
+    else
+#endif
+        hipLaunchKernelGGL((gemm256_sched_kernel<T, float, true, true>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
