@@ -251,12 +251,20 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
 //    0   0   NT   y = x W^T          (forward; x [M][K], W [N][K])
 //    1   1   TN   dW = dy^T x        (weight gradient; dy [m][N], x [m][K], contraction over the batch rows m)
 //    0   1   NN   dx = dy W          (input gradient; dy [M][N], W [N][K] read as it was sampled: no transposed copy)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
 
 //
-// RING (TN form only, >= 2 k-steps): the DMA of a k-step is not issued in one burst of 8 pieces per wave at L0 but as
+// RING (TN form, >= 2 k-steps): the DMA of a k-step is not issued in one burst of 8 pieces per wave at L0 but as
 // four UNITS of [32 contraction rows][256] (16 KiB: X0, W0 = the halves read in L0, X1, W1 = the halves read in L1),
 // one unit per wave group per L slot, each into the half-buffer whose last read is one barrier behind:
 //      G0:  L0(t): X1(t+1)    L1(t): X0(t+2)          G1:  L0(t): W1(t+1)    L1(t): W0(t+2)
@@ -264,10 +272,13 @@ typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
 // (vmcnt(8) = "everything but the two youngest units"): G0 at the end of its M slots, G1 at the end of its L slots.
 // The units of the next tile's first two k-steps are issued by the last two k-steps of a tile; the epilogue scratch
 // is a separate 32 KiB region, so nothing of the next tile has to wait for the epilogue.
+// Measured (dW GEMMs of the BERT-base step, one box): 940-958 -> 1067-1117 TFLOP/s.  The same ring over row-major
+// operands (units = the 32-deep halves of all rows, i.e. 64-byte row segments: code below, -DBF_RING_ROWMAJOR) is
+// 3-7 % SLOWER than the burst form at every K: half-line DMA requests cost more than the spread issue gains.
 template <typename T, typename YT, bool TRX = false, bool TRW = false, bool SEG = false, bool RING = false>
 __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams p) {
     using frag = typename Mfma16<T>::frag;
-    static_assert(!RING || (TRX && TRW && !SEG), "the unit ring is the TN form's");
+
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE_BYTES + (RING ? 32768 : 0)];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -282,6 +293,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
     struct Src {
         const T* xb;
         const T* wb;
+        const T* ob;  // RING: the base of the operand this wave's group fetches (x: group 0, w: group 1)
         unsigned xo[XPIECES], wo[4];
     };
     auto tile_setup = [&](const int4 d, Src& t, int& s, int& m0, int& n0, int& h) {
@@ -291,24 +303,42 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
         h = z >> 24;
         m0 = __builtin_amdgcn_readfirstlane(d.w);
         n0 = (z & 0xFFFFFF) * TN;
-        t.xb = reinterpret_cast<const T*>(p.x) + (long long)__builtin_amdgcn_readfirstlane(d.y) * p.x_sstride;
-        t.wb = reinterpret_cast<const T*>(p.w) + (long long)s * N * K;
+        const T* xb = reinterpret_cast<const T*>(p.x) + (long long)__builtin_amdgcn_readfirstlane(d.y) * p.x_sstride;
+        const T* wb = reinterpret_cast<const T*>(p.w) + (long long)s * N * K;
+        t.xb = xb;
+        t.wb = wb;
+        t.ob = wm == 0 ? xb : wb;
         // contraction-major operand: piece q = i * 8 + wid = contraction rows 2 q, 2 q + 1 of the k-step; lane -> (row,
         // 16-byte position); the position holds source chunk c = position ^ (key(row) << 1), key = row bits {0, 1, 3};
         // columns past the edge are clamped (they only feed output rows / columns that are masked on store).  The key
         // does not depend on i, so one offset per operand serves all four pieces (piece i = + 16 i rows, added to the
         // wave-uniform base)
         if constexpr (RING) {
-            // a unit = 16 pieces of 2 rows; wave wn of the group fetches pieces i * 4 + wn = rows i * 8 + rb (+ lane >> 5
-            // inside rb).  key(row) = (rb & 3) | (i & 1) << 2: two lane offsets serve the four pieces.  Group 0 only ever
-            // fetches x units, group 1 w units: each wave keeps its own operand's offsets in xo[0..1].
-            const int rb = wn * 2 + (lane >> 5);
-            const int ld = wm == 0 ? M : N, c0 = wm == 0 ? m0 : n0;
+            // Group 0 only ever fetches x units, group 1 w units: each wave keeps its own operand's offsets in xo[].
+            // Contraction-major operand: a unit = 16 pieces of 2 rows; wave wn of the group fetches pieces i * 4 + wn = rows
+            // i * 8 + rb (+ lane >> 5 inside rb).  key(row) = (rb & 3) | (i & 1) << 2.
+            // Row-major operand: a unit = the 32-deep half of the k-step of all 256 rows = [256][64 B]; piece q = i * 4 + wn
+            // = rows 16 q .. 16 q + 15, lane -> (row lane >> 2, 16-byte position lane & 3) holding source chunk
+            // position ^ ((row >> 2) & 3) (conflict-free ds_read_b128 of a [16 rows][4 chunks] fragment block).
+            auto offsets = [&](auto tr, int rows, int c0) {
+                if constexpr (decltype(tr)::value) {
+                    const int rb = wn * 2 + (lane >> 5);
+                    // (xo[2], xo[3] repeat xo[0], xo[1]: both operand forms then index xo[] by the piece number, which
+                    // keeps the struct in registers when the two groups of a kernel use different forms)
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int c = (lane & 31) ^ (((rb & 3) | (e << 2)) << 1);
-                t.xo[e] = (unsigned)rb * (unsigned)ld + (unsigned)min(c0 + c * 8, ld - 8);
-            }
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = (lane & 31) ^ (((rb & 3) | ((e & 1) << 2)) << 1);
+                        t.xo[e] = (unsigned)rb * (unsigned)rows + (unsigned)min(c0 + c * 8, rows - 8);
+                    }
+                } else {
+                    const int c = (lane & 3) ^ ((lane >> 4) & 3);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        t.xo[i] = (unsigned)min(c0 + (i * 4 + wn) * 16 + (lane >> 2), rows - 1) * (unsigned)K + c * 8;
+                }
+            };
+            if (wm == 0) offsets(std::integral_constant<bool, TRX>{}, M, m0);
+            else offsets(std::integral_constant<bool, TRW>{}, N, n0);
             return;
         }
         const int tr_r = wid * 2 + (lane >> 5);
@@ -361,20 +391,45 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
         }
     };
 
-    // RING: this wave's four pieces of its group's unit `half` (0 / 1) of k-step kt of tile t, into buffer buf
-    auto issue_unit = [&](const Src& t, int kt, int buf, int half) {
-        const T* b = wm == 0 ? t.xb : t.wb;
-        const long long ld = wm == 0 ? M : N;
+    // RING: this wave's pieces (the first `cnt` of four) of its group's unit `half` (0 / 1) of k-step kt of tile t, into
+    // buffer buf
+    auto issue_unit = [&](const Src& t, int kt, int buf, int half, int cnt) {
         char* dst = smem + buf * STAGE_BYTES + (wm == 0 ? 0 : X_BYTES) + half * 16384 + wn * 1024;
-        const T* rowp = b + (long long)(kt * TK + half * 32) * ld;
+        const T* b = t.ob;
+        if constexpr (SEG) {
+            const int nks = K / TK;
+            const int seg = (kt >= nks ? 1 : 0) + (kt >= 2 * nks ? 1 : 0) + (kt >= 3 * nks ? 1 : 0);
+            kt -= seg * nks;
+            b += (long long)seg * (wm == 0 ? p.x_seg_stride : p.w_seg_stride);
+        }
+        auto go = [&](auto tr, long long ld) {
+            if constexpr (decltype(tr)::value) {
+                const T* rowp = b + (long long)(kt * TK + half * 32) * ld;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(rowp + (long long)(i * 8) * ld + t.xo[i & 1], dst + i * 4096);
+                for (int i = 0; i < 4; ++i) glds16(rowp + (long long)(i * 8) * ld + t.xo[i], dst + i * 4096);
+            } else {
+                const T* colp = b + kt * TK + half * 32;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < cnt) glds16(colp + t.xo[i], dst + i * 4096);
+            }
+        };
+        if (wm == 0) go(std::integral_constant<bool, TRX>{}, M);
+        else go(std::integral_constant<bool, TRW>{}, N);
     };
-    auto wait_units = [&](int younger) {  // wave-uniform: all but the `younger` most recent units have landed
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto wait_pieces = [&](int n) {  // wave-uniform: all but this wave's n most recent pieces have landed
+        switch (n) {
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
     };
+    // row-major operands under RING: lane -> row lane & 15 of a 16-row block, chunk (lane >> 4) ^ ((row >> 2) & 3)
 
     const int fsw = (lane >> 1) & 7;
     const int foff0 = (lane & 15) * ROW_BYTES + ((((lane >> 4)) ^ fsw) << 4);
@@ -395,6 +450,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned tr_w0 = lds0 + X_BYTES + tr_lane + (((wn * 4) ^ tr_rl) << 5);
     const unsigned tr_x0 = lds0 + tr_lane + ((wm ^ tr_rl) << 5);
+    // row-major operands under RING: lane -> row lane & 15 of a 16-row block, chunk (lane >> 4) ^ ((row >> 2) & 3); the
+    // blocks of a wave are immediate offsets away (x: wm + 2 j -> 2 KiB apart, w: wn * 4 + i -> 1 KiB apart)
+    const unsigned ring_foff = (lane & 15) * 64 + (((lane >> 4) ^ ((lane >> 2) & 3)) << 4);
+    const unsigned ring_x0 = lds0 + ring_foff + wm * 1024;
+    const unsigned ring_w0 = lds0 + X_BYTES + ring_foff + wn * 4096;
+    auto ring_read = [&](unsigned a, auto off) -> frag {
+        frag v;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(decltype(off)::value));
+        return v;
+    };
     auto tr_read = [&](unsigned a0, int blk_xor, auto half) -> frag {
         const unsigned a = a0 ^ (unsigned)(blk_xor << 5);
         constexpr int off = decltype(half)::value * 32 * 512;
@@ -415,9 +480,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
     tile_setup(d, cur, s, m0, n0, h);
     int g = 0;  // running k-step counter: step g lives in LDS buffer g & 1
     if constexpr (RING) {
-        issue_unit(cur, 0, 0, 0);
-        issue_unit(cur, 0, 0, 1);
-        issue_unit(cur, 1, 1, 0);
+        issue_unit(cur, 0, 0, 0, 4);
+        issue_unit(cur, 0, 0, 1, 4);
+        issue_unit(cur, 1, 1, 0, 4);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         stage(cur, 0, 0, h);
@@ -493,22 +558,42 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
                 ++g;
             };
 
-            // the RING k-step: same slots and barriers; one unit issued per L slot, counted waits
-            // `steady`: k-steps kt and kt + 1 both have a successor in this tile — no conditions in the loop body
-            auto kstep_ring = [&](int kt, const Src& nxt, auto last, auto steady) {
+            // the RING k-step: same slots and barriers; one unit issued per L slot, counted waits.
+            // A row-major x unit only needs the tile's 32 H rows: every wave of group 0 fetches the first CX of its four
+            // pieces (64 CX >= 32 H rows).  Units issued across a tile boundary (and by the prologue) are always whole:
+            // pieces(j, half) below is what this wave issued for that unit of k-step j (j >= nk = the next tile).
+            // `steady`: kt + 2 < nk — every unit issued is this tile's own, no conditions in the loop body
+            constexpr int CX = TRX ? 4 : (2 * H + 3) / 4;
+            const int cw = wm == 0 ? CX : 4;
+            auto pieces = [&](int j, int half) { return (j >= nk || j == 0 || (j == 1 && half == 0)) ? 4 : cw; };
+            auto read_frags = [&](unsigned sboff, auto half) {
+                constexpr int HF = decltype(half)::value;
+                static_for<0, 4>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if constexpr (TRW) wf[i] = tr_read(tr_w0 + sboff, i, half);
+                    else wf[i] = ring_read(ring_w0 + sboff, std::integral_constant<int, HF * 16384 + i * 1024>{});
+                });
+                static_for<0, H>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    if constexpr (TRX) xf[j] = tr_read(tr_x0 + sboff, 2 * j, half);
+                    else xf[j] = ring_read(ring_x0 + sboff, std::integral_constant<int, HF * 16384 + j * 2048>{});
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            Src nxt = cur;  // the next tile's sources, set up before the last two k-steps
+            auto kstep_ring = [&](int kt, auto last, auto steady) {
                 constexpr bool ST = decltype(steady)::value;
                 const bool e1 = ST || kt + 1 < nk || has_next, e2 = ST || kt + 2 < nk || has_next;
                 const unsigned sboff = (g & 1) * STAGE_BYTES;
                 if (e1) {
-                    if (ST || kt + 1 < nk) issue_unit(cur, kt + 1, (g & 1) ^ 1, 1);
-                    else issue_unit(nxt, 0, (g & 1) ^ 1, 1);
+                    if (ST || kt + 1 < nk) issue_unit(cur, kt + 1, (g & 1) ^ 1, 1, cw);
+                    else issue_unit(nxt, 0, (g & 1) ^ 1, 1, 4);
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wf[i] = tr_read(tr_w0 + sboff, i, std::integral_constant<int, 0>{});
-#pragma unroll
-                for (int j = 0; j < H; ++j) xf[j] = tr_read(tr_x0 + sboff, 2 * j, std::integral_constant<int, 0>{});
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (wm == 1) wait_units(e1 ? 2 : 0);  // W1(kt)
+                read_frags(sboff, std::integral_constant<int, 0>{});
+                if (wm == 1) {  // W1(kt)
+                    if constexpr (ST) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else wait_pieces(e1 ? 8 : 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_s_setprio(1);
@@ -517,19 +602,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
 #pragma unroll
                     for (int j = 0; j < H; ++j) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
                 __builtin_amdgcn_s_setprio(0);
-                if (wm == 0) wait_units(e1 ? 2 : 0);  // X1(kt)
+                if (wm == 0) {  // X1(kt)
+                    if constexpr (ST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CX) : "memory");
+                    else wait_pieces(e1 ? pieces(kt + 1, 0) + pieces(kt + 1, 1) : 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 if (e2) {
-                    if (ST || kt + 2 < nk) issue_unit(cur, kt + 2, g & 1, 0);
-                    else issue_unit(nxt, kt + 2 - nk, g & 1, 0);
+                    if (ST || kt + 2 < nk) issue_unit(cur, kt + 2, g & 1, 0, cw);
+                    else issue_unit(nxt, kt + 2 - nk, g & 1, 0, 4);
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wf[i] = tr_read(tr_w0 + sboff, i, std::integral_constant<int, 1>{});
-#pragma unroll
-                for (int j = 0; j < H; ++j) xf[j] = tr_read(tr_x0 + sboff, 2 * j, std::integral_constant<int, 1>{});
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (wm == 1) wait_units(e1 ? (e2 ? 2 : 1) : 0);  // W0(kt + 1)
+                read_frags(sboff, std::integral_constant<int, 1>{});
+                if (wm == 1) {  // W0(kt + 1)
+                    if constexpr (ST) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else wait_pieces(e1 ? (e2 ? 8 : 4) : 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_s_setprio(1);
@@ -538,7 +625,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
 #pragma unroll
                     for (int j = 0; j < H; ++j) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
                 __builtin_amdgcn_s_setprio(0);
-                if (wm == 0) wait_units(e1 ? (e2 ? 2 : 1) : 0);  // X0(kt + 1)
+                if (wm == 0) {  // X0(kt + 1)
+                    if constexpr (ST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CX) : "memory");
+                    else wait_pieces(e1 ? pieces(kt + 1, 1) + (e2 ? pieces(kt + 2, 0) : 0) : 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(decltype(last)::value && wm == 1)) __builtin_amdgcn_s_barrier();
                 ++g;
@@ -548,14 +638,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
             init_acc<H>(acc, p.bias ? p.bias + (long long)s * N : nullptr, n0, N, wn, lane);
 
             if constexpr (RING) {
-                for (int kt = 0; kt + 2 < nk; ++kt) kstep_ring(kt, cur, std::false_type{}, std::true_type{});
-                Src nxt = cur;
+                // (k-step 0 runs the steady code too: its wait at the end of M0 then counts the whole unit X0(1) as 2 CX
+                // <= 4 + CX pieces — stricter than needed, and that unit was issued before the previous epilogue)
+                for (int kt = 0; kt + 2 < nk; ++kt) kstep_ring(kt, std::false_type{}, std::true_type{});
                 if (has_next) {
                     int s2, m2, n2, h2;
                     tile_setup(dn, nxt, s2, m2, n2, h2);
                 }
-                kstep_ring(nk - 2, nxt, std::false_type{}, std::false_type{});
-                kstep_ring(nk - 1, nxt, std::true_type{}, std::false_type{});
+                kstep_ring(nk - 2, std::false_type{}, std::false_type{});
+                kstep_ring(nk - 1, std::true_type{}, std::false_type{});
             } else {
             for (int kt = 0; kt + 1 < nk; ++kt)
                 kstep([&] {
@@ -594,7 +685,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
             // end of group 1's last LDS slot, group 1 comes from its last MFMA slot
             if (!skip) {
                 if constexpr (RING)
-                    epilogue_wave<YT, H, 1>(smem + 2 * STAGE_BYTES + wid * 4096, acc, y, y2, m0, m_end, n0, N, wm, wn, lane,
+                    epilogue_wave<YT, H, sizeof(YT) == 2 ? 2 : 1>(smem + 2 * STAGE_BYTES + wid * 4096, acc, y, y2, m0, m_end, n0, N, wm, wn, lane,
                                             p.act);
                 else
                     epilogue_wave<YT, H>(smem + ((g - 1) & 1) * STAGE_BYTES + wid * 8192, acc, y, y2, m0, m_end, n0, N, wm,
@@ -836,11 +927,9 @@ int get_schedule(int S, int layers, int tiles_n, int M, int policy, hipStream_t 
 template <typename T>
 int launch256_tn(const GemmParams& p, hipStream_t stream, int grid) {
     // the unit ring needs two k-steps to wrap around (the contraction here is over the S * B * L batch rows: always)
-#ifndef BF_TN_NO_RING
     if (p.K >= 2 * TK)
         hipLaunchKernelGGL((gemm256_sched_kernel<T, float, true, true, false, true>), dim3(grid), dim3(512), 0, stream, p);
     else
-#endif
         hipLaunchKernelGGL((gemm256_sched_kernel<T, float, true, true>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
@@ -848,6 +937,13 @@ int launch256_tn(const GemmParams& p, hipStream_t stream, int grid) {
 
 template <typename T>
 int launch256_nn(const GemmParams& p, hipStream_t stream, int grid) {
+#ifdef BF_RING_ROWMAJOR  // measured slower than the burst form for row-major operands: developer builds only
+    if (p.segs > 1)
+        hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, true, true, true>), dim3(grid), dim3(512), 0, stream, p);
+    else if (p.K >= 2 * TK)
+        hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, true, false, true>), dim3(grid), dim3(512), 0, stream, p);
+    else
+#endif
     if (p.segs > 1) hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, true, true>), dim3(grid), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, true>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
@@ -858,6 +954,10 @@ template <typename T>
 int launch256(const GemmParams& p, int y_dtype, hipStream_t stream, int grid) {
     if (y_dtype == BF_DT_F32)
         hipLaunchKernelGGL((gemm256_sched_kernel<T, float>), dim3(grid), dim3(512), 0, stream, p);
+#ifdef BF_RING_ROWMAJOR
+    else if (p.K >= 2 * TK)
+        hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, false, false, true>), dim3(grid), dim3(512), 0, stream, p);
+#endif
     else
         hipLaunchKernelGGL((gemm256_sched_kernel<T, T>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
