@@ -347,6 +347,59 @@ def conversion_case():
     return d
 
 
+# ---------------------------------------------------------------------------------------------- training step (tiny BERT)
+def bert_train_case():
+    """One training step of the reference on the tiny BERT of bert_case(True): the sample loop of
+    examples/bert_glue.py:63-66 WITH gradients, nll = CrossEntropy(mean logits) and
+    loss = (lvp - log_prior) / n_batches + nll (bert_glue.py:234-235), loss.backward() (bert_glue.py:239).
+    Dropout is off (eval mode) so that the step is a function of the Philox epsilon only.  Stored: the gradient of every
+    trainable tensor as (sum, sum |g|, max |g|) and, in full, the rho gradients of one layer of each kind."""
+    from transformers import BertConfig, BertForSequenceClassification
+
+    cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                     vocab_size=1000, max_position_embeddings=64)
+    S, B, L, NB = 3, 4, 16, 2105
+    torch.manual_seed(0)
+    model = BertForSequenceClassification(cfg).eval()
+    bmodel = ref_to_bayesian(model, delta=0.05, freeze=True).eval()
+    csum = checksum(bmodel)
+    torch.manual_seed(321)
+    ids = torch.randint(0, cfg.vocab_size, (B, L))
+    mask = torch.ones(B, L, dtype=torch.long)
+    labels = torch.randint(0, 2, (B,))
+    clock = {"seed": SEED, "sample": 0}
+    inject(bmodel, clock)
+    logits = torch.zeros(S, B, 2)
+    lp = torch.zeros(S, B)
+    lq = torch.zeros(S, B)
+    for s in range(S):
+        clock["sample"] = s
+        logits[s] = bmodel(input_ids=ids, attention_mask=mask, labels=labels)[1]
+        lp[s] = bmodel.log_prior()
+        lq[s] = bmodel.log_variational_posterior()
+    nll = torch.nn.functional.cross_entropy(logits.mean(0).view(-1, 2), labels.view(-1))
+    loss = (lq.mean() - lp.mean()) / NB + nll
+    loss.backward()
+    out = {"S": S, "B": B, "L": L, "n_batches": NB, "model_seed": 0, "input_seed": 321, "delta": 0.05, "checksum": csum,
+           "ids_sum": int(ids.sum()), "labels": t2n(labels), "logits": t2n(logits), "nll": float(nll.detach()), "loss": float(loss.detach())}
+    full = ("bert.encoder.layer.0.attention.self.query", "bert.encoder.layer.1.attention.self.value",
+            "bert.encoder.layer.0.attention.output.dense", "bert.encoder.layer.1.intermediate.dense",
+            "bert.encoder.layer.0.output.dense", "bert.pooler.dense", "classifier")
+    names = []
+    for name, p_ in bmodel.named_parameters():
+        if p_.grad is None:
+            continue
+        g = p_.grad.detach().double()
+        names.append(name)
+        out[f"stat/{name}"] = np.array([float(g.sum()), float(g.abs().sum()), float(g.abs().max())], np.float64)
+        if name.endswith(".rho") and "prior" not in name and name.rsplit(".", 2)[0].replace("model.", "", 1) in full:
+            out[f"grad/{name}"] = t2n(p_.grad)
+    out["names"] = np.array(names)
+    print(f"  bert train: {len(names)} tensors with a gradient, {sum(k.startswith('grad/') for k in out)} stored in full")
+    return out
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-bert", action="store_true")
@@ -354,6 +407,7 @@ def main():
     ap.add_argument("--only-bert-large", action="store_true")
     ap.add_argument("--only-c4", action="store_true", help="BASELINE config 4: BERT-base, S = 64 (about 6 minutes of CPU)")
     ap.add_argument("--only-checkpoint", action="store_true")
+    ap.add_argument("--only-bert-train", action="store_true")
     args = ap.parse_args()
     torch.set_num_threads(8)
     if args.only_c4:
@@ -361,6 +415,9 @@ def main():
         return
     if args.only_checkpoint:
         np.savez_compressed(os.path.join(HERE, "checkpoint.npz"), **checkpoint_case())
+        return
+    if args.only_bert_train:
+        np.savez_compressed(os.path.join(HERE, "bert_tiny_train.npz"), **bert_train_case())
         return
     if args.only_bert_large:
         np.savez_compressed(os.path.join(HERE, "bert_large_qa_c5.npz"), **bert_large_qa_case())
@@ -376,6 +433,7 @@ def main():
     print("checkpoint"); np.savez_compressed(os.path.join(HERE, "checkpoint.npz"), **checkpoint_case())
     print("mlp C1"); np.savez_compressed(os.path.join(HERE, "mlp_c1.npz"), **mlp_case())
     print("bert tiny"); np.savez_compressed(os.path.join(HERE, "bert_tiny.npz"), **bert_case(True))
+    print("bert tiny training step"); np.savez_compressed(os.path.join(HERE, "bert_tiny_train.npz"), **bert_train_case())
     if not args.skip_bert:
         print("bert base C3 (about a minute of CPU)"); np.savez_compressed(os.path.join(HERE, "bert_c3.npz"), **bert_case(False))
         print("bert base C4, S = 64 (about 6 minutes of CPU)")
