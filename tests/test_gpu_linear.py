@@ -175,7 +175,11 @@ def test_gemm_detects_transposes():
 
 
 @pytest.mark.parametrize("batch,Mc,N,K", [(1, 64, 8, 8), (2, 128, 256, 256), (3, 192, 200, 136), (1, 1024, 776, 264),
-                                          (2, 64, 1032, 40), (20, 2048, 768, 768), (1, 320, 24, 520), (40, 64, 768, 768)])
+                                          (2, 64, 1032, 40), (20, 2048, 768, 768), (1, 320, 24, 520), (40, 64, 768, 768),
+                                          # more tiles than workgroups: the unit ring carries on across tile boundaries
+                                          # (2 / 3 k-steps: no steady-state step; ragged edges; the benchmarked shape)
+                                          (40, 128, 768, 768), (36, 192, 768, 1024), (30, 256, 776, 520),
+                                          (10, 4096, 3072, 768)])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_gemm_tn_against_torch(batch, Mc, N, K, dt):
     """bf_gemm_tn (dW = dy^T x, operands read contraction-major through the LDS transpose read) against an fp64 einsum
