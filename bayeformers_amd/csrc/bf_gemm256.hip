@@ -219,6 +219,19 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
     }
 }
 
+// compile-time loop (immediate offsets for the inline-asm LDS reads)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+
 // ------------------------------------------------------------------------------------------------------------
 // The kernel: persistent ping-pong over a host-built tile schedule.
 // The two waves that share a SIMD belong to different wave groups (G0 = waves 0-3 = even 16-row blocks of the tile,
@@ -251,18 +264,6 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
 //    0   0   NT   y = x W^T          (forward; x [M][K], W [N][K])
 //    1   1   TN   dW = dy^T x        (weight gradient; dy [m][N], x [m][K], contraction over the batch rows m)
 //    0   1   NN   dx = dy W          (input gradient; dy [M][N], W [N][K] read as it was sampled: no transposed copy)
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
-
 //
 // RING (TN form, >= 2 k-steps): the DMA of a k-step is not issued in one burst of 8 pieces per wave at L0 but as
 // four UNITS of [32 contraction rows][256] (16 KiB: X0, W0 = the halves read in L0, X1, W1 = the halves read in L1),
