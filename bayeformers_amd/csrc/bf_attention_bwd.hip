@@ -89,11 +89,11 @@ __device__ __forceinline__ typename Mfma<T>::frag row_frag(const char* swz, int 
 
 // transposed fragment: rows = features db*16 + li, k = the 32 tile rows {(2c)*16 + 4 lg + 0..3, (2c+1)*16 + 4 lg + 0..3}
 // of a padded tile, by two LDS transpose reads (the 16 lanes of a group point at a [4 rows][16 features] block)
-template <typename T>
+template <typename T, int ROW = P_ROW>
 __device__ __forceinline__ typename Mfma<T>::frag tr_frag(const char* pad, int c, int db, int li, int lg) {
-    const char* blk = pad + (lg * 4 + (li >> 2)) * P_ROW + (db * 16 + (li & 3) * 4) * 2;
-    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(blk + (2 * c) * 16 * P_ROW));
-    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(blk + (2 * c + 1) * 16 * P_ROW));
+    const char* blk = pad + (lg * 4 + (li >> 2)) * ROW + (db * 16 + (li & 3) * 4) * 2;
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(blk + (2 * c) * 16 * ROW));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(blk + (2 * c + 1) * 16 * ROW));
     const s16x8_t ab = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return __builtin_bit_cast(typename Mfma<T>::frag, ab);
 }
@@ -298,6 +298,140 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------- T = 128: all three
+// One key tile = one query tile: dQ, dK and dV of a (sequence, head) in ONE workgroup, P and dS computed once.
+// The first part is the dK / dV kernel (8 waves x 16 keys; S = Q K^T, dP = dO V^T with the queries as rows), with delta
+// computed here (wave w: queries 16 w .. 16 w + 15).  Then every wave leaves the dS of its 16 keys — a lane holds 4
+// consecutive queries of one key: 8-byte writes — as rows of a padded dS^T[key][query] image, and its 16 K rows (still
+// in registers as the column operand) as rows of a padded K image, both over the Q / dO images that are dead by then;
+// wave w takes queries 16 w .. 16 w + 15 of dQ^T = K^T dS^T with BOTH operands through the LDS transpose read (the
+// same contraction order on either side: keys (2c) 16 + 4 lg + 0..3, (2c + 1) 16 + 4 lg + 0..3).  Deterministic: no
+// atomics, a fixed summation order.  HBM: 5 reads (Q, K, V, O, dO) + 3 writes, against 9 + 3 of the two-kernel path.
+constexpr int DS_ROW = TT * 2 + 32;  // 288 B: a row of dS^T (128 queries) + the transpose read's padding
+
+template <typename T>
+__global__ __launch_bounds__(512, 4) void attention_bwd_tile_kernel(const BwdParams p) {
+    using frag = typename Mfma<T>::frag;
+    using half4 = typename Mfma<T>::half4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * S_BYTES + 2 * P_BYTES + 2 * TT * 4];
+    char* const qs = smem;                               // Q, swizzled: row operand of S
+    char* const dos = smem + S_BYTES;                    // dO, swizzled: row operand of dP
+    char* const qp = smem + 2 * S_BYTES;                 // Q, padded: Q^T through the transpose read
+    char* const dop = smem + 2 * S_BYTES + P_BYTES;      // dO, padded: dO^T through the transpose read
+    float* const lse_s = reinterpret_cast<float*>(smem + 2 * S_BYTES + 2 * P_BYTES);
+    float* const del_s = lse_s + TT;
+    char* const dst = smem;                              // second part: dS^T [128 keys][DS_ROW] over qs | dos | qp ...
+    char* const kp = dop;                                // ... and K, padded, over dO^T
+    static_assert(TT * DS_ROW <= 2 * S_BYTES + P_BYTES, "the dS^T image must end before the K image");
+    const float* const mask = (p.mask && !(p.mask_off && *p.mask_off)) ? p.mask : nullptr;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const long long row = wid * 16 + li;                 // this lane's key in the first part, its query in the second
+    const long long hoff = (long long)h * HD;
+    const T* qb = reinterpret_cast<const T*>(p.q) + (long long)b * p.T * p.tok_stride + hoff;
+    const T* kb = reinterpret_cast<const T*>(p.k) + (long long)b * p.T * p.tok_stride + hoff;
+    const T* vb = reinterpret_cast<const T*>(p.v) + (long long)b * p.T * p.tok_stride + hoff;
+    const long long ostride = (long long)p.H * HD;
+    const T* ob = reinterpret_cast<const T*>(p.o) + (long long)b * p.T * ostride + hoff;
+    const T* dob = reinterpret_cast<const T*>(p.dout) + (long long)b * p.T * ostride + hoff;
+    const float* lse_g = p.lse + ((long long)b * p.H + h) * p.T;
+
+    frag kf[2], vf[2];
+    float part = 0.f;
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh) {
+        kf[dh] = *reinterpret_cast<const frag*>(kb + row * p.tok_stride + dh * 32 + lg * 8);
+        vf[dh] = *reinterpret_cast<const frag*>(vb + row * p.tok_stride + dh * 32 + lg * 8);
+        const frag df = *reinterpret_cast<const frag*>(dob + row * ostride + dh * 32 + lg * 8);
+        const frag of = *reinterpret_cast<const frag*>(ob + row * ostride + dh * 32 + lg * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part = fmaf((float)df[e], (float)of[e], part);
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    if (lg == 0) {
+        del_s[row] = part;
+        p.delta[((long long)b * p.H + h) * p.T + row] = part;
+    }
+    const float mk = mask ? mask[(long long)b * p.T + row] * 1.4426950408889634f : 0.f;
+
+    stage_tile<T, 512>(qb, p.tok_stride, 0, qs, qp, tid);
+    stage_tile<T, 512>(dob, ostride, 0, dos, dop, tid);
+    if (tid < TT / 4)
+        *reinterpret_cast<f32x4_t*>(lse_s + tid * 4) = *reinterpret_cast<const f32x4_t*>(lse_g + tid * 4);
+    __syncthreads();
+    // S and dP [query][key]: lane (key li, group lg) holds queries qbk*16 + 4 lg + 0..3 of each block
+    f32x4_t s[8], dp[8];
+#pragma unroll
+    for (int qbk = 0; qbk < 8; ++qbk) {
+        s[qbk] = dp[qbk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+            s[qbk] = Mfma<T>::run(row_frag<T>(qs, qbk, dh, li, lg), kf[dh], s[qbk]);
+            dp[qbk] = Mfma<T>::run(row_frag<T>(dos, qbk, dh, li, lg), vf[dh], dp[qbk]);
+        }
+    }
+#pragma unroll
+    for (int qbk = 0; qbk < 8; ++qbk) {
+        const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_s + qbk * 16 + lg * 4);
+        const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(del_s + qbk * 16 + lg * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float pr = __builtin_amdgcn_exp2f(fmaf(s[qbk][j], p.scale_log2e, mk) - l4[j]);
+            s[qbk][j] = pr;                          // P
+            dp[qbk][j] = pr * (dp[qbk][j] - d4[j]);  // dS
+        }
+    }
+    f32x4_t dk[4], dv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dk[j] = dv[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const frag pf = pack2<T>(s[2 * c], s[2 * c + 1]);
+        const frag dsf = pack2<T>(dp[2 * c], dp[2 * c + 1]);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            dv[db] = Mfma<T>::run(tr_frag<T>(dop, c, db, li, lg), pf, dv[db]);
+            dk[db] = Mfma<T>::run(tr_frag<T>(qp, c, db, li, lg), dsf, dk[db]);
+        }
+    }
+    T* dkb = reinterpret_cast<T*>(p.dk) + (long long)b * p.T * ostride + hoff;
+    T* dvb = reinterpret_cast<T*>(p.dv) + (long long)b * p.T * ostride + hoff;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        *reinterpret_cast<half4*>(dkb + row * ostride + db * 16 + lg * 4) = __builtin_convertvector(dk[db] * p.scale, half4);
+        *reinterpret_cast<half4*>(dvb + row * ostride + db * 16 + lg * 4) = __builtin_convertvector(dv[db], half4);
+    }
+
+    __syncthreads();  // every wave has read the last of Q, dO and their transposes
+#pragma unroll
+    for (int qbk = 0; qbk < 8; ++qbk)
+        *reinterpret_cast<half4*>(dst + row * DS_ROW + (qbk * 16 + lg * 4) * 2) = __builtin_convertvector(dp[qbk], half4);
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)  // K again (L2-hot) rather than 8 registers held across the first part: 128 VGPRs =
+                                    // two workgroups per CU, one staging while the other computes
+        *reinterpret_cast<frag*>(kp + row * P_ROW + (dh * 32 + lg * 8) * 2) =
+            *reinterpret_cast<const frag*>(kb + row * p.tok_stride + dh * 32 + lg * 8);
+    __syncthreads();
+    // dQ^T[d][query] = sum_k K^T[d][k] dS^T[k][query] for the wave's query block `wid`
+    f32x4_t dq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dq[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const frag dsf = tr_frag<T, DS_ROW>(dst, c, wid, li, lg);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dq[db] = Mfma<T>::run(tr_frag<T>(kp, c, db, li, lg), dsf, dq[db]);
+    }
+    T* dqb = reinterpret_cast<T*>(p.dq) + (long long)b * p.T * ostride + hoff;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+        *reinterpret_cast<half4*>(dqb + row * ostride + db * 16 + lg * 4) = __builtin_convertvector(dq[db] * p.scale, half4);
+}
+
 }  // namespace
 
 int bf_launch_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask,
@@ -335,6 +469,12 @@ int bf_launch_attention_bwd(const void* d_q, const void* d_k, const void* d_v, c
     p.scale = scaling;
     p.scale_log2e = scaling * 1.4426950408889634f;
     const dim3 grid(T / TT, H, B);
+    if (T == TT) {  // one tile: dQ, dK, dV in one launch
+        if (dtype == BF_DT_BF16) hipLaunchKernelGGL(attention_bwd_tile_kernel<__bf16>, grid, dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL(attention_bwd_tile_kernel<_Float16>, grid, dim3(512), 0, stream, p);
+        BF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (dtype == BF_DT_BF16) {
         hipLaunchKernelGGL(attention_bwd_dq_kernel<__bf16>, grid, dim3(256), 0, stream, p);
         hipLaunchKernelGGL(attention_bwd_dkv_kernel<__bf16>, grid, dim3(512), 0, stream, p);
