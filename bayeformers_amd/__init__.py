@@ -259,7 +259,7 @@ def _attention_interface(module, query, key, value, attention_mask, dropout: flo
         if m.dim() == 4 and m.shape[0] == B and m.shape[1] == 1 and m.shape[3] == T and (m.shape[2] == 1 or m.stride(2) == 0):
             row = m[:, 0, 0, :]
             if row.dtype == torch.bool:
-                key_mask = torch.zeros(row.shape, dtype=torch.float32, device=row.device).masked_fill_(~row, float("-inf"))
+                key_mask = torch.where(row, 0.0, float("-inf")).to(torch.float32)
             else:
                 key_mask = row.to(torch.float32).contiguous()
         else:
@@ -294,7 +294,7 @@ def _padding_mask_interface(batch_size, q_length=None, kv_length=None, q_offset=
         return sdpa_mask(batch_size=batch_size, q_length=q_length, kv_length=kv_length, q_offset=q_offset,
                          kv_offset=kv_offset, mask_function=mask_function, attention_mask=attention_mask, **kwargs)
     visible = attention_mask if attention_mask.dtype == torch.bool else attention_mask != 0
-    additive = torch.zeros(visible.shape, dtype=torch.float32, device=visible.device).masked_fill_(~visible, float("-inf"))
+    additive = torch.where(visible, 0.0, float("-inf")).to(torch.float32)  # one launch (fp32 already: .to is a no-op)
     out = additive[:, None, None, :]
     out._bf_key_mask = additive
     out._bf_mask_off = visible.all().reshape(1)  # stays on the device

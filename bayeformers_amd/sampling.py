@@ -145,4 +145,4 @@ def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callabl
 
 def elbo(log_prior: Tensor, log_variational_posterior: Tensor, nll: Tensor, n_batches: int) -> Tensor:
     """loss = (lvp - log_prior) / n_batches + nll  (bert_glue.py:235, mlp_mnist.py:107, README.md:72)."""
-    return (log_variational_posterior - log_prior) / n_batches + nll
+    return torch.add(nll, log_variational_posterior - log_prior, alpha=1.0 / n_batches)
