@@ -302,9 +302,9 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
 // ---------------------------------------------------------------------------------------------------- T = 128: all three
 // One key tile = one query tile: dQ, dK and dV of a (sequence, head) in ONE workgroup, P and dS computed once.
 // The first part is the dK / dV kernel (8 waves x 16 keys; S = Q K^T, dP = dO V^T with the queries as rows), with delta
-// computed here (wave w: queries 16 w .. 16 w + 15).  Then every wave leaves the dS of its 16 keys — a lane holds 4
-// consecutive queries of one key: 8-byte writes — as rows of a padded dS^T[key][query] image, and its 16 K rows (still
-// in registers as the column operand) as rows of a padded K image, both over the Q / dO images that are dead by then;
+// computed here (wave w: queries 16 w .. 16 w + 15).  Every wave leaves its 16 K rows (still in registers as the column
+// operand) as rows of a padded K image once S and dP are done, and the dS of its 16 keys — a lane holds 4 consecutive
+// queries of one key: 8-byte writes — as rows of a padded dS^T[key][query] image, over the Q / dO images that are dead by then;
 // wave w takes queries 16 w .. 16 w + 15 of dQ^T = K^T dS^T with BOTH operands through the LDS transpose read (the
 // same contraction order on either side: keys (2c) 16 + 4 lg + 0..3, (2c + 1) 16 + 4 lg + 0..3).  Deterministic: no
 // atomics, a fixed summation order.  HBM: 5 reads (Q, K, V, O, dO) + 3 writes, against 9 + 3 of the two-kernel path.
@@ -321,9 +321,9 @@ __global__ __launch_bounds__(512, 4) void attention_bwd_tile_kernel(const BwdPar
     char* const dop = smem + 2 * S_BYTES + P_BYTES;      // dO, padded: dO^T through the transpose read
     float* const lse_s = reinterpret_cast<float*>(smem + 2 * S_BYTES + 2 * P_BYTES);
     float* const del_s = lse_s + TT;
-    char* const dst = smem;                              // second part: dS^T [128 keys][DS_ROW] over qs | dos | qp ...
-    char* const kp = dop;                                // ... and K, padded, over dO^T
-    static_assert(TT * DS_ROW <= 2 * S_BYTES + P_BYTES, "the dS^T image must end before the K image");
+    char* const kp = smem;                               // K, padded, over qs | dos once S and dP are done (K is still in registers)
+    char* const dst = smem + 2 * S_BYTES;                // dS^T [128 keys][DS_ROW] over qp | dop once dK and dV are done
+    static_assert(P_BYTES <= 2 * S_BYTES && TT * DS_ROW <= 2 * P_BYTES, "the K and dS^T images alias dead tiles only");
     const float* const mask = (p.mask && !(p.mask_off && *p.mask_off)) ? p.mask : nullptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -339,22 +339,12 @@ __global__ __launch_bounds__(512, 4) void attention_bwd_tile_kernel(const BwdPar
     const T* dob = reinterpret_cast<const T*>(p.dout) + (long long)b * p.T * ostride + hoff;
     const float* lse_g = p.lse + ((long long)b * p.H + h) * p.T;
 
-    frag kf[2], vf[2];
-    float part = 0.f;
+    frag kf[2], vf[2], of[2];
 #pragma unroll
     for (int dh = 0; dh < 2; ++dh) {
         kf[dh] = *reinterpret_cast<const frag*>(kb + row * p.tok_stride + dh * 32 + lg * 8);
         vf[dh] = *reinterpret_cast<const frag*>(vb + row * p.tok_stride + dh * 32 + lg * 8);
-        const frag df = *reinterpret_cast<const frag*>(dob + row * ostride + dh * 32 + lg * 8);
-        const frag of = *reinterpret_cast<const frag*>(ob + row * ostride + dh * 32 + lg * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) part = fmaf((float)df[e], (float)of[e], part);
-    }
-    part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);
-    if (lg == 0) {
-        del_s[row] = part;
-        p.delta[((long long)b * p.H + h) * p.T + row] = part;
+        of[dh] = *reinterpret_cast<const frag*>(ob + row * ostride + dh * 32 + lg * 8);
     }
     const float mk = mask ? mask[(long long)b * p.T + row] * 1.4426950408889634f : 0.f;
 
@@ -363,6 +353,22 @@ __global__ __launch_bounds__(512, 4) void attention_bwd_tile_kernel(const BwdPar
     if (tid < TT / 4)
         *reinterpret_cast<f32x4_t*>(lse_s + tid * 4) = *reinterpret_cast<const f32x4_t*>(lse_g + tid * 4);
     __syncthreads();
+    {   // delta of query `row` = <dO, O>: the dO row comes out of the staged tile (a row fragment of block wid is the
+        // lane's 8 features of that row); it is first read behind the barrier that follows the S / dP products
+        float part = 0.f;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+            const frag df = row_frag<T>(dos, wid, dh, li, lg);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part = fmaf((float)df[e], (float)of[dh][e], part);
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (lg == 0) {
+            del_s[row] = part;
+            p.delta[((long long)b * p.H + h) * p.T + row] = part;
+        }
+    }
     // S and dP [query][key]: lane (key li, group lg) holds queries qbk*16 + 4 lg + 0..3 of each block
     f32x4_t s[8], dp[8];
 #pragma unroll
@@ -373,29 +379,40 @@ __global__ __launch_bounds__(512, 4) void attention_bwd_tile_kernel(const BwdPar
             s[qbk] = Mfma<T>::run(row_frag<T>(qs, qbk, dh, li, lg), kf[dh], s[qbk]);
             dp[qbk] = Mfma<T>::run(row_frag<T>(dos, qbk, dh, li, lg), vf[dh], dp[qbk]);
         }
+        if (qbk & 1) __builtin_amdgcn_sched_barrier(0);  // (keeps the fragment reads of later blocks from piling up in registers)
     }
+    __syncthreads();  // delta of all 128 queries is in LDS; the swizzled Q and dO images are dead
 #pragma unroll
-    for (int qbk = 0; qbk < 8; ++qbk) {
-        const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_s + qbk * 16 + lg * 4);
-        const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(del_s + qbk * 16 + lg * 4);
+    for (int dh = 0; dh < 2; ++dh) *reinterpret_cast<frag*>(kp + row * P_ROW + (dh * 32 + lg * 8) * 2) = kf[dh];
+    // P and dS leave the fp32 accumulators as 16-bit column operands right away (half the registers through the dV /
+    // dK products: no spills at 128 VGPRs); pf[c] / dsf[c] = query blocks 2c, 2c + 1
+    frag pf[4], dsf[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float pr = __builtin_amdgcn_exp2f(fmaf(s[qbk][j], p.scale_log2e, mk) - l4[j]);
-            s[qbk][j] = pr;                          // P
-            dp[qbk][j] = pr * (dp[qbk][j] - d4[j]);  // dS
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int qbk = 2 * c + e;
+            const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lse_s + qbk * 16 + lg * 4);
+            const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(del_s + qbk * 16 + lg * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pr = __builtin_amdgcn_exp2f(fmaf(s[qbk][j], p.scale_log2e, mk) - l4[j]);
+                s[qbk][j] = pr;                          // P
+                dp[qbk][j] = pr * (dp[qbk][j] - d4[j]);  // dS
+            }
         }
+        pf[c] = pack2<T>(s[2 * c], s[2 * c + 1]);
+        dsf[c] = pack2<T>(dp[2 * c], dp[2 * c + 1]);
     }
     f32x4_t dk[4], dv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) dk[j] = dv[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const frag pf = pack2<T>(s[2 * c], s[2 * c + 1]);
-        const frag dsf = pack2<T>(dp[2 * c], dp[2 * c + 1]);
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-            dv[db] = Mfma<T>::run(tr_frag<T>(dop, c, db, li, lg), pf, dv[db]);
-            dk[db] = Mfma<T>::run(tr_frag<T>(qp, c, db, li, lg), dsf, dk[db]);
+            dv[db] = Mfma<T>::run(tr_frag<T>(dop, c, db, li, lg), pf[c], dv[db]);
+            dk[db] = Mfma<T>::run(tr_frag<T>(qp, c, db, li, lg), dsf[c], dk[db]);
         }
     }
     T* dkb = reinterpret_cast<T*>(p.dk) + (long long)b * p.T * ostride + hoff;
@@ -408,13 +425,11 @@ __global__ __launch_bounds__(512, 4) void attention_bwd_tile_kernel(const BwdPar
 
     __syncthreads();  // every wave has read the last of Q, dO and their transposes
 #pragma unroll
-    for (int qbk = 0; qbk < 8; ++qbk)
-        *reinterpret_cast<half4*>(dst + row * DS_ROW + (qbk * 16 + lg * 4) * 2) = __builtin_convertvector(dp[qbk], half4);
-#pragma unroll
-    for (int dh = 0; dh < 2; ++dh)  // K again (L2-hot) rather than 8 registers held across the first part: 128 VGPRs =
-                                    // two workgroups per CU, one staging while the other computes
-        *reinterpret_cast<frag*>(kp + row * P_ROW + (dh * 32 + lg * 8) * 2) =
-            *reinterpret_cast<const frag*>(kb + row * p.tok_stride + dh * 32 + lg * 8);
+    for (int c = 0; c < 4; ++c) {  // elements 0..3 / 4..7 of dsf[c]: queries (2c) 16 + 4 lg + 0..3 / (2c + 1) 16 + 4 lg + 0..3
+        const half4 lo = {dsf[c][0], dsf[c][1], dsf[c][2], dsf[c][3]}, hi = {dsf[c][4], dsf[c][5], dsf[c][6], dsf[c][7]};
+        *reinterpret_cast<half4*>(dst + row * DS_ROW + ((2 * c) * 16 + lg * 4) * 2) = lo;
+        *reinterpret_cast<half4*>(dst + row * DS_ROW + ((2 * c + 1) * 16 + lg * 4) * 2) = hi;
+    }
     __syncthreads();
     // dQ^T[d][query] = sum_k K^T[d][k] dS^T[k][query] for the wave's query block `wid`
     f32x4_t dq[4];
