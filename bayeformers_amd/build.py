@@ -17,7 +17,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libbayeformers_amd.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-SOURCES = ["bf_api.hip", "bf_sample.hip", "bf_gemm.hip", "bf_gemm256.hip", "bf_backward.hip", "bf_fused_small.hip", "bf_fused_ws.hip", "bf_norm.hip", "bf_attention.hip", "bf_attention_bwd.hip"]
+SOURCES = ["bf_api.hip", "bf_sample.hip", "bf_gemm.hip", "bf_gemm256.hip", "bf_gemm256_r5.hip", "bf_backward.hip", "bf_fused_small.hip", "bf_fused_ws.hip", "bf_norm.hip", "bf_attention.hip", "bf_attention_bwd.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

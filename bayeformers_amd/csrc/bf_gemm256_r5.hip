@@ -1,0 +1,269 @@
+// bf_gemm256_r5.hip — the forward form (NT: x [M][K], W_s [N][K], both K-contiguous) of the 256-wide sampled-weight GEMM
+// with its LDS run as a FIVE-SLOT RING of 32 KiB operand units: y[s] = x[s] W_s^T + b_s, F.linear at
+// /root/reference/bayeformers/nn/layers/linear.py:104 for all S samples in one launch.
+//
+// Same tile, waves, fragments, swizzle, schedule and epilogue as bf_gemm256.hip (read its header first).  What differs is
+// how a k-step's operands reach LDS.  There, a k-step's 64 KiB stage (x rows + W rows) is DMA'd in ONE burst of 8 pieces
+// per wave at the top of the L0 slot into the other half of a double buffer: the L0 slot (8 DMA issues + 12 fragment
+// reads) is about twice as long as the 32-MFMA slot it is paired with, and a piece has 3-4 slots to land.  Here all
+// 160 KiB of the CU's LDS are five slots of one UNIT each — a unit = the 256 rows x 128 B of ONE operand of one k-step,
+// in ring order W(0) X(0) W(1) X(1) ... — so the ring runs 1.5 k-steps ahead of the MFMAs:
+//
+//      slot sequence of a wave group:   L0(t)            M0(t)    L1(t)            M1(t)
+//      DMA issued (4 pieces per wave):  X(t+1)                    W(t+2)
+//      into the ring slot that held:    W(t-1)                    X(t-1)
+//      waited for (vmcnt(4) = all but the newest unit) before the barrier that ends M1(t) (group 0) / L1(t) (group 1)
+//
+// Every L slot carries 4 pieces instead of 8 or 0, an x unit has 4 slots to land and a W unit 6 (W_s is the operand that
+// comes cold from HBM: it is read once per step), and every piece is still 8 FULL 128-byte rows (the k-half ring of the
+// burst kernel's -DBF_RING_ROWMAJOR build splits every line in two and loses).  The last two k-steps of a tile issue
+// W(0), X(0), W(1) of the workgroup's next tile, so a tile boundary costs the ring nothing; the wave-private epilogue
+// (16-bit outputs: 4 KiB of scratch per wave) fits in ONE of the two slots the last k-step consumed, the one whose next
+// unit is issued two barriers into the next tile — no DMA ever waits for an epilogue (the burst kernel's `defer`).
+// Requirements on top of bf_gemm256_supported(): K >= 128 (two k-steps: the ring wraps a tile boundary by 1.5 steps).
+#include "bf_gemm256_dev.h"
+
+namespace {
+
+constexpr int SLOT_BYTES = 32768;  // one unit: 256 rows x 128 B (= X_BYTES)
+constexpr int NSLOT = 5;
+
+// BUF: the pieces are fetched with buffer_load ... lds through a per-tile buffer descriptor (32-bit per-lane byte offset
+// + scalar k offset: no 64-bit vector address arithmetic per piece) instead of global_load_lds.
+template <typename T, typename YT, bool BUF>
+__global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams p) {
+    using frag = typename Mfma16<T>::frag;
+
+    __shared__ __attribute__((aligned(1024))) char smem[NSLOT * SLOT_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int M = p.M, N = p.N, K = p.K;
+
+    // piece q = i * 8 + wid of a unit = rows 8 q .. 8 q + 7; lane -> (row lane >> 3, 16-byte position lane & 7) holding
+    // source chunk position ^ ((row >> 1) & 7)
+    const int prow = lane >> 3;
+    const int kc8 = ((lane & 7) ^ ((((wid & 1) << 2) + (lane >> 4)) & 7)) * 8;
+
+    // DMA sources of the units still to be issued: wave-uniform operand bases + four per-lane offsets per operand (elements;
+    // bytes under BUF).  Only ONE such set exists: the W half is switched to the workgroup's next tile before the k-step
+    // that issues that tile's W(0), the x half one k-step later.
+    const T* xb;
+    const T* wb;
+    unsigned xo[4], wo[4];
+    auto setup_w = [&](const int4 d) {
+        const int s = __builtin_amdgcn_readfirstlane(d.x);
+        const int n0 = (__builtin_amdgcn_readfirstlane(d.z) & 0xFFFFFF) * TN;
+        wb = reinterpret_cast<const T*>(p.w) + (long long)s * N * K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            wo[i] = ((unsigned)min(n0 + (i * 8 + wid) * 8 + prow, N - 1) * (unsigned)K + kc8) * (BUF ? 2u : 1u);
+    };
+    auto setup_x = [&](const int4 d) {
+        const int m0 = __builtin_amdgcn_readfirstlane(d.w);
+        xb = reinterpret_cast<const T*>(p.x) + (long long)__builtin_amdgcn_readfirstlane(d.y) * p.x_sstride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            xo[i] = ((unsigned)min(m0 + (i * 8 + wid) * 8 + prow, M - 1) * (unsigned)K + kc8) * (BUF ? 2u : 1u);
+    };
+    auto piece = [&](const T* base, unsigned off, int kt, char* dst) {
+#ifdef BF_DEV
+        if (p.flags & 1) return;   // ablation: no DMA in the k-loop
+        if (p.flags & 64) kt = 0;  // ablation: every k-step re-reads k-step 0 (operands L2-hot)
+#endif
+        if constexpr (BUF) {
+            const __amdgpu_buffer_rsrc_t r =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, 0x7FFFFFFF, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, (int)off, kt * (TK * 2), 0, 0);
+        } else {
+            glds16(base + (long long)kt * TK + off, dst);
+        }
+    };
+    // this wave's pieces of unit X(kt) / W(kt) into ring slot `slot`; only the 4 h pieces of the tile's rows of x are
+    // fetched (h4 = 4 h: an integral_constant inside a tile's k-loop, so a full-height tile issues without branches)
+    auto issue_x = [&](int kt, int slot, auto h4) {
+        char* base = smem + slot * SLOT_BYTES + wid * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i * 8 + 7 < h4 || i * 8 + wid < h4) piece(xb, xo[i], kt, base + i * 8192);
+    };
+    auto issue_w = [&](int kt, int slot) {
+        char* base = smem + slot * SLOT_BYTES + wid * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) piece(wb, wo[i], kt, base + i * 8192);
+    };
+
+    // fragment reads: inline asm (the k-loop's own waits order them against the DMA and the MFMAs; the compiler's
+    // wait-count pass would otherwise drain every in-flight DMA before an LDS load it can see)
+    const int fsw = (lane >> 1) & 7;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned foff0 = (lane & 15) * ROW_BYTES + ((((lane >> 4)) ^ fsw) << 4);
+    const unsigned foff1 = (lane & 15) * ROW_BYTES + (((4 + (lane >> 4)) ^ fsw) << 4);
+    const unsigned xrow0 = lds0 + wm * 16 * ROW_BYTES;  // + j * 32 rows: wave group wm owns blocks wm, wm + 2, ...
+    const unsigned wrow0 = lds0 + wn * 64 * ROW_BYTES;  // + i * 16 rows
+    auto lds_read = [&](unsigned a, auto off) -> frag {
+        frag v;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(decltype(off)::value));
+        return v;
+    };
+
+    const int nk = K / TK;
+    const int4* __restrict__ sched = p.sched + blockIdx.x;
+    const unsigned G = gridDim.x;
+    int4 d = sched[0];
+    if ((d.z >> 24) == 0) return;
+    int s = __builtin_amdgcn_readfirstlane(d.x);
+    int h = __builtin_amdgcn_readfirstlane(d.z) >> 24;
+    int m0 = __builtin_amdgcn_readfirstlane(d.w);
+    int n0 = (__builtin_amdgcn_readfirstlane(d.z) & 0xFFFFFF) * TN;
+    setup_w(d);
+    setup_x(d);
+    int a = 0;  // ring slot of W of the k-step about to run; X of that step sits in a + 1, X(+1) goes to a + 3, W(+2) to a + 4
+    issue_w(0, 0);
+    issue_x(0, 1, 4 * h);
+    issue_w(1, 2);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int round = 0;
+    for (;;) {
+        int4 dn = {0, 0, 0, 0};
+        if (round + 1 < p.sched_rounds) dn = sched[(unsigned)(round + 1) * G];
+        const int h2 = __builtin_amdgcn_readfirstlane(dn.z) >> 24;
+        const bool has_next = h2 != 0;
+
+        auto body = [&](auto hc) {
+            constexpr int H = decltype(hc)::value;
+            f32x4_t acc[4][H];
+            frag wf[4], xf[H];
+            auto read_frags = [&](unsigned aw, unsigned ax) {
+                static_for<0, 4>([&](auto ic) {
+                    wf[decltype(ic)::value] = lds_read(aw, std::integral_constant<int, decltype(ic)::value * 16 * ROW_BYTES>{});
+                });
+                static_for<0, H>([&](auto jc) {
+                    xf[decltype(jc)::value] = lds_read(ax, std::integral_constant<int, decltype(jc)::value * 32 * ROW_BYTES>{});
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            auto mfmas = [&] {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < H; ++j) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+            };
+            // MODE 0: kt + 2 < nk, every unit issued is this tile's own; 1: kt = nk - 2 (L1 issues the next tile's W(0));
+            // 2: kt = nk - 1 (L0: the next tile's X(0), L1: its W(1)).
+            auto kstep = [&](int kt, auto mode) {
+                constexpr int MODE = decltype(mode)::value;
+                int ax = a + 1, a3 = a + 3, a4 = a + 4;
+                if (ax >= NSLOT) ax -= NSLOT;
+                if (a3 >= NSLOT) a3 -= NSLOT;
+                if (a4 >= NSLOT) a4 -= NSLOT;
+                const unsigned sw = wrow0 + a * SLOT_BYTES, sx = xrow0 + ax * SLOT_BYTES;
+                auto dma0 = [&] {
+                    if constexpr (MODE == 2) {
+                        if (has_next) issue_x(0, a3, 4 * h2);
+                    } else {
+                        issue_x(kt + 1, a3, std::integral_constant<int, 4 * H>{});
+                    }
+                };
+                auto wait_all_but_newest = [&] {
+                    if (MODE == 0 || has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                };
+                dma0();
+                read_frags(sw + foff0, sx + foff0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                mfmas();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                if constexpr (MODE == 0) issue_w(kt + 2, a4);
+                else if (has_next) issue_w(MODE == 1 ? 0 : 1, a4);
+                read_frags(sw + foff1, sx + foff1);
+                if (wm == 1) wait_all_but_newest();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                mfmas();
+                if (wm == 0) wait_all_but_newest();
+                __builtin_amdgcn_sched_barrier(0);
+                // (group 1 does not meet group 0 again before the tile-end barrier: its last slot ends without one, which
+                // also keeps the two groups' barrier counts equal)
+                if (!(MODE == 2 && wm == 1)) __builtin_amdgcn_s_barrier();
+                a += 2;
+                if (a >= NSLOT) a -= NSLOT;
+            };
+
+            if (wm == 1) __builtin_amdgcn_s_barrier();  // G1 runs one slot behind G0
+#ifdef BF_DEV
+            init_acc<H>(acc, (p.bias && !(p.flags & 2)) ? p.bias + (long long)s * N : nullptr, n0, N, wn, lane);
+#else
+            init_acc<H>(acc, p.bias ? p.bias + (long long)s * N : nullptr, n0, N, wn, lane);
+#endif
+
+            for (int kt = 0; kt + 2 < nk; ++kt) kstep(kt, std::integral_constant<int, 0>{});
+            if (has_next) setup_w(dn);  // every W unit of this tile is issued
+            kstep(nk - 2, std::integral_constant<int, 1>{});
+            if (has_next) setup_x(dn);  // ... and now every x unit
+            kstep(nk - 1, std::integral_constant<int, 2>{});
+
+            // epilogue scratch: 4 KiB per wave (two 16-row blocks of 16-bit outputs), all eight in the slot of X of the last
+            // k-step.  Every fragment read of it is complete: group 0 passed its last barrier together with the end of
+            // group 1's last LDS slot, group 1 comes from its last MFMA slot.  The next unit that lands there is W(2) of
+            // the next tile, issued behind that tile's second barrier, which every wave reaches after its epilogue; the
+            // slot of W of the last k-step takes the next tile's X(1) at once (no wave reads it any more).
+            static_assert(sizeof(YT) == 2, "the one-slot epilogue scratch holds 16-bit outputs");
+            int sc = a + 4;
+            if (sc >= NSLOT) sc -= NSLOT;
+            YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
+            YT* y2 = p.y2 ? reinterpret_cast<YT*>(p.y2) + (long long)s * M * N : nullptr;
+            int m_end = min(M, m0 + h * UNIT);
+#ifdef BF_DEV
+            if (p.flags & 16) m_end = 0;  // ablation: no global stores
+            if (!(p.flags & 8))           // ablation: no epilogue
+#endif
+            epilogue_wave<YT, H>(smem + sc * SLOT_BYTES + wid * 4096, acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act);
+        };
+        switch (h) {
+            case 8: body(std::integral_constant<int, 8>{}); break;
+            case 7: body(std::integral_constant<int, 7>{}); break;
+            case 6: body(std::integral_constant<int, 6>{}); break;
+            case 5: body(std::integral_constant<int, 5>{}); break;
+            default: body(std::integral_constant<int, 4>{}); break;  // h <= 4: rows past 32 h are masked on store
+        }
+        if (!has_next) break;
+        d = dn;
+        ++round;
+        s = __builtin_amdgcn_readfirstlane(d.x);
+        h = h2;
+        m0 = __builtin_amdgcn_readfirstlane(d.w);
+        n0 = (__builtin_amdgcn_readfirstlane(d.z) & 0xFFFFFF) * TN;
+        // (no barrier between tiles: see `defer` in kstep)
+    }
+}
+
+template <typename T, typename YT>
+int launch_r5(const GemmParams& p, hipStream_t stream, int grid, bool buf) {
+    if (buf) hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, true>), dim3(grid), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, false>), dim3(grid), dim3(512), 0, stream, p);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+bool bf_gemm256_r5_supported(const GemmParams& p, int w_dtype, int y_dtype) {
+    if (p.K < 2 * TK || p.segs > 1) return false;
+    if (y_dtype != w_dtype) return false;  // fp32 outputs stay on the burst kernel
+    return true;
+}
+
+int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, int grid, bool buf) {
+    // the buffer form addresses an operand by 32-bit byte offsets
+    if (buf && ((long long)p.M * p.K >= (1ll << 30) || (long long)p.N * p.K >= (1ll << 30))) buf = false;
+    if (w_dtype == BF_DT_BF16) return launch_r5<__bf16, __bf16>(p, stream, grid, buf);
+    return launch_r5<_Float16, _Float16>(p, stream, grid, buf);
+}

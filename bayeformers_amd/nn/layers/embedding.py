@@ -90,6 +90,11 @@ class Embedding(KernelLayer):
         inside `bnn.Model.monte_carlo(S)`; otherwise S = 1)."""
         if input.dtype not in (torch.int64, torch.int32):
             raise TypeError("bnn.Embedding expects integer token ids")
+        if bfr.STATE.ctx is None:
+            again = bfr.recompute_context()
+            if again is not None:  # a checkpointed block recomputed during backward: the forward's own epsilon
+                with again.replay():
+                    return self.forward(input)
         ctx, base, S, slot = self._begin(self.weight.mu.device)
         ids = input.reshape(-1).to(torch.int64).contiguous()
         _, lp = ops.sample_logprob([self.weight], [self.weight_prior], [2 * self.layer_id], S, bfr.STATE.seed, base)

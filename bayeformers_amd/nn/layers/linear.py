@@ -183,6 +183,11 @@ class Linear(KernelLayer):
 
         Inside `bnn.Model` with S Monte-Carlo samples in flight the input is [S*B, ..., in_features]
         (sample-major) and slab s is multiplied by W_s; otherwise S = 1 and one fresh sample index is used."""
+        if bfr.STATE.ctx is None:
+            again = bfr.recompute_context()
+            if again is not None:  # a checkpointed block recomputed during backward: the forward's own epsilon
+                with again.replay():
+                    return self.forward(input)
         ctx, base, S, slot = self._begin(input.device)
         x2 = input.reshape(-1, self.in_features)
         if x2.shape[0] == 0:

@@ -45,6 +45,22 @@ class _ForwardContext:
         self.plan, self.lp_buf = plan, lp_buf
         self.token = next(_TOKENS)
         self.shared_out = {}  # id(first layer of a stacked run) -> (input identity, [L, S, M, N] outputs)
+        self.counter = bfr.counter_snapshot()  # device-counter mode: the counter value this forward's kernels added
+
+    @contextlib.contextmanager
+    def replay(self):
+        """Run layer forwards again under this (finished) forward's sample indices: the recomputation of a checkpointed
+        block during backward (bayeformers_amd.random.recompute_context).  Sampled weights still resident in the plan's
+        arenas are reused; overwritten ones are drawn again from the same counters."""
+        prev = bfr.STATE.ctx
+        bfr.STATE.ctx = self
+        try:
+            with bfr.counter_override(self.counter):
+                yield self
+        finally:
+            bfr.STATE.ctx = prev
+            if self.plan is not None and prev is None:
+                self.plan.pending.clear()  # the log-probs of these samples were reduced when the forward ended
 
     def slot(self, layer) -> Optional[Tensor]:
         return self._slots.get(id(layer))
@@ -88,7 +104,7 @@ class Model(Module):
         super(Model, self).__init__()
         self.model = model
         self._mc_samples = 1
-        self._mc_shard = (0, 1)
+        self._mc_span = (0, 1)  # (first global sample index of this process, indices every step consumes)
         self._fused: Optional[List[KernelLayer]] = None
         self._lp_buf: Optional[Tensor] = None
         self._last_base = None
@@ -129,9 +145,9 @@ class Model(Module):
                     self._plan = SamplePlan(pl, S, cdt, layers[0].weight.mu.device, index=[i for i, _ in planned],
                                             shared=shared)
                 plan = self._plan
-        rank, world = self._mc_shard
-        # every rank reserves the GLOBAL S*world indices and runs its own contiguous slice of them
-        base = bfr.reserve_samples(S * world) + rank * S
+        # every rank reserves the GLOBAL sample indices of the step and runs its own contiguous slice of them
+        start, total = self._mc_span
+        base = bfr.reserve_samples(total) + start
         self._last_base, self._last_seed, self._last_S = base, bfr.STATE.seed, S
         self._last_counter = bfr.counter_snapshot() if bfr.STATE.kl_gradient else None
         bfr.STATE.ctx = _ForwardContext(base, S, slots, plan, self._lp_buf)
@@ -140,20 +156,28 @@ class Model(Module):
         finally:
             if plan is not None:
                 plan.finish(self._lp_buf)  # one log-prob reduction for all the groups this forward sampled
-            bfr.STATE.ctx = None
-            bfr.commit_samples(S * world)
+            bfr.STATE.last_ctx, bfr.STATE.ctx = bfr.STATE.ctx, None
+            bfr.commit_samples(total)
 
     @contextlib.contextmanager
-    def monte_carlo(self, samples: int, shard=(0, 1)):
+    def monte_carlo(self, samples: int, shard=(0, 1), span=None):
         """Run forwards with `samples` Monte-Carlo samples folded into the batch axis (inputs repeated S times,
         sample-major: `x.repeat(S, 1, ...)`).  shard = (rank, world): this process runs `samples` of the
-        `samples * world` global sample indices of each step (S-sharding over GPUs, sampling.sample_bayesian)."""
-        prev = (self._mc_samples, self._mc_shard)
-        self._mc_samples, self._mc_shard = int(samples), (int(shard[0]), int(shard[1]))
+        `samples * world` global sample indices of each step (S-sharding over GPUs, sampling.sample_bayesian).
+        span = (start, total) says it directly — this process runs the global indices [start, start + samples) of the
+        `total` every step consumes — for shards of unequal size (S = 10 over 8 GPUs: sampling.shard_span)."""
+        prev = (self._mc_samples, self._mc_span)
+        S = int(samples)
+        if span is None:
+            span = (int(shard[0]) * S, S * int(shard[1]))
+        start, total = int(span[0]), int(span[1])
+        if S < 1 or start < 0 or start + S > total:
+            raise ValueError(f"monte_carlo: samples={S} at offset {start} do not fit in the step's {total} sample indices")
+        self._mc_samples, self._mc_span = S, (start, total)
         try:
             yield self
         finally:
-            self._mc_samples, self._mc_shard = prev
+            self._mc_samples, self._mc_span = prev
 
     def fused_children(self) -> List[KernelLayer]:
         """The kernel-backed children (bnn.Linear, bnn.Embedding) in registration order; their layer_id (Philox

@@ -27,6 +27,7 @@ class _State:
         self.seed = DEFAULT_SEED
         self.next_sample = 0
         self.ctx = None  # (sample_base, S) while a bnn.Model forward is running
+        self.last_ctx = None  # the context of the last finished bnn.Model forward (recompute_context)
         self.compute_dtype = torch.bfloat16
         self.next_layer_id = 0
         self.device_counter = None  # 1-element int32 device tensor when the sample counter lives on the GPU
@@ -94,6 +95,20 @@ def set_compute_dtype(dtype) -> None:
 
 def get_compute_dtype() -> torch.dtype:
     return STATE.compute_dtype
+
+
+def recompute_context():
+    """The context of the last bnn.Model forward, when a Bayesian layer is called with no forward running WHILE autograd
+    executes a backward pass: that is the recomputation of a checkpointed block (torch.utils.checkpoint), which must draw
+    the epsilon of the forward it repeats — the same sample indices, the same (device) counter value — not fresh ones."""
+    c = STATE.last_ctx
+    if c is None:
+        return None
+    try:
+        in_backward = torch._C._current_graph_task_id() != -1
+    except AttributeError:  # pragma: no cover - private API of the installed torch
+        in_backward = False
+    return c if in_backward else None
 
 
 def new_layer_id() -> int:

@@ -72,6 +72,14 @@ def _default_select(out):
     raise TypeError("sample_bayesian: pass select= to pick the output tensor(s) of the model")
 
 
+def shard_span(samples: int, rank: int, world: int) -> Tuple[int, int]:
+    """(first global sample index, number of samples) of rank `rank` when `samples` Monte-Carlo samples are sharded
+    over `world` ranks: contiguous slices whose sizes differ by at most one (S = 10 over 8 GPUs: 2, 2, 1, 1, 1, 1, 1, 1 —
+    BASELINE config 5's 8-GPU leg).  A rank past the last sample gets (samples, 0)."""
+    q, r = divmod(int(samples), int(world))
+    return rank * q + min(rank, r), q + (1 if rank < r else 0)
+
+
 def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callable] = None,
                     group: Optional["dist.ProcessGroup"] = None, gather_raw: bool = False
                     ) -> Tuple[Tuple[Tensor, ...], Tuple[Tensor, ...], Tensor, Tensor]:
@@ -81,24 +89,30 @@ def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callabl
         batch; they are repeated S_local times here.
     select: maps the model output to a tuple of [S_local*B, ...] tensors to average (default: `.logits`,
         `(start_logits, end_logits)`, or the output itself).
-    group: if torch.distributed is initialised (or a group is given) the samples are sharded over its ranks;
-        `samples` must be a multiple of the world size.
+    group: if torch.distributed is initialised (or a group is given) the samples are sharded over its ranks in
+        contiguous slices whose sizes differ by at most one (`shard_span`); `samples` need not be a multiple of the
+        world size.  (A rank left without a sample — more ranks than samples — still runs one forward, of the step's
+        first sample, to learn the output shapes; it enters the reduction with weight zero.)
 
     Returns (raw, mean, log_prior, log_variational_posterior):
-        raw   tuple of [S_local, B, ...] per-sample outputs of this rank (all S if gather_raw),
+        raw   tuple of [S_local, B, ...] per-sample outputs of this rank, S_local = shard_span(...)[1] (all S if gather_raw),
         mean  tuple of [B, ...] means over ALL S samples,
         log_prior, log_variational_posterior: 0-d float64 means over ALL S samples.
     """
     distributed = dist.is_available() and dist.is_initialized() and (group is not None or dist.get_world_size() > 1)
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
-    if samples % world:
-        raise ValueError(f"samples={samples} must be a multiple of the world size {world}")
-    s_local = samples // world
+    if samples < 1:
+        raise ValueError(f"samples={samples}: at least one Monte-Carlo sample")
+    start, count = shard_span(samples, rank, world)
+    idle = count == 0
+    if idle:
+        start, count = 0, 1
+    s_local = count
     select = select or _default_select
 
     rep = repeat_inputs(inputs, s_local)
-    with model.monte_carlo(s_local, shard=(rank, world)):
+    with model.monte_carlo(s_local, span=(start, samples)):
         if isinstance(rep, dict):
             out = model(**rep)
         elif isinstance(rep, Tensor):
@@ -111,10 +125,13 @@ def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callabl
 
     # sums over this rank's samples: outputs in fp32 (fused convert-on-load, they can be large), the two log-prob
     # scalars in fp64; small outputs ride in the same fp64 buffer so that a distributed step is ONE collective
-    n_out = sum(r[0].numel() for r in raw)
+    sizes = [r[0].numel() for r in raw]
+    n_out = sum(sizes)
     one_buffer = n_out <= 65536
     acc_dt = torch.float64 if one_buffer else torch.float32
     sums = [r.sum(0, dtype=acc_dt).reshape(-1) for r in raw]
+    if idle:  # this rank's forward only provided the shapes
+        sums, lp, raw = [t * 0 for t in sums], lp * 0, tuple(r[:0] for r in raw)
     if one_buffer:
         packed = torch.cat(sums + [lp.sum(0)])
         if distributed:
@@ -128,17 +145,22 @@ def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callabl
             dist.all_reduce(lp_part, op=dist.ReduceOp.SUM, group=group)
         out_part, lp_part = out_part / samples, lp_part / samples
     means, off = [], 0
-    for r in raw:
-        n = r[0].numel()
+    for r, n in zip(raw, sizes):
         means.append(out_part[off:off + n].reshape(r.shape[1:]).to(r.dtype))
         off += n
     log_prior, lvp = lp_part[0], lp_part[1]
     if distributed and gather_raw:
+        # shards may differ by one sample: every rank sends ceil(S / world) slabs, the receiver keeps each rank's own
+        s_max = -(-samples // world)
+        counts = [shard_span(samples, r, world)[1] for r in range(world)]
         gathered = []
         for r in raw:
-            parts = [torch.empty_like(r) for _ in range(world)]
-            dist.all_gather(parts, r.contiguous(), group=group)
-            gathered.append(torch.cat(parts, 0))
+            send = r.contiguous()
+            if send.shape[0] < s_max:
+                send = torch.cat([send, send.new_zeros((s_max - send.shape[0],) + tuple(send.shape[1:]))], 0)
+            parts = [torch.empty_like(send) for _ in range(world)]
+            dist.all_gather(parts, send, group=group)
+            gathered.append(torch.cat([part[:c] for part, c in zip(parts, counts)], 0))
         raw = tuple(gathered)
     return raw, tuple(means), log_prior, lvp
 

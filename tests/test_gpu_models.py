@@ -299,13 +299,11 @@ def test_fused_residual_layernorm_matches_unfused_bert():
     assert any(p.grad is not None and p.grad.abs().sum() > 0 for p in bmodel.parameters())
 
 
-@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-2), ("bf16", 8e-2)])
-def test_bert_large_qa_c5(golden_dir, dtype, tol):
-    """BASELINE config 5: to_bayesian(BERT-large QA), S=10, seq=384, batch=16, fp16 MFMA (and bf16), vs the reference."""
+def _bert_large_c5(g, dtype):
+    """to_bayesian(BERT-large QA) in the configuration bench.py --workload bert_large_qa times, and its inputs."""
     from transformers import BertConfig, BertForQuestionAnswering
 
-    g = np.load(f"{golden_dir}/bert_large_qa_c5.npz")
-    S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
+    B, L = int(g["B"]), int(g["L"])
     cfg = BertConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
     torch.manual_seed(int(g["model_seed"]))
     model = BertForQuestionAnswering(cfg).eval()
@@ -320,13 +318,33 @@ def test_bert_large_qa_c5(golden_dir, dtype, tol):
     bf.fuse_activations(bmodel)
     bf.fuse_residual_layernorm(bmodel)
     assert bf.fuse_shared_inputs(bmodel) == cfg.num_hidden_layers
-    assert bf.fuse_attention(bmodel)  # the configuration bench.py --workload bert_large_qa times
+    assert bf.fuse_attention(bmodel)
     assert bf.fuse_embeddings(bmodel) == 1
+    inputs = {"input_ids": ids.cuda(), "attention_mask": torch.ones(B, L, dtype=torch.long, device="cuda")}
+    return bmodel, inputs
+
+
+def _c5_scales(g):
+    """Tolerance scales of the config-5 logits: the fixture's own magnitudes (the mean start logits of a random-init
+    BERT-large peak at 0.035, the mean end logits at 0.15, single samples at ~1: a max(1, .) scale made the mean checks
+    vacuous)."""
+    return (max(np.abs(g["start_mean"]).max(), np.abs(g["end_mean"]).max()),
+            max(np.abs(g["start_s0"]).max(), np.abs(g["end_s9"]).max()))
+
+
+# tolerances relative to the largest per-sample logit (operand rounding through 24 layers); the mean over S = 10 samples
+# is checked against the same ABSOLUTE bound / sqrt(S): rounding errors of independent samples average out like the
+# logits themselves do
+@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-2), ("bf16", 8e-2)])
+def test_bert_large_qa_c5(golden_dir, dtype, tol):
+    """BASELINE config 5: to_bayesian(BERT-large QA), S=10, seq=384, batch=16, fp16 MFMA (and bf16), vs the reference."""
+    g = np.load(f"{golden_dir}/bert_large_qa_c5.npz")
+    S = int(g["S"])
+    bmodel, inputs = _bert_large_c5(g, dtype)
     bf.manual_seed(SEED)
     bf.set_compute_dtype(dtype)
     try:
         with torch.no_grad():
-            inputs = {"input_ids": ids.cuda(), "attention_mask": torch.ones(B, L, dtype=torch.long, device="cuda")}
             raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S)
     finally:
         bf.set_compute_dtype("bf16")
@@ -334,11 +352,55 @@ def test_bert_large_qa_c5(golden_dir, dtype, tol):
     np.testing.assert_allclose(lps[:, 0], g["log_prior"], rtol=2e-6)
     np.testing.assert_allclose(lps[:, 1], g["lvp"], rtol=2e-6)
     start, end = raw[0].float().cpu().numpy(), raw[1].float().cpu().numpy()
-    scale = max(1.0, np.abs(g["start_mean"]).max())
-    assert np.abs(start.mean(0) - g["start_mean"]).max() < tol * scale
-    assert np.abs(end.mean(0) - g["end_mean"]).max() < tol * scale
-    assert np.abs(start[0] - g["start_s0"]).max() < tol * scale
-    assert np.abs(end[9] - g["end_s9"]).max() < tol * scale
+    mean_scale, sample_scale = _c5_scales(g)
+    assert np.abs(start[0] - g["start_s0"]).max() < tol * sample_scale
+    assert np.abs(end[9] - g["end_s9"]).max() < tol * sample_scale
+    assert np.abs(start.mean(0) - g["start_mean"]).max() < tol * sample_scale / np.sqrt(S)
+    assert np.abs(end.mean(0) - g["end_mean"]).max() < tol * sample_scale / np.sqrt(S)
+    assert np.abs(mean[0].float().cpu().numpy() - g["start_mean"]).max() < tol * sample_scale / np.sqrt(S)
+
+
+def test_config5_shards_match_reference_c5(golden_dir):
+    """BASELINE config 5's 8-GPU leg: S = 10 samples of BERT-large QA over 8 ranks is not an even split — rank r runs
+    `shard_span(10, r, 8)` = 2, 2, 1, 1, 1, 1, 1, 1 samples.  The eight shards run here one after the other on one GPU
+    (`monte_carlo(count, span=(start, 10))`, exactly what sample_bayesian does on rank r); each slice is checked against
+    the reference's samples [start, start + count) and the summed contributions — what the all-reduce adds up —
+    against the reference's means over all 10."""
+    from bayeformers_amd.sampling import repeat_inputs, shard_span
+
+    g = np.load(f"{golden_dir}/bert_large_qa_c5.npz")
+    S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
+    G, dtype, tol = 8, "fp16", 2e-2
+    spans = [shard_span(S, r, G) for r in range(G)]
+    assert [c for _, c in spans] == [2, 2, 1, 1, 1, 1, 1, 1] and [s for s, _ in spans] == [0, 2, 4, 5, 6, 7, 8, 9]
+    bmodel, inputs = _bert_large_c5(g, dtype)
+    mean_scale, sample_scale = _c5_scales(g)
+    bf.set_compute_dtype(dtype)
+    sum_start = torch.zeros(B, L, dtype=torch.float64, device="cuda")
+    sum_end = torch.zeros(B, L, dtype=torch.float64, device="cuda")
+    try:
+        for r, (start, count) in enumerate(spans):
+            bf.manual_seed(SEED)  # every rank starts the step from the same global sample counter
+            rep = repeat_inputs(inputs, count)
+            with torch.no_grad(), bmodel.monte_carlo(count, span=(start, S)):
+                out = bmodel(**rep)
+            lps = bmodel.log_prob_samples().cpu().numpy()
+            sl = slice(start, start + count)
+            np.testing.assert_allclose(lps[:, 0], g["log_prior"][sl], rtol=2e-6)
+            np.testing.assert_allclose(lps[:, 1], g["lvp"][sl], rtol=2e-6)
+            st = out.start_logits.float().reshape(count, B, L)
+            en = out.end_logits.float().reshape(count, B, L)
+            if start == 0:
+                assert np.abs(st[0].cpu().numpy() - g["start_s0"]).max() < tol * sample_scale
+            if start + count == S:
+                assert np.abs(en[-1].cpu().numpy() - g["end_s9"]).max() < tol * sample_scale
+            sum_start += st.double().sum(0)
+            sum_end += en.double().sum(0)
+            assert bf.random.get_state()[1] == S  # the step consumed the 10 global indices on every rank
+    finally:
+        bf.set_compute_dtype("bf16")
+    assert np.abs((sum_start / S).cpu().numpy() - g["start_mean"]).max() < tol * sample_scale / np.sqrt(S)
+    assert np.abs((sum_end / S).cpu().numpy() - g["end_mean"]).max() < tol * sample_scale / np.sqrt(S)
 
 
 def test_hip_graph_replay_draws_fresh_samples():

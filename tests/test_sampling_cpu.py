@@ -55,33 +55,83 @@ def test_single_process_harness():
     assert float(elbo(lp, lq, torch.tensor(2.0), 10)) == pytest.approx((elq - elp) / 10 + 2.0)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, S=6):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         bfr.manual_seed(1)
         torch.manual_seed(0)
         x = torch.randn(4, 5)
-        raw, mean, lp, lq = sample_bayesian(StubModel(), x, 6, gather_raw=True)
-        raw_local, _, _, _ = sample_bayesian(StubModel(), x, 6)
+        raw, mean, lp, lq = sample_bayesian(StubModel(), x, S, gather_raw=True)
+        raw_local, _, _, _ = sample_bayesian(StubModel(), x, S)
         q.put((rank, raw[0].numpy(), mean[0].numpy(), float(lp), float(lq), raw_local[0].numpy()))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_sharding_matches_single_process():
+def _run_ranks(world, S):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, S)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    return res
+
+
+def test_shard_span_partitions_the_samples():
+    from bayeformers_amd.sampling import shard_span
+
+    assert [shard_span(10, r, 8) for r in range(8)] == [(0, 2), (2, 2), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1), (9, 1)]
+    assert [shard_span(64, r, 8) for r in range(8)] == [(8 * r, 8) for r in range(8)]
+    for S, G in [(10, 3), (5, 8), (1, 4), (7, 7), (13, 5)]:
+        spans = [shard_span(S, r, G) for r in range(G)]
+        assert sum(c for _, c in spans) == S and spans[0][0] == 0
+        assert all(spans[r][0] + spans[r][1] == spans[r + 1][0] for r in range(G - 1))
+        assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_monte_carlo_span_checks_its_range():
+    m = StubModel()
+    with pytest.raises(ValueError):
+        with m.monte_carlo(3, span=(8, 10)):
+            pass
+    with m.monte_carlo(2, span=(8, 10)):
+        assert m._mc_span == (8, 10)
+    with m.monte_carlo(4, shard=(1, 2)):
+        assert m._mc_span == (4, 8)
+
+
+@pytest.mark.parametrize("world,S", [(3, 10), (3, 2)])
+def test_uneven_shards_match_single_process(world, S):
+    """S = 10 over 3 ranks (4, 3, 3 samples) — BASELINE config 5's `S = 10 on 8 GPUs` in small — and S = 2 over 3 ranks
+    (one rank idles): all-gathered per-sample outputs in global order, all-reduced means and log-probs equal to the
+    single-process run; the second step starts at global sample S on every rank."""
+    from bayeformers_amd.sampling import shard_span
+
+    res = _run_ranks(world, S)
+    torch.manual_seed(0)
+    x = torch.randn(4, 5)
+    logits, elp, elq = expected(x, S)
+    for rank, raw, mean, lp, lq, raw_local in res:
+        assert raw.shape[0] == S
+        np.testing.assert_allclose(raw, logits, rtol=1e-5)
+        np.testing.assert_allclose(mean, logits.mean(0), rtol=1e-5)
+        assert lp == pytest.approx(elp) and lq == pytest.approx(elq)
+        start, count = shard_span(S, rank, world)
+        assert raw_local.shape[0] == count
+        if count:
+            np.testing.assert_allclose(raw_local, expected(x, count, S + start)[0], rtol=1e-5)
+
+
+def test_two_rank_sharding_matches_single_process():
+    res = _run_ranks(2, 6)
     torch.manual_seed(0)
     x = torch.randn(4, 5)
     logits, elp, elq = expected(x, 6)

@@ -7,6 +7,7 @@
 // BF_BENCH_CONFIGS="1 2:0 2:1:32" lists the configurations to compare as variant[:schedule policy[:ablation bits]] (variant 0 = generic
 // 128x128 kernel, 1 = round-1 fixed-tile kernel, 2 = scheduled kernel).  Every configuration is checked against
 // variant 0, then all of them are timed in interleaved rounds in this one process; median and best are reported.
+// A fourth field selects the forward form (BF_GEMM_NT_FORM): "2:12:0:1" = scheduled kernel, policy 12, no ablation, five-slot ring.
 // BF_GEMM_ABLATE bits (dev build): 1 no DMA in the k-loop, 8 no epilogue, 16 no global stores, 64 L2-hot DMA.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -47,6 +48,7 @@ struct Config {
     int variant, policy;
     std::string name;
     int ablate = 0;
+    int form = -1;  // BF_GEMM_NT_FORM (0 burst, 1 five-slot ring, 2 ring with buffer loads); -1 = the library's default
 };
 
 static void select(const Config& c) {
@@ -57,6 +59,12 @@ static void select(const Config& c) {
     setenv("BF_GEMM_SCHED", v, 1);
     snprintf(v, sizeof v, "%d", c.ablate);
     setenv("BF_GEMM_ABLATE", v, 1);
+    if (c.form >= 0) {
+        snprintf(v, sizeof v, "%d", c.form);
+        setenv("BF_GEMM_NT_FORM", v, 1);
+    } else {
+        unsetenv("BF_GEMM_NT_FORM");
+    }
 }
 
 int main(int argc, char** argv) {
@@ -82,6 +90,8 @@ int main(int argc, char** argv) {
         size_t colon2 = colon == std::string::npos ? colon : tok.find(':', colon + 1);
         c.ablate = colon2 == std::string::npos ? (getenv("BF_GEMM_ABLATE") ? atoi(getenv("BF_GEMM_ABLATE")) : 0)
                                                : atoi(tok.c_str() + colon2 + 1);
+        size_t colon3 = colon2 == std::string::npos ? colon2 : tok.find(':', colon2 + 1);
+        if (colon3 != std::string::npos) c.form = atoi(tok.c_str() + colon3 + 1);
         c.name = "v" + tok;
         configs.push_back(c);
         p = q;
@@ -131,7 +141,7 @@ int main(int argc, char** argv) {
         select(Config{0, 0, "v0", 0});
         call(dy0);
         CK(hipDeviceSynchronize());
-        std::vector<uint16_t> h0(ny), h1(ny);
+        std::vector<uint16_t> h0(ny), h1(ny), hfirst;
         CK(hipMemcpy(h0.data(), dy0, ny * 2, hipMemcpyDeviceToHost));
         printf("L=%d S=%d M=%d N=%d K=%d act=%d |", L, S, M, N, K, act);
         for (const Config& c : configs) {
@@ -147,7 +157,12 @@ int main(int argc, char** argv) {
                 if (!(d <= 1e-2 * (1.0 + fabs((double)bf2f(h0[i]))))) ++bad;
                 if (d > maxd || d != d) maxd = d;
             }
-            printf(" %s maxdiff %.3g bad %zu |", c.name.c_str(), maxd, bad);
+            // the kernel forms accumulate in the same order: every configuration must agree with the first one bit for bit
+            size_t bits = 0;
+            if (hfirst.empty()) hfirst = h1;
+            else
+                for (size_t i = 0; i < ny; ++i) bits += hfirst[i] != h1[i];
+            printf(" %s maxdiff %.3g bad %zu bitdiff %zu |", c.name.c_str(), maxd, bad, bits);
         }
         printf("\n");
         std::vector<std::vector<double>> t(configs.size());
