@@ -76,7 +76,7 @@ SYMBOLS = {
                               ctypes.c_float, _vp]),
     "bf_add_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "bf_add_layernorm_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i64, _i, ctypes.c_float, _vp]),
-    "bf_embed_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i64, ctypes.c_float, _vp]),
+    "bf_embed_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _i64, _i64, _i64, _i64, ctypes.c_float, _vp]),
     "bf_add_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, ctypes.c_float, _vp]),
     "bf_profile_enable": (_i, [_i]),
     "bf_profile_reset": (_i, []),
@@ -85,6 +85,8 @@ SYMBOLS = {
 }
 BF_PROF_SAMPLE, BF_PROF_GEMM, BF_PROF_FUSED_SMALL, BF_PROF_FUSED_WS = 0, 1, 2, 3
 BF_ACT_NONE, BF_ACT_GELU = 0, 1
+
+ABI_VERSION = 2  # bf_version() of the library these bindings describe (include/bayeformers_amd.h: BF_VERSION_*)
 
 _lib = None
 
@@ -106,6 +108,10 @@ def lib():
             fn = getattr(l, name)  # AttributeError here = header/library drift
             fn.restype = res
             fn.argtypes = args
+        if l.bf_version() != ABI_VERSION:  # a stale .so called through newer signatures corrupts the stack: refuse it
+            raise BayeFormersAMDError(
+                f"{LIB_PATH} is version {l.bf_version()}, these bindings expect {ABI_VERSION}: rebuild it with "
+                "`python -m bayeformers_amd.build`")
         _lib = l
     return _lib
 

@@ -199,7 +199,8 @@ def fuse_embeddings(model: torch.nn.Module) -> int:
     `token_type_embeddings`, `position_embeddings`, `LayerNorm`, `dropout`) as ONE launch: three table gathers, two
     full-size adds and the LayerNorm of their result become bf_embed_layernorm.  Inference-time rewrite like the other
     fuse_* functions: with dropout active, gradients needed or unusual arguments the module's own forward runs.
-    Returns the number of blocks rewritten."""
+    Only blocks whose default positions are 0 .. L-1 (BERT, ELECTRA, ...) are rewritten; the RoBERTa family, which derives
+    position ids from the padding mask, keeps its own forward.  Returns the number of blocks rewritten."""
     fused = 0
     for m in model.modules():
         parts = [getattr(m, n, None) for n in ("word_embeddings", "token_type_embeddings", "position_embeddings")]
@@ -207,6 +208,9 @@ def fuse_embeddings(model: torch.nn.Module) -> int:
         if (all(isinstance(e, torch.nn.Embedding) for e in parts) and isinstance(ln, torch.nn.LayerNorm)
                 and isinstance(drop, torch.nn.Dropout) and ln.elementwise_affine and ln.bias is not None
                 and getattr(m, "position_embedding_type", "absolute") == "absolute"
+                # RoBERTa-style blocks (XLM-R, CamemBERT, ...) number positions from padding_idx + 1 and skip padding
+                # tokens (create_position_ids_from_input_ids): not the arange positions the kernel assumes — left alone
+                and not hasattr(m, "padding_idx") and not hasattr(m, "create_position_ids_from_input_ids")
                 and not hasattr(m, "_bf_plain_forward")):
             m._bf_plain_forward = m.forward
             m.forward = types.MethodType(_embeddings_forward, m)

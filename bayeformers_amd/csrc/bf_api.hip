@@ -377,10 +377,11 @@ int bf_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamm
 
 int bf_embed_layernorm(const int64_t* d_ids, const int64_t* d_type_ids, const int64_t* d_pos_ids, const void* d_word,
                        const void* d_type, const void* d_pos, const void* d_gamma, const void* d_beta, int param_dtype,
-                       void* d_out, int dtype, int64_t rows, int N, int seq_len, int64_t pos_rows, float eps, void* stream) {
+                       void* d_out, int dtype, int64_t rows, int N, int seq_len, int64_t pos_rows, int64_t word_rows,
+                       int64_t type_rows, int64_t pos_table_rows, float eps, void* stream) {
     return bf_launch_embed_layernorm((const long long*)d_ids, (const long long*)d_type_ids, (const long long*)d_pos_ids,
                                      d_word, d_type, d_pos, d_gamma, d_beta, param_dtype, d_out, dtype, rows, N, seq_len,
-                                     pos_rows, eps, (hipStream_t)stream);
+                                     pos_rows, word_rows, type_rows, pos_table_rows, eps, (hipStream_t)stream);
 }
 
 int bf_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,

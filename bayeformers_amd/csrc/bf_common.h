@@ -173,7 +173,8 @@ int bf_launch_add_layernorm(const void* d_x, const void* d_residual, const void*
 int bf_launch_embed_layernorm(const long long* d_ids, const long long* d_type_ids, const long long* d_pos_ids,
                               const void* d_word, const void* d_type, const void* d_pos, const void* d_gamma,
                               const void* d_beta, int param_dtype, void* d_out, int dtype, long long rows, int N,
-                              int seq_len, long long pos_rows, float eps, hipStream_t stream);
+                              int seq_len, long long pos_rows, long long word_rows, long long type_rows,
+                              long long pos_table_rows, float eps, hipStream_t stream);
 int bf_launch_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask,
                             const unsigned char* d_mask_off, void* d_out, float* d_lse, int dtype, int B, int T, int H,
                             int head_dim, long long token_stride, float scaling, hipStream_t stream);

@@ -84,6 +84,15 @@ __device__ __forceinline__ void init_acc(f32x4_t (&acc)[4][H], const float* bias
     }
 }
 
+// compile-time loop (immediate offsets for the inline-asm LDS reads)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 #ifndef BF_NT_STORES
 #define BF_NT_STORES 1
 #endif
@@ -200,15 +209,6 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
                 }
             }
         }
-    }
-}
-
-// compile-time loop (immediate offsets for the inline-asm LDS reads)
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
     }
 }
 

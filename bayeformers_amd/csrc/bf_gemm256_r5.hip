@@ -221,11 +221,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
             YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
             YT* y2 = p.y2 ? reinterpret_cast<YT*>(p.y2) + (long long)s * M * N : nullptr;
             int m_end = min(M, m0 + h * UNIT);
+            char* scratch = smem + sc * SLOT_BYTES + wid * 4096;
 #ifdef BF_DEV
             if (p.flags & 16) m_end = 0;  // ablation: no global stores
-            if (!(p.flags & 8))           // ablation: no epilogue
+            if (p.flags & 8) return;      // ablation: no epilogue
 #endif
-            epilogue_wave<YT, H>(smem + sc * SLOT_BYTES + wid * 4096, acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act);
+            epilogue_wave<YT, H>(scratch, acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act);
         };
         switch (h) {
             case 8: body(std::integral_constant<int, 8>{}); break;

@@ -355,14 +355,20 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void embed_layernorm_kernel(
     const long long* __restrict__ ids, const long long* __restrict__ type_ids, const long long* __restrict__ pos_ids,
     const T* __restrict__ word, const T* __restrict__ type, const T* __restrict__ pos, const GT* __restrict__ gamma,
     const GT* __restrict__ beta, T* __restrict__ out, long long rows, int N, int seq_len, long long pos_rows,
-    float eps) {
+    long long word_rows, long long type_rows, long long pos_table_rows, float eps) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nvec = N >> 3;
-    const T* wr = word + ids[row] * N;
-    const T* tr = type + (type_ids ? type_ids[row] : 0) * N;
-    const T* pr = pos + (pos_ids ? pos_ids[row % pos_rows] : row % seq_len) * N;
+    long long wi = ids[row], ti = type_ids ? type_ids[row] : 0, pi = pos_ids ? pos_ids[row % pos_rows] : row % seq_len;
+    // an id outside its table: read row 0 instead and poison the output row (NaN) — never an out-of-bounds access
+    const bool bad = (unsigned long long)wi >= (unsigned long long)word_rows ||
+                     (unsigned long long)ti >= (unsigned long long)type_rows ||
+                     (unsigned long long)pi >= (unsigned long long)pos_table_rows;
+    if (bad) wi = ti = pi = 0;
+    const T* wr = word + wi * N;
+    const T* tr = type + ti * N;
+    const T* pr = pos + pi * N;
     float v[VPL][8];
     float sum = 0.f;
 #pragma unroll
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void embed_layernorm_kernel(
             }
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_n + eps);
+    const float rstd = bad ? __builtin_nanf("") : 1.0f / sqrtf(wave_sum(sq) * inv_n + eps);
     T* orow = out + row * N;
 #pragma unroll
     for (int c = 0; c < VPL; ++c) {
@@ -412,13 +418,14 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void embed_layernorm_kernel(
 template <typename T, typename GT>
 int launch_embed(const long long* ids, const long long* type_ids, const long long* pos_ids, const void* word,
                  const void* type, const void* pos, const void* gamma, const void* beta, void* out, long long rows, int N,
-                 int seq_len, long long pos_rows, float eps, hipStream_t stream) {
+                 int seq_len, long long pos_rows, long long word_rows, long long type_rows, long long pos_table_rows,
+                 float eps, hipStream_t stream) {
     const dim3 grid((unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock)), block(64 * kRowsPerBlock);
     const int nvec = N / 8;
 #define BF_EMB(V)                                                                                                      \
     hipLaunchKernelGGL((embed_layernorm_kernel<T, GT, V>), grid, block, 0, stream, ids, type_ids, pos_ids,              \
                        (const T*)word, (const T*)type, (const T*)pos, (const GT*)gamma, (const GT*)beta, (T*)out, rows, \
-                       N, seq_len, pos_rows, eps)
+                       N, seq_len, pos_rows, word_rows, type_rows, pos_table_rows, eps)
     if (nvec <= 64) BF_EMB(1);
     else if (nvec <= 128) BF_EMB(2);
     else if (nvec <= 256) BF_EMB(4);
@@ -452,7 +459,12 @@ int bf_launch_add_layernorm(const void* d_x, const void* d_residual, const void*
 int bf_launch_embed_layernorm(const long long* d_ids, const long long* d_type_ids, const long long* d_pos_ids,
                               const void* d_word, const void* d_type, const void* d_pos, const void* d_gamma,
                               const void* d_beta, int param_dtype, void* d_out, int dtype, long long rows, int N,
-                              int seq_len, long long pos_rows, float eps, hipStream_t stream) {
+                              int seq_len, long long pos_rows, long long word_rows, long long type_rows,
+                              long long pos_table_rows, float eps, hipStream_t stream) {
+    if (word_rows < 1 || type_rows < 1 || pos_table_rows < 1)
+        BF_FAIL("bf_embed_layernorm: empty table (%lld / %lld / %lld rows)", word_rows, type_rows, pos_table_rows);
+    if (!d_pos_ids && seq_len > pos_table_rows)
+        BF_FAIL("bf_embed_layernorm: seq_len=%d exceeds the position table (%lld rows)", seq_len, pos_table_rows);
     if (rows < 0 || N <= 0 || seq_len < 1) BF_FAIL("bf_embed_layernorm: bad shape rows=%lld N=%d seq_len=%d", rows, N, seq_len);
     if (rows == 0) return 0;
     if (!d_ids || !d_word || !d_type || !d_pos || !d_gamma || !d_beta || !d_out) BF_FAIL("bf_embed_layernorm: null pointer");
@@ -465,9 +477,9 @@ int bf_launch_embed_layernorm(const long long* d_ids, const long long* d_type_id
     const bool pf = param_dtype == BF_DT_F32;
 #define BF_EMB_T(T)                                                                                                     \
     return pf ? launch_embed<T, float>(d_ids, d_type_ids, d_pos_ids, d_word, d_type, d_pos, d_gamma, d_beta, d_out, rows, N, \
-                                       seq_len, pos_rows, eps, stream)                                                     \
+                                       seq_len, pos_rows, word_rows, type_rows, pos_table_rows, eps, stream)               \
               : launch_embed<T, T>(d_ids, d_type_ids, d_pos_ids, d_word, d_type, d_pos, d_gamma, d_beta, d_out, rows, N,    \
-                                   seq_len, pos_rows, eps, stream)
+                                   seq_len, pos_rows, word_rows, type_rows, pos_table_rows, eps, stream)
     switch (dtype) {
         case BF_DT_BF16: BF_EMB_T(__bf16);
         case BF_DT_F16: BF_EMB_T(_Float16);

@@ -426,7 +426,8 @@ def add_layernorm(x: Tensor, residual: Optional[Tensor], gamma: Tensor, beta: Te
 def embed_layernorm(ids: Tensor, type_ids: Optional[Tensor], pos_ids: Optional[Tensor], word: Tensor, type_table: Tensor,
                     pos_table: Tensor, gamma: Tensor, beta: Tensor, eps: float) -> Tensor:
     """LayerNorm(word[ids] + type[type_ids or 0] + pos[pos_ids or position in sequence]) in one pass
-    (bf_embed_layernorm).  ids: [B, L] int64; type_ids: [B, L] or None; pos_ids: [1 or B, L] or None; returns [B, L, N]."""
+    (bf_embed_layernorm).  ids: [B, L] int64; type_ids: [B, L] or None; pos_ids: [1 or B, L] or None; returns [B, L, N].
+    An id outside its table gives a NaN output row (no out-of-bounds read)."""
     _require_device(ids, "embed_layernorm ids")
     B, L = ids.shape
     N = word.shape[1]
@@ -441,7 +442,8 @@ def embed_layernorm(ids: Tensor, type_ids: Optional[Tensor], pos_ids: Optional[T
     ptr = lambda t: t.data_ptr() if t is not None else None
     _C.check(_C.lib().bf_embed_layernorm(ids.data_ptr(), ptr(type_ids), ptr(pos_ids), word.data_ptr(), type_table.data_ptr(),
                                          pos_table.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _TORCH2BF[gamma.dtype],
-                                         out.data_ptr(), _TORCH2BF[word.dtype], B * L, N, L, pos_rows, float(eps),
+                                         out.data_ptr(), _TORCH2BF[word.dtype], B * L, N, L, pos_rows, word.shape[0],
+                                         type_table.shape[0], pos_table.shape[0], float(eps),
                                          _stream_ptr()), "bf_embed_layernorm")
     return out
 

@@ -72,6 +72,19 @@ def _default_select(out):
     raise TypeError("sample_bayesian: pass select= to pick the output tensor(s) of the model")
 
 
+def _all_reduce_sum(t: Tensor, group) -> Tensor:
+    """Sum over the ranks of the S-shard group.  With gradients recorded the result keeps THIS rank's part of the sum in
+    the autograd graph (value = the global sum; d/d(local) = 1): a loss built on the all-reduced means then sends each
+    rank the gradient of its own samples, and summing the ranks' parameter gradients (training.GradientBuckets) gives
+    the gradient of the single-process step."""
+    if torch.is_grad_enabled() and t.requires_grad:
+        total = t.detach().clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        return t + (total - t.detach())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def shard_span(samples: int, rank: int, world: int) -> Tuple[int, int]:
     """(first global sample index, number of samples) of rank `rank` when `samples` Monte-Carlo samples are sharded
     over `world` ranks: contiguous slices whose sizes differ by at most one (S = 10 over 8 GPUs: 2, 2, 1, 1, 1, 1, 1, 1 —
@@ -135,14 +148,14 @@ def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callabl
     if one_buffer:
         packed = torch.cat(sums + [lp.sum(0)])
         if distributed:
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+            packed = _all_reduce_sum(packed, group)
         packed = packed / samples
         out_part, lp_part = packed[:n_out], packed[n_out:]
     else:
         out_part, lp_part = torch.cat(sums) if len(sums) > 1 else sums[0], lp.sum(0)
         if distributed:
-            dist.all_reduce(out_part, op=dist.ReduceOp.SUM, group=group)
-            dist.all_reduce(lp_part, op=dist.ReduceOp.SUM, group=group)
+            out_part = _all_reduce_sum(out_part, group)
+            lp_part = _all_reduce_sum(lp_part, group)
         out_part, lp_part = out_part / samples, lp_part / samples
     means, off = [], 0
     for r, n in zip(raw, sizes):

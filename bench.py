@@ -57,6 +57,12 @@ def parse():
     return ap.parse_args()
 
 
+def _world() -> int:
+    """Ranks of the S-shard group.  Weak scaling: S is the number of Monte-Carlo samples PER GPU, a step draws S * world
+    samples and sample_bayesian hands every rank its S of them."""
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 class Workload:
     """name, S (per GPU), dtype, step() -> python float (the ELBO), config dict, cpu_baseline() -> dict."""
 
@@ -98,7 +104,7 @@ def make_bert(device, S, dtype, train=False):
 
     def step():
         with torch.no_grad():
-            raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S)
+            raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S * _world())
             nll = torch.nn.functional.cross_entropy(mean[0].float(), labels_d)
             return elbo(lp, lq, nll.double(), n_batches)
 
@@ -107,16 +113,19 @@ def make_bert(device, S, dtype, train=False):
         # every sampled-weight layer (eps regenerated from the Philox counter), Adam on the unfrozen parameters
         # (examples/bert_glue.py:215 uses transformers' AdamW(lr, eps) with its default weight_decay = 0: torch's AdamW
         # with weight_decay = 0 is the same update; fused = one multi-tensor kernel for all 85 parameter tensors)
-        opt = torch.optim.AdamW([p for p in bmodel.parameters() if p.requires_grad], lr=2e-5, eps=1e-8,
-                                weight_decay=0.0, fused=True)
+        from bayeformers_amd.training import GradientBuckets, training_step
+
+        params = [p for p in bmodel.parameters() if p.requires_grad]
+        opt = torch.optim.AdamW(params, lr=2e-5, eps=1e-8, weight_decay=0.0, fused=True)
+        # flat gradient buffers: all-reduced over the ranks while backward runs (world > 1), clipped in a few launches
+        buckets = GradientBuckets(params)
+
+        def nll_fn(mean):
+            return torch.nn.functional.cross_entropy(mean[0].float(), labels_d)
 
         def step():  # noqa: F811
-            opt.zero_grad(set_to_none=True)
-            raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S)
-            loss = elbo(lp, lq, torch.nn.functional.cross_entropy(mean[0].float(), labels_d).double(), n_batches)
-            loss.backward()
-            opt.step()
-            return loss.detach()
+            # examples/bert_glue.py:227-241: forward, ELBO, backward, clip_grad_norm_(1), optimizer step
+            return training_step(bmodel, inputs, S * _world(), nll_fn, opt, n_batches, buckets=buckets, max_grad_norm=1.0)
 
     def cpu_baseline():
         from oracle.model_oracle import log_probs, to_oracle
@@ -137,7 +146,7 @@ def make_bert(device, S, dtype, train=False):
                           f"torch-CPU fp32, {dt:.1f}s"}
 
     cfgd = {"workload": "to_bayesian(BERT-base seq-cls, delta=0.05, freeze=True) " +
-                        ("training step: fwd+ELBO+backward+AdamW" if train else "fwd+ELBO"), "samples_per_gpu": S,
+                        ("training step: fwd+ELBO+backward+clip+AdamW, dropout off" if train else "fwd+ELBO"), "samples_per_gpu": S,
             "batch": B, "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "bayesian_scalars": 85609730}
     cfgd.update(info)
     return step, cpu_baseline, cfgd, bmodel
@@ -168,7 +177,7 @@ def make_bert_large_qa(device, S, dtype):
 
     def step():
         with torch.no_grad():
-            raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S)
+            raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S * _world())
             ce = torch.nn.functional.cross_entropy
             nll = 0.5 * (ce(mean[0].float(), sp) + ce(mean[1].float(), ep))  # examples/bert_squad.py:474-481
             return elbo(lp, lq, nll.double(), n_batches)
@@ -209,7 +218,7 @@ def make_linear(device, S, dtype, M):
 
     def step():
         with torch.no_grad():
-            raw, mean, lp, lq = sample_bayesian(model, xd, S)
+            raw, mean, lp, lq = sample_bayesian(model, xd, S * _world())
             nll = torch.nn.functional.cross_entropy(mean[0].float(), tgt)
             return elbo(lp, lq, nll.double(), 100)
 
@@ -247,7 +256,7 @@ def make_mlp(device, S, dtype):
 
     def step():
         with torch.no_grad():
-            raw, mean, lp, lq = sample_bayesian(bmodel, xd, S)
+            raw, mean, lp, lq = sample_bayesian(bmodel, xd, S * _world())
             nll = torch.nn.functional.nll_loss(mean[0], labels, reduction="sum")
             return elbo(lp, lq, nll.double(), 469)
 
@@ -328,7 +337,7 @@ def measure_traffic(args):
             vals = []
             for f in files:
                 for r in csv.DictReader(open(f)):
-                    if "gemm256_sched" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    if ("gemm256_ring5" in r["Kernel_Name"] or "gemm256_sched" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
                         vals.append(float(r["Counter_Value"]))
             if not vals:
                 return None
@@ -341,14 +350,39 @@ def measure_traffic(args):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def visible_gpus():
+    """Number of GPUs the ranks will see, WITHOUT touching the HIP runtime: the KFD topology in sysfs lists every node
+    (CPUs have simd_count 0), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  None if sysfs has no KFD
+    topology (no amdgpu driver): the ranks then find out themselves."""
+    import glob
+
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for path in nodes:
+        try:
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        except (OSError, ValueError):
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip()]))
+    return n
+
+
 def launch_ranks(args) -> int:
     """--gpus N without a torch.distributed environment: run the N ranks as a CHILD process tree (one rank per GPU,
-    torch.distributed.run) and relay its output.  This process does not initialise a GPU — it only counts them."""
+    torch.distributed.run) and relay its output.  This process never initialises a GPU: it counts them in sysfs."""
     import socket
     import subprocess
 
-    if not args.dry_run and torch.cuda.device_count() < args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
+    have = visible_gpus()
+    if not args.dry_run and have is not None and have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
@@ -418,8 +452,6 @@ def main():
     if args.workload == "bert_base":
         step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype)
     elif args.workload == "bert_base_train":
-        if world > 1:
-            raise SystemExit("bert_base_train is a single-GPU workload (no gradient all-reduce in this bench)")
         step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype, train=True)
     elif args.workload == "bert_large_qa":
         step, cpu_baseline, cfgd, bmodel = make_bert_large_qa(device, S, dtype)
@@ -526,7 +558,7 @@ def main():
             gn, gms, gflop = fn, fms, fflop
             kernel, bound, fused = fused["kernel"], "latency", None
         else:
-            kernel = "gemm256_sched_kernel (sampled-weight GEMM; mean over the step's tiled-GEMM launches)"
+            kernel = "gemm256_ring5_kernel (sampled-weight GEMM, five-slot LDS ring; mean over the step's tiled-GEMM launches)"
             bound = "mfma"
         tflops = gflop / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
         roofline = {"bound": bound, "kernel": kernel,

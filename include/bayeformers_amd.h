@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 #define BF_VERSION_MAJOR 0
-#define BF_VERSION_MINOR 1
+#define BF_VERSION_MINOR 2  /* 2: bf_embed_layernorm takes the table row counts */
 
 /* element types of activations / sampled weights */
 enum { BF_DT_F32 = 0, BF_DT_BF16 = 1, BF_DT_F16 = 2 };
@@ -247,10 +247,14 @@ int bf_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamm
 /* The embedding block that feeds the first Bayesian layers of a converted transformer (HF BertEmbeddings, called
  * ahead of bnn.Linear.forward, bayeformers/nn/layers/linear.py:83-104), in one pass:
  *   out[r] = LayerNorm(word[ids[r]] + type[type_ids ? type_ids[r] : 0] + pos[pos_ids ? pos_ids[r % pos_rows] : r % seq_len])
- * tables [*, N] and out [rows, N] of `dtype`; gamma/beta fp32 or `dtype`; ids int64 [rows].  Sum and statistics in fp32. */
+ * tables [*, N] and out [rows, N] of `dtype`; gamma/beta fp32 or `dtype`; ids int64 [rows].  Sum and statistics in fp32.
+ * word_rows / type_rows / pos_table_rows = the number of rows of the three tables: an id outside its table reads nothing
+ * and makes its output row NaN (torch.nn.functional.embedding asserts on the device instead).  seq_len must not exceed
+ * pos_table_rows when d_pos_ids is NULL. */
 int bf_embed_layernorm(const int64_t* d_ids, const int64_t* d_type_ids, const int64_t* d_pos_ids, const void* d_word,
                        const void* d_type, const void* d_pos, const void* d_gamma, const void* d_beta, int param_dtype,
-                       void* d_out, int dtype, int64_t rows, int N, int seq_len, int64_t pos_rows, float eps, void* stream);
+                       void* d_out, int dtype, int64_t rows, int N, int seq_len, int64_t pos_rows, int64_t word_rows,
+                       int64_t type_rows, int64_t pos_table_rows, float eps, void* stream);
 
 /* Backward of bf_add_layernorm.  z = x + residual and its row statistics are recomputed from the forward's inputs;
  * d_dz [rows, N] of `dtype` is the gradient of BOTH x and residual; d_dgamma / d_dbeta are fp32 [N], written (not

@@ -379,26 +379,15 @@ def test_stacked_qkv_training_matches_per_layer_autograd(monkeypatch):
         assert torch.allclose(g0[n], g1[n], rtol=1e-5, atol=1e-6 * g0[n].abs().max().item()), n
 
 
-@pytest.mark.parametrize("dtype,fused,tol,tol_vec", [("fp32", False, 1e-4, 1e-4), ("fp32", True, 1e-4, 1e-4),
-                                                     ("bf16", True, 5e-2, 1.5e-1)])
-def test_training_step_gradients_match_reference_bert_tiny(golden_dir, dtype, fused, tol, tol_vec):
-    """One training step of the REAL reference on the tiny BERT (tests/golden/bert_tiny_train.npz, generated by
-    make_golden.py:bert_train_case = examples/bert_glue.py:63-66, 234-239 with dropout off): the gradient of every
-    trainable tensor.  `fused` = the rewrites bench.py's training step runs on (GELU in the GEMM epilogue with its
-    backward, residual+LayerNorm, q/k/v as one autograd node, the attention kernels, the embedding block).
-    Tolerances, per tensor stored in full: weight matrices max |g - g_ref| <= tol * max |g_ref| (fp32 1e-4, measured
-    <= 2e-5; bf16 activations end to end 5e-2, measured <= 2.6e-2); bias vectors |g - g_ref|_2 <= tol_vec * |g_ref|_2
-    (bf16 1.5e-1: the query bias of the first layer, a sum over 16-bit rounded rows behind the softmax backward's
-    cancellation, measures 9e-2; all others <= 1e-2); every other tensor: sum |g| within 2 tol_vec."""
+def _tiny_train_setup(golden_dir, dtype, fused):
+    """The tiny BERT of tests/golden/bert_tiny_train.npz, converted and (optionally) rewritten as bench.py's training step."""
     from transformers import BertConfig, BertForSequenceClassification
-
-    from bayeformers_amd.sampling import elbo, sample_bayesian
 
     def checksum(module):
         return float(sum(p.detach().double().abs().sum() for p in module.parameters()))
 
     g = np.load(f"{golden_dir}/bert_tiny_train.npz")
-    S, B, L, NB = int(g["S"]), int(g["B"]), int(g["L"]), int(g["n_batches"])
+    B, L = int(g["B"]), int(g["L"])
     cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
                      vocab_size=1000, max_position_embeddings=64)
     torch.manual_seed(0)
@@ -417,18 +406,11 @@ def test_training_step_gradients_match_reference_bert_tiny(golden_dir, dtype, fu
     if fused:
         assert bf.fuse_activations(bmodel) == 2 and bf.fuse_residual_layernorm(bmodel) == 4
         assert bf.fuse_shared_inputs(bmodel) == 2 and bf.fuse_attention(bmodel) and bf.fuse_embeddings(bmodel) == 1
-    bf.manual_seed(SEED)
-    bf.set_compute_dtype(dtype)
-    try:
-        inputs = {"input_ids": ids.cuda(), "attention_mask": mask.cuda()}
-        raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S)
-        nll = torch.nn.functional.cross_entropy(mean[0].float(), labels.cuda())
-        loss = elbo(lp, lq, nll.double(), NB)
-        loss.backward()
-    finally:
-        bf.set_compute_dtype("bf16")
-    assert np.abs(raw[0].detach().float().cpu().numpy() - g["logits"]).max() < max(tol, 2e-4) * max(1.0, np.abs(g["logits"]).max())
-    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=1e-3)
+    inputs = {"input_ids": ids.cuda(), "attention_mask": mask.cuda()}
+    return g, bmodel, params, inputs, labels.cuda()
+
+
+def _check_tiny_train_grads(g, params, tol, tol_vec):
     names = [str(n) for n in g["names"]]
     assert sorted(names) == sorted(n for n, p in params.items() if p.grad is not None)
     worst = {}
@@ -449,3 +431,135 @@ def test_training_step_gradients_match_reference_bert_tiny(golden_dir, dtype, fu
             worst[n] = err / (tol if ref.ndim == 2 else tol_vec)
     assert len(worst) == 14
     assert all(e <= 1.0 for e in worst.values()), worst
+
+
+@pytest.mark.parametrize("dtype,fused,tol,tol_vec", [("fp32", False, 1e-4, 1e-4), ("fp32", True, 1e-4, 1e-4),
+                                                     ("bf16", True, 5e-2, 1.5e-1)])
+def test_training_step_gradients_match_reference_bert_tiny(golden_dir, dtype, fused, tol, tol_vec):
+    """One training step of the REAL reference on the tiny BERT (tests/golden/bert_tiny_train.npz, generated by
+    make_golden.py:bert_train_case = examples/bert_glue.py:63-66, 234-239 with dropout off): the gradient of every
+    trainable tensor.  `fused` = the rewrites bench.py's training step runs on (GELU in the GEMM epilogue with its
+    backward, residual+LayerNorm, q/k/v as one autograd node, the attention kernels, the embedding block).
+    Tolerances, per tensor stored in full: weight matrices max |g - g_ref| <= tol * max |g_ref| (fp32 1e-4, measured
+    <= 2e-5; bf16 activations end to end 5e-2, measured <= 2.6e-2); bias vectors |g - g_ref|_2 <= tol_vec * |g_ref|_2
+    (bf16 1.5e-1: the query bias of the first layer, a sum over 16-bit rounded rows behind the softmax backward's
+    cancellation, measures 9e-2; all others <= 1e-2); every other tensor: sum |g| within 2 tol_vec."""
+    from bayeformers_amd.sampling import elbo, sample_bayesian
+
+    g, bmodel, params, inputs, labels = _tiny_train_setup(golden_dir, dtype, fused)
+    S, NB = int(g["S"]), int(g["n_batches"])
+    bf.manual_seed(SEED)
+    bf.set_compute_dtype(dtype)
+    try:
+        raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S)
+        nll = torch.nn.functional.cross_entropy(mean[0].float(), labels)
+        loss = elbo(lp, lq, nll.double(), NB)
+        loss.backward()
+    finally:
+        bf.set_compute_dtype("bf16")
+    assert np.abs(raw[0].detach().float().cpu().numpy() - g["logits"]).max() < max(tol, 2e-4) * max(1.0, np.abs(g["logits"]).max())
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=1e-3)
+    _check_tiny_train_grads(g, params, tol, tol_vec)
+
+
+@pytest.mark.parametrize("dtype,tol,tol_vec", [("fp32", 1e-4, 1e-4), ("bf16", 5e-2, 1.5e-1)])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_training_step_gradients_match_reference_bert_tiny(golden_dir, dtype, tol, tol_vec, world):
+    """The S-sharded training step (bayeformers_amd.training) against the reference's single-process gradients: the
+    shards of `world` ranks run here one after the other on one GPU, each exactly as its rank would — forward of its
+    own samples (`monte_carlo(count, span=(start, S))`), the loss on the all-reduced mean logits with only the local part
+    in the autograd graph (what sampling._all_reduce_sum builds), backward — and their gradients are SUMMED, which is
+    what GradientBuckets' all-reduce does.  The sum must be the gradient of examples/bert_glue.py:234-239."""
+    from bayeformers_amd.sampling import elbo, repeat_inputs, shard_span
+
+    g, bmodel, params, inputs, labels = _tiny_train_setup(golden_dir, dtype, True)
+    S, NB, B = int(g["S"]), int(g["n_batches"]), int(g["B"])
+    spans = [shard_span(S, r, world) for r in range(world)]
+    assert sum(c for _, c in spans) == S and all(c > 0 for _, c in spans)
+    bf.set_compute_dtype(dtype)
+    try:
+        def forward(start, count):
+            bf.manual_seed(SEED)  # every rank starts the step from the same global sample counter
+            with bmodel.monte_carlo(count, span=(start, S)):
+                out = bmodel(**repeat_inputs(inputs, count))
+            return out.logits.reshape(count, B, -1), bmodel.log_prob_samples().sum(0)
+
+        with torch.no_grad():  # what the all-reduce delivers: the sums over all ranks
+            parts = [forward(st, c) for st, c in spans]
+            total = sum(p[0].double().sum(0) for p in parts)
+            lp_total = sum(p[1] for p in parts) / S
+        for st, c in spans:
+            logits, _ = forward(st, c)
+            local = logits.double().sum(0)
+            mean = ((local + (total - local.detach())) / S).to(logits.dtype)
+            nll = torch.nn.functional.cross_entropy(mean.float(), labels)
+            loss = elbo(lp_total[0], lp_total[1], nll.double(), NB)
+            loss.backward()  # accumulates into .grad: the sum over the ranks
+    finally:
+        bf.set_compute_dtype("bf16")
+    assert float(loss.detach()) == pytest.approx(float(g["loss"]), rel=1e-3)
+    _check_tiny_train_grads(g, params, tol, tol_vec)
+
+
+@pytest.mark.parametrize("device_counter", [False, True])
+def test_checkpointed_blocks_recompute_the_forwards_epsilon(device_counter):
+    """torch.utils.checkpoint re-runs a block's forward DURING backward, outside any bnn.Model forward.  The Bayesian
+    layers inside must then draw the epsilon of the forward they repeat (bayeformers_amd.random.recompute_context) —
+    the same sample indices, also with the device-resident counter, which has moved on by then: outputs, log-probs and
+    every gradient equal those of the run without checkpointing."""
+    from torch.utils.checkpoint import checkpoint
+
+    class Block(torch.nn.Module):
+        def __init__(self, d):
+            super().__init__()
+            self.a, self.b = torch.nn.Linear(d, 2 * d), torch.nn.Linear(2 * d, d)
+
+        def forward(self, x):
+            return x + self.b(torch.nn.functional.gelu(self.a(x)))
+
+    class Net(torch.nn.Module):
+        def __init__(self, d, ckpt):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList([Block(d) for _ in range(3)])
+            self.head = torch.nn.Linear(d, 4)
+            self.ckpt = ckpt
+
+        def forward(self, x):
+            for blk in self.blocks:
+                x = checkpoint(blk, x, use_reentrant=False) if self.ckpt else blk(x)
+            return self.head(x)
+
+    d, S, B = 128, 3, 80   # 80 rows per sample: the planned (cross-layer sampled) path; the head (N = 4) runs on its own
+    torch.manual_seed(0)
+    net = Net(d, False)
+    bmodel = bf.to_bayesian(net, delta=0.05).cuda()
+    x = torch.randn(B, d, device="cuda")
+    target = torch.randn(S * B, 4, device="cuda")
+
+    def run(ckpt):
+        net_b = bmodel.model
+        net_b.ckpt = ckpt
+        for p in bmodel.parameters():
+            p.grad = None
+        bf.manual_seed(SEED, next_sample=7)
+        with bmodel.monte_carlo(S):
+            out = bmodel(x.repeat(S, 1))
+        lps = bmodel.log_prob_samples().clone()
+        # a second forward between forward and backward would move a host-side counter; the device counter has moved anyway
+        ((out - target) ** 2).mean().backward()
+        grads = {n: p.grad.clone() for n, p in bmodel.named_parameters() if p.grad is not None}
+        return out.detach().clone(), lps, grads
+
+    if device_counter:
+        bf.use_device_counter(True)
+    try:
+        out0, lp0, g0 = run(False)
+        out1, lp1, g1 = run(True)
+    finally:
+        if device_counter:
+            bf.use_device_counter(False)
+    assert torch.equal(out0, out1) and torch.equal(lp0, lp1)
+    assert g0.keys() == g1.keys() and len(g0) >= 14
+    for n in g0:
+        scale = g0[n].abs().max().item() + 1e-30
+        assert (g0[n] - g1[n]).abs().max().item() <= 1e-6 * scale, n

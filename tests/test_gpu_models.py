@@ -206,6 +206,48 @@ def test_fused_embeddings_match_the_module(dtype, tol):
         assert torch.equal(emb(inputs_embeds=e), emb._bf_plain_forward(inputs_embeds=e))
 
 
+def test_fused_embeddings_poison_out_of_range_ids():
+    """An id outside its table must not read out of bounds: bf_embed_layernorm makes that token's output row NaN (where
+    torch.nn.functional.embedding asserts on the device) and leaves every other row exact."""
+    cfg, model = _bert(True)
+    emb = model.bert.embeddings.cuda().eval()
+    torch.manual_seed(12)
+    ids = torch.randint(0, cfg.vocab_size, (3, 16)).cuda()
+    with torch.no_grad():
+        assert bf.fuse_embeddings(model) == 1
+        ref = emb(input_ids=ids)        # the kernel on the clean ids
+        bad = ids.clone()
+        bad[1, 5] = cfg.vocab_size      # one past the table
+        bad[2, 0] = -1
+        out = emb(input_ids=bad)
+        tt = torch.zeros_like(ids)
+        tt[0, 3] = cfg.type_vocab_size
+        out_t = emb(input_ids=ids, token_type_ids=tt)
+    nan_rows = torch.isnan(out).all(-1)
+    assert nan_rows[1, 5] and nan_rows[2, 0] and int(nan_rows.sum()) == 2
+    ok = ~nan_rows
+    assert torch.equal(out[ok], ref[ok])
+    nt = torch.isnan(out_t).all(-1)
+    assert nt[0, 3] and int(nt.sum()) == 1
+
+
+def test_fuse_embeddings_leaves_roberta_blocks_alone():
+    """RoBERTa-style embedding blocks derive position ids from the padding mask (padding_idx + 1 + cumsum): the one-launch
+    rewrite assumes positions 0 .. L-1, so fuse_embeddings must not touch them — and the model's outputs stay its own."""
+    from transformers import RobertaConfig, RobertaModel
+
+    cfg = RobertaConfig(hidden_size=64, num_hidden_layers=1, num_attention_heads=2, intermediate_size=128,
+                        vocab_size=200, max_position_embeddings=40)
+    torch.manual_seed(0)
+    model = RobertaModel(cfg).cuda().eval()
+    ids = torch.randint(3, 200, (2, 12)).cuda()
+    ids[0, 8:] = cfg.pad_token_id
+    with torch.no_grad():
+        ref = model.embeddings(input_ids=ids)
+        assert bf.fuse_embeddings(model) == 0
+        assert torch.equal(model.embeddings(input_ids=ids), ref)
+
+
 def test_training_embeddings_run_on_one_copy_of_the_batch():
     """With gradients the rewritten embedding block runs the module's own forward on ONE copy of sample_bayesian's S-fold
     repeated ids and repeats the result: same outputs, same table / LayerNorm gradients as on the repeated batch."""

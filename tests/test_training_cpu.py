@@ -1,0 +1,117 @@
+"""The S-sharded training step (bayeformers_amd.training) on CPU: gloo, world sizes 2 and 3.  The HIP forward is replaced
+by a differentiable stub whose per-sample weights are a pure function of the GLOBAL sample index — the property the
+Philox contract gives the real kernels — so the ranks' summed gradients must equal the single-process gradients."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import bayeformers_amd.nn as bnn
+from bayeformers_amd import random as bfr
+from bayeformers_amd.training import GradientBuckets, clip_grad_norm_, training_step
+
+
+class NoisyNet(bnn.Model):
+    """y_s = x (W * (1 + 0.3 sin(global sample index + k))) + b: a 'sampled' weight per Monte-Carlo sample."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(3)
+        self.w = torch.nn.Parameter(torch.randn(5, 3, generator=g))
+        self.b = torch.nn.Parameter(torch.randn(3, generator=g))
+        self.unused = torch.nn.Parameter(torch.ones(2))  # never receives a gradient: its bucket is sent by finish()
+
+    def forward(self, x):
+        ctx = bfr.STATE.ctx
+        S, base = ctx.S, ctx.sample_base
+        B = x.shape[0] // S
+        idx = base + torch.arange(S, dtype=torch.float32)
+        scale = 1.0 + 0.3 * torch.sin(idx[:, None, None] + torch.arange(3, dtype=torch.float32)[None, None, :])
+        y = torch.einsum("sbi,sio->sbo", x.view(S, B, 5), self.w[None] * scale) + self.b
+        self._lp_buf = torch.stack([-(idx.double() ** 2), 2.0 * idx.double()], dim=1)[None]
+        return y.reshape(S * B, 3)
+
+
+def _run(S, steps, group_used):
+    torch.manual_seed(0)
+    x = torch.randn(4, 5)
+    labels = torch.tensor([0, 2, 1, 1])
+    model = NoisyNet()
+    params = list(model.parameters())
+    opt = torch.optim.SGD(params, lr=0.5)
+    buckets = GradientBuckets(params, bucket_bytes=32)  # tiny buckets: w alone, b + unused together
+    bfr.manual_seed(11)
+    grads = None
+    for _ in range(steps):
+        loss = training_step(model, x, S, lambda mean: torch.nn.functional.cross_entropy(mean[0], labels), opt, n_batches=7,
+                             buckets=buckets, max_grad_norm=0.05)
+        if grads is None:
+            grads = [p.grad.clone() for p in (model.w, model.b)]
+    return float(loss), [g.numpy() for g in grads], [p.detach().numpy().copy() for p in (model.w, model.b)]
+
+
+def _worker(rank, world, port, q, S, steps):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank,) + _run(S, steps, True))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_buckets_and_clip_single_process():
+    torch.manual_seed(1)
+    ps = [torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2))]
+    buckets = GradientBuckets(ps, bucket_bytes=64)
+    assert len(buckets.buckets) == 2  # reverse order: [2x2 + 5] (36 B), then [7x3] (84 B, alone)
+    buckets.zero()
+    loss = (ps[0] ** 2).sum() + (3 * ps[1]).sum() + ps[2].sum()
+    loss.backward()
+    buckets.finish()
+    for p in ps:
+        assert p.grad.data_ptr() == buckets._views[p].data_ptr()
+    np.testing.assert_allclose(ps[0].grad.numpy(), 2 * ps[0].detach().numpy(), rtol=1e-6)
+    ref = [p.grad.clone() for p in ps]
+    want = torch.nn.utils.clip_grad_norm_([torch.nn.Parameter(p.detach().clone()) for p in ps], 1.0)  # norm of params: unused
+    total = clip_grad_norm_(buckets, 0.5)
+    tn = torch.sqrt(sum((g ** 2).sum() for g in ref))
+    assert float(total) == pytest.approx(float(tn), rel=1e-6)
+    for p, g in zip(ps, ref):
+        np.testing.assert_allclose(p.grad.numpy(), (g * min(1.0, 0.5 / (float(tn) + 1e-6))).numpy(), rtol=1e-6)
+    # a second step accumulates from zero again, gradients set to None by an optimizer are re-attached
+    ps[1].grad = None
+    buckets.zero()
+    (ps[1] * 2).sum().backward()
+    buckets.finish()
+    assert ps[1].grad.data_ptr() == buckets._views[ps[1]].data_ptr() and float(ps[1].grad.sum()) == 10.0
+    assert float(ps[0].grad.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("world,S", [(2, 6), (3, 10)])
+def test_sharded_training_step_matches_single_process(world, S):
+    """Two optimisation steps (ELBO of the mean logits, backward, clip at 0.05, SGD) on `world` ranks that each
+    backpropagate their own slice of the S samples: the first step's summed gradients and the parameters after both steps
+    equal the single-process run's on every rank (S = 10 over 3 ranks: shards of 4, 3, 3)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, S, 2)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    loss, grads, params = _run(S, 2, False)
+    for rank, l, g, w in res:
+        assert l == pytest.approx(loss, rel=1e-6)
+        for a, b in zip(g, grads):
+            np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-7)
+        for a, b in zip(w, params):
+            np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-7)

@@ -38,7 +38,7 @@ def main(path, note=""):
     print("|---|---:|---:|---:|---:|")
     for name, v in sorted(per.items(), key=lambda kv: -sum(kv[1]))[:22]:
         print(f"| `{short(name)}` | {len(v)} | {sum(v):.1f} | {sum(v) / len(v):.2f} | {100 * sum(v) / total:.2f} |")
-    gemm = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "gemm256_sched" in r["Kernel_Name"]]
+    gemm = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if "gemm256_sched" in r["Kernel_Name"] or "gemm256_ring5" in r["Kernel_Name"]]
     if len(gemm) >= 48 and len(gemm) % 48 == 0:
         steps = len(gemm) // 48
         names = list(FLOP)
