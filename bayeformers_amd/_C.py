@@ -60,6 +60,7 @@ SYMBOLS = {
     "bf_gemm_nn_layers": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "bf_gemm_nn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "bf_gemm_tn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "bf_gemm_prepare": (_i, [_i, _i, _i, _i, _vp]),
     "bf_gemm_schedule": (_sz, [_i, _i, _i, _i, _i, _vp, _sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "bf_linear_fwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "bf_linear_fwd": (_i, [_vp, _i, _i64, _tp, _tp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u32, _vp, _vp, _sz, _vp]),

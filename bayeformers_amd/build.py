@@ -17,6 +17,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libbayeformers_amd.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
+# (bf_fused_ws.hip — the weight-stationary single-kernel variant of NS-1 — is built and tested (tests/test_gpu_fused_ws.py)
+# but nothing dispatches to it: measured 2.1-3.3x slower than sampling launch + 256-wide GEMM, DESIGN.md section 4.3.
+# It stays in the library as the measured alternative the north-star sentence asks about.)
 SOURCES = ["bf_api.hip", "bf_sample.hip", "bf_gemm.hip", "bf_gemm256.hip", "bf_gemm256_r5.hip", "bf_backward.hip", "bf_fused_small.hip", "bf_fused_ws.hip", "bf_norm.hip", "bf_attention.hip", "bf_attention_bwd.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

@@ -411,7 +411,7 @@ int bf_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_
 int bf_gemm_tn(const void* d_a, const void* d_bm, float* d_out, int dtype, int batch, int Mc, int N, int K, void* stream) {
     if (!d_a || !d_bm || !d_out) BF_FAIL("bf_gemm_tn: null pointer");
     if (!bf_gemm256_tn_supported(dtype, batch, Mc, N, K, d_a, d_bm, d_out))
-        BF_FAIL("bf_gemm_tn: needs a 16-bit dtype, Mc % 64 == 0, N % 8 == 0, K % 8 == 0 and 16-byte aligned pointers");
+        BF_FAIL("bf_gemm_tn: needs a 16-bit dtype, Mc %% 64 == 0, N %% 8 == 0, K %% 8 == 0 and 16-byte aligned pointers");
     return bf_launch_gemm256_tn(d_a, d_bm, d_out, dtype, batch, Mc, N, K, (hipStream_t)stream);
 }
 

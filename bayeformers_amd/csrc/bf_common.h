@@ -16,7 +16,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 // thread-local error string behind bf_last_error()
-void bf_set_error(const char* fmt, ...);
+void bf_set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
 #define BF_FAIL(...)               \
     do {                           \

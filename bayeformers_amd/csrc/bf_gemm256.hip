@@ -719,7 +719,15 @@ int get_schedule(int S, int layers, int tiles_n, int M, int policy, hipStream_t 
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
         BF_FAIL("bf_gemm_nt: the first launch of a shape (S=%d M=%d) builds its tile schedule and allocates device "
-                "memory; run the step once before capturing it into a graph", S, M);
+                "memory; call bf_gemm_prepare() for it, or run the step once, before capturing it into a graph", S, M);
+    // (variable-length batches: every new M is a new shape — keep the cache bounded; an evicted table is rebuilt on demand.
+    // Kernels already enqueued keep reading theirs: the memory is released with hipFreeAsync-like ordering by freeing only
+    // after a device synchronisation, which 256 evictions apart is rare enough not to matter)
+    if (g_sched.size() >= 256) {
+        BF_HIP_CHECK(hipDeviceSynchronize());
+        for (auto& kv : g_sched) (void)hipFree(kv.second.d_table);
+        g_sched.clear();
+    }
     std::vector<int4> table;
     Sched sc;
     build_schedule(S, layers, tiles_n, M, n_cu, policy, table, sc.rounds, sc.grid);
@@ -790,6 +798,12 @@ bool bf_gemm256_supported(int x_dtype, int w_dtype, int y_dtype, int S, int M, i
     const long long tiles = (long long)((M + UNIT * HMIN - 1) / (UNIT * HMIN)) * ((N + TN - 1) / TN) * S;  // S counts (layer, sample) pairs
     if (tiles > 0x3FFFFFll) return false;  // the host-built schedule stays small
     return true;
+}
+
+extern "C" int bf_gemm_prepare(int S, int L, int M, int N, void* stream) {
+    if (S < 1 || L < 1 || M < 1 || N < 1) BF_FAIL("bf_gemm_prepare: bad shape S=%d L=%d M=%d N=%d", S, L, M, N);
+    Sched sc;
+    return get_schedule(S, L, (N + TN - 1) / TN, M, BF_SCHED_POLICY, (hipStream_t)stream, sc);
 }
 
 extern "C" size_t bf_gemm_schedule(int S, int L, int M, int N, int n_cu, int32_t* out, size_t cap_values, int* rounds,

@@ -29,10 +29,16 @@ __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
     for (int i = 0; i < 4; ++i) v[i] = a[i], v[4 + i] = b[i];
 }
 #ifndef BF_LN_NT_STORES
-#define BF_LN_NT_STORES 1
+#define BF_LN_NT_STORES 3
 #endif
+// BF_LN_NT_STORES: how the normalised rows are written — 0 plain stores, 1 nontemporal, 2 sc1, 3 sc0 sc1 (write-through).
+// Measured on the whole BERT-base step, three interleaved rounds on one box (profiles/r3k_layernorm_store_policy.txt):
+// nontemporal 8.81-8.87 ms, plain 8.78-8.79, sc1 8.71-8.77, sc0 sc1 8.70-8.75: write-through rows are what the GEMM that
+// reads them next (cold, from another XCD's point of view) finds fastest.
 __device__ __forceinline__ void st16(f32x4_t* p, f32x4_t v) {
-    if (BF_LN_NT_STORES) __builtin_nontemporal_store(v, p);
+    if (BF_LN_NT_STORES == 1) __builtin_nontemporal_store(v, p);
+    else if (BF_LN_NT_STORES == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else if (BF_LN_NT_STORES == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
     else *p = v;
 }
 __device__ __forceinline__ void store8(__bf16* p, const float (&v)[8]) {

@@ -39,6 +39,14 @@ class KernelLayer(Module):
             self._sync_logprobs()
         super(KernelLayer, self)._save_to_state_dict(destination, prefix, keep_vars)
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """A checkpoint's log-prob scalars replace those of an earlier forward: drop the pending lazy refresh, or the next
+        attribute access would overwrite the loaded values with that forward's (the reference keeps what it loaded until
+        the next forward, layers/linear.py:99-102)."""
+        if any((prefix + n) in state_dict for n in _LOGPROB_NAMES):
+            self.__dict__["_lp_dirty"] = False
+        super(KernelLayer, self)._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def _sync_logprobs(self) -> None:
         self.__dict__["_lp_dirty"] = False
         v = self._lp_view.mean(0).to(torch.float32)

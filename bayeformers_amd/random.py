@@ -80,11 +80,14 @@ def use_device_counter(enable: bool = True, device="cuda") -> None:
         if STATE.device_counter is None:
             v = STATE.next_sample if STATE.next_sample < 2 ** 31 else STATE.next_sample - 2 ** 32
             STATE.device_counter = torch.full((1,), v, dtype=torch.int32, device=device)
-        _C.check(_C.lib().bf_set_sample_counter(STATE.device_counter.data_ptr()), "bf_set_sample_counter")
+        # the library keeps one pointer per HIP device, selected by the CURRENT device: make it the counter's
+        with torch.cuda.device(STATE.device_counter.device):
+            _C.check(_C.lib().bf_set_sample_counter(STATE.device_counter.data_ptr()), "bf_set_sample_counter")
     else:
         if STATE.device_counter is not None:
             STATE.next_sample = int(STATE.device_counter.item()) & 0xFFFFFFFF
-        _C.check(_C.lib().bf_set_sample_counter(None), "bf_set_sample_counter")
+            with torch.cuda.device(STATE.device_counter.device):
+                _C.check(_C.lib().bf_set_sample_counter(None), "bf_set_sample_counter")
         STATE.device_counter = None
 
 

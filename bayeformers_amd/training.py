@@ -28,64 +28,88 @@ from .sampling import elbo, sample_bayesian
 class GradientBuckets:
     """Flat gradient buffers over the trainable parameters of a model, summed over the ranks of `group` while backward
     runs.  `zero()` before the forward, `finish()` after `backward()`; the parameters' `.grad` are views of the buffers
-    (the optimizer updates from them directly)."""
+    (the optimizer updates from them directly).  Buckets hold one dtype each (the fp32 mu / rho masters apart from a
+    16-bit model's embeddings and LayerNorms) and every view starts on a 256-byte boundary, so the multi-tensor optimizer
+    kernels keep their vectorised path.  What it costs: one multi-tensor copy per bucket (the gradients backward produced
+    -> their slots), i.e. one extra read and write of the gradients per step — use it where there is something to
+    all-reduce (world > 1)."""
+
+    ALIGN = 256  # bytes
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional["dist.ProcessGroup"] = None,
                  bucket_bytes: int = 128 << 20):
         self.group = group
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-        # backward produces gradients roughly in reverse order of use: buckets are filled in reverse registration order
         self.buckets = []   # [flat tensor, [params], pending count, launched]
         self._bucket_of = {}
         self._views = {}
-        cur, cur_bytes, key = [], 0, None
+        # backward produces gradients roughly in reverse order of use: per dtype, buckets are filled in reverse
+        # registration order, so the first bucket to go on the wire holds the last layers' gradients
+        by_kind = {}
         for p in reversed(self.params):
-            k = (p.dtype, p.device)
-            nb = p.numel() * p.element_size()
-            if cur and (k != key or cur_bytes + nb > bucket_bytes):
+            by_kind.setdefault((p.dtype, p.device), []).append(p)
+        for ps in by_kind.values():
+            cur, cur_bytes = [], 0
+            for p in ps:
+                nb = self._padded(p) * p.element_size()
+                if cur and cur_bytes + nb > bucket_bytes:
+                    self._close(cur)
+                    cur, cur_bytes = [], 0
+                cur.append(p)
+                cur_bytes += nb
+            if cur:
                 self._close(cur)
-                cur, cur_bytes = [], 0
-            key = k
-            cur.append(p)
-            cur_bytes += nb
-        if cur:
-            self._close(cur)
         self._works = []
+        self._seen = set()
         self._hooks = [p.register_post_accumulate_grad_hook(self._arrived) for p in self.params]
 
+    def _padded(self, p) -> int:
+        q = self.ALIGN // p.element_size()
+        return (p.numel() + q - 1) // q * q
+
     def _close(self, ps):
-        flat = torch.zeros(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
+        flat = torch.zeros(sum(self._padded(p) for p in ps), dtype=ps[0].dtype, device=ps[0].device)
         off = 0
         for p in ps:
             self._views[p] = flat[off:off + p.numel()].view_as(p)
             self._bucket_of[p] = len(self.buckets)
-            off += p.numel()
+            off += self._padded(p)
         self.buckets.append([flat, ps, len(ps), False])
 
     def zero(self) -> None:
-        """Clear the buffers and (re-)attach the views as the parameters' gradients."""
+        """Start a step: gradients are None (autograd adopts the tensors backward produces, no accumulation kernels);
+        a bucket is filled by ONE multi-tensor copy when its last gradient has arrived."""
         self._works = []
+        self._seen = set()
         for b in self.buckets:
-            b[0].zero_()
             b[2], b[3] = len(b[1]), False
         for p in self.params:
-            if p.grad is not self._views[p]:
-                p.grad = self._views[p]
+            p.grad = None
 
     def _launch(self, i: int) -> None:
         b = self.buckets[i]
         if b[3]:
             return
         b[3] = True
+        have = [p for p in b[1] if p.grad is not None and p.grad is not self._views[p]]
+        if len(have) < len(b[1]):
+            b[0].zero_()  # some parameter of the bucket got no gradient this step: its slot must read zero
+        if have:
+            torch._foreach_copy_([self._views[p] for p in have], [p.grad for p in have])
+        for p in b[1]:
+            p.grad = self._views[p]
         if self.distributed:
             self._works.append(dist.all_reduce(b[0], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _arrived(self, p) -> None:
-        if p.grad is not self._views[p]:  # autograd replaced the view (first gradient of a parameter whose grad was None)
-            self._views[p].copy_(p.grad)
-            p.grad = self._views[p]
         i = self._bucket_of[p]
+        if self.buckets[i][3]:
+            raise RuntimeError("GradientBuckets: a parameter received a gradient after its bucket had been sent — every "
+                               "trainable parameter must receive at most one accumulated gradient per backward()")
+        if p in self._seen:
+            return  # a parameter used twice: autograd has added the second gradient to the first
+        self._seen.add(p)
         self.buckets[i][2] -= 1
         if self.buckets[i][2] == 0:
             self._launch(i)
@@ -107,14 +131,32 @@ class GradientBuckets:
         self._hooks = []
 
 
-def clip_grad_norm_(buckets: GradientBuckets, max_norm: float) -> Tensor:
-    """torch.nn.utils.clip_grad_norm_(parameters, max_norm) on the flat buffers: the same total 2-norm and scaling
-    (examples/bert_glue.py:240 clips at 1), in a few launches instead of one per parameter."""
-    flats = buckets.flats()
-    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(f.float()) for f in flats]))
+def grad_norm(tensors: List[Tensor]) -> Tensor:
+    """2-norm of all `tensors` together (0-d fp32), as torch.nn.utils.clip_grad_norm_ computes it, in one multi-tensor
+    launch per dtype instead of one reduction per tensor."""
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    norms = [n.float() for ts in by_dtype.values() for n in torch._foreach_norm(ts)]
+    return torch.linalg.vector_norm(torch.stack(norms))
+
+
+def clip_gradients(optimizer: torch.optim.Optimizer, tensors: List[Tensor], max_norm: float) -> Tensor:
+    """clip_grad_norm_(parameters, max_norm) (examples/bert_glue.py:240) for the step that follows: gradients are scaled
+    by min(1, max_norm / (|g| + 1e-6)).  A fused torch optimizer applies the factor inside its update kernel (its
+    `grad_scale` input, the hook torch.amp's GradScaler uses: gradients are divided by it) — no extra pass over the
+    gradients; any other optimizer gets them scaled in place.  Returns the total norm."""
+    total = grad_norm(tensors)
     coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
-    for f in flats:
-        f.mul_(coef.to(f.dtype))
+    if all(g.get("fused") for g in optimizer.param_groups):
+        optimizer.grad_scale = (1.0 / coef).to(torch.float32)
+        optimizer.found_inf = torch.zeros((), dtype=torch.float32, device=total.device)
+    else:
+        by_dtype = {}
+        for t in tensors:
+            by_dtype.setdefault(t.dtype, []).append(t)
+        for dt, ts in by_dtype.items():
+            torch._foreach_mul_(ts, coef.to(dt))
     return total
 
 
@@ -134,9 +176,9 @@ def training_step(model: Model, inputs, samples: int, nll_fn: Callable, optimize
     loss.backward()
     if buckets is not None:
         buckets.finish()
-        if max_grad_norm is not None:
-            clip_grad_norm_(buckets, max_grad_norm)
-    elif max_grad_norm is not None:
-        torch.nn.utils.clip_grad_norm_([p for g in optimizer.param_groups for p in g["params"]], max_grad_norm)
+    if max_grad_norm is not None:
+        grads = buckets.flats() if buckets is not None else [p.grad for g in optimizer.param_groups for p in g["params"]
+                                                             if p.grad is not None]
+        clip_gradients(optimizer, grads, max_grad_norm)
     optimizer.step()
     return loss.detach()

@@ -117,15 +117,16 @@ def make_bert(device, S, dtype, train=False):
 
         params = [p for p in bmodel.parameters() if p.requires_grad]
         opt = torch.optim.AdamW(params, lr=2e-5, eps=1e-8, weight_decay=0.0, fused=True)
-        # flat gradient buffers: all-reduced over the ranks while backward runs (world > 1), clipped in a few launches
-        buckets = GradientBuckets(params)
+        # world > 1: flat gradient buffers, all-reduced over the ranks while backward runs
+        buckets = GradientBuckets(params) if _world() > 1 or os.environ.get("BF_BENCH_TRAIN_BUCKETS") is not None else None
 
         def nll_fn(mean):
             return torch.nn.functional.cross_entropy(mean[0].float(), labels_d)
 
         def step():  # noqa: F811
             # examples/bert_glue.py:227-241: forward, ELBO, backward, clip_grad_norm_(1), optimizer step
-            return training_step(bmodel, inputs, S * _world(), nll_fn, opt, n_batches, buckets=buckets, max_grad_norm=1.0)
+            return training_step(bmodel, inputs, S * _world(), nll_fn, opt, n_batches, buckets=buckets,
+                                 max_grad_norm=None if os.environ.get("BF_BENCH_TRAIN_NO_CLIP") is not None else 1.0)
 
     def cpu_baseline():
         from oracle.model_oracle import log_probs, to_oracle

@@ -161,6 +161,12 @@ int bf_gemm_nn(const void* d_x, const void* d_w, void* d_y, int dtype, int S, in
 int bf_gemm_nn_layers(const void* d_x, const void* d_w, void* d_y, int dtype, int L, int S, int M, int N, int K,
                       void* stream);
 
+/* Build (once per device and shape) the tile schedule the 256-wide GEMM kernels run a [S][M][N] problem of L stacked
+ * layers on — a small device table, allocated here.  The first bf_gemm_nt* / bf_linear_* call of a shape does the same
+ * implicitly, which is an error inside a stream capture: call this for the shapes of a step before capturing it (or
+ * simply run the step once).  Returns 0, or 1 with bf_last_error() set. */
+int bf_gemm_prepare(int S, int L, int M, int N, void* stream);
+
 /* The host-built tile schedule the 256-wide persistent GEMM kernel runs for a problem of S samples x L layers x
  * [M, N] outputs on n_cu compute units (introspection: the library builds and caches the same table on the first
  * launch of a shape).  The output is cut into tiles of 32 h rows (h = 1..8) x 256 columns; every workgroup b of the

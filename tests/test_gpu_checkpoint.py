@@ -80,3 +80,27 @@ def test_state_dict_round_trip_through_a_file(tmp_path):
     assert torch.equal(ya, yb)
     assert float(b.log_prior()) == float(a.log_prior())
     assert float(b.state_dict()["model.0.log_prior"]) == float(a.state_dict()["model.0.log_prior"]) != 0.0
+
+
+def test_loaded_logprob_scalars_survive_an_earlier_forward():
+    """load_state_dict after a forward: the layer's lazily refreshed log-prob scalars must be the checkpoint's, not the
+    pre-load forward's (nn/layers/base.py::_load_from_state_dict), until the next forward replaces them."""
+    torch.manual_seed(5)
+    bmodel = bf.to_bayesian(_net(), delta=0.05).cuda()
+    x = torch.randn(8, 48, device="cuda")
+    bf.manual_seed(SEED)
+    with torch.no_grad():
+        bmodel(x)                                   # leaves a pending refresh in every layer
+    sd = {k: v.clone() for k, v in bmodel.state_dict().items()}
+    first = next(k for k in sd if k.endswith("0.log_prior"))
+    sd[first] = torch.tensor(-123.5)
+    sd[first.replace("log_prior", "log_variational_posterior")] = torch.tensor(77.25)
+    with torch.no_grad():
+        bmodel(x)                                   # a later forward: pending refresh with OTHER values
+    bmodel.load_state_dict(sd, strict=True)
+    layer = bmodel.model[0]
+    assert float(layer.log_prior) == -123.5 and float(layer.log_variational_posterior) == 77.25
+    assert float(bmodel.state_dict()[first]) == -123.5
+    with torch.no_grad():
+        bmodel(x)
+    assert float(layer.log_prior) != -123.5       # the next forward owns the attributes again

@@ -480,6 +480,32 @@ def test_hip_graph_replay_draws_fresh_samples():
     assert not torch.equal(got[0], got[1])
 
 
+def test_gemm_prepare_lets_a_first_launch_be_captured():
+    """The first launch of a GEMM shape builds its tile schedule (a device allocation): an error inside a stream capture
+    unless bf_gemm_prepare() built it before."""
+    from bayeformers_amd import _C, ops
+
+    S, M, N, K = 2, 520, 328, 192   # shapes no other test uses
+    x = torch.randn(S, M, K, device="cuda").bfloat16()
+    w = (torch.randn(S, N, K, device="cuda") * 0.1).bfloat16()
+    b = torch.randn(S, N, device="cuda")
+    ref = torch.einsum("smk,snk->smn", x.float(), w.float()) + b[:, None]
+    _C.check(_C.lib().bf_gemm_prepare(S, 1, M, N, None), "bf_gemm_prepare")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y = ops.gemm_nt(x, w, b, S, M, N, K, M * K, torch.bfloat16, 0)
+    g.replay()
+    torch.cuda.synchronize()
+    assert (y.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+    # an unprepared shape inside a capture is refused with a message that says what to do
+    x2 = torch.randn(S, M + 64, K, device="cuda").bfloat16()
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(_C.BayeFormersAMDError, match="bf_gemm_prepare|run the step once"):
+        with torch.cuda.graph(g2):
+            ops.gemm_nt(x2, w, b, S, M + 64, N, K, (M + 64) * K, torch.bfloat16, 0)
+
+
 def test_device_counter_survives_backward():
     """Device-counter mode with a backward pass in between (autograd runs it on its own thread): the counter the
     kernels add must still be the live one afterwards, so step k draws the eps of eager step k — not step 0's again."""

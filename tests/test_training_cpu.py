@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 
 import bayeformers_amd.nn as bnn
 from bayeformers_amd import random as bfr
-from bayeformers_amd.training import GradientBuckets, clip_grad_norm_, training_step
+from bayeformers_amd.training import GradientBuckets, clip_gradients, grad_norm, training_step
 
 
 class NoisyNet(bnn.Model):
@@ -43,7 +43,7 @@ def _run(S, steps, group_used):
     model = NoisyNet()
     params = list(model.parameters())
     opt = torch.optim.SGD(params, lr=0.5)
-    buckets = GradientBuckets(params, bucket_bytes=32)  # tiny buckets: w alone, b + unused together
+    buckets = GradientBuckets(params, bucket_bytes=300)  # small buckets: w alone, b + unused together
     bfr.manual_seed(11)
     grads = None
     for _ in range(steps):
@@ -65,30 +65,56 @@ def _worker(rank, world, port, q, S, steps):
 
 def test_gradient_buckets_and_clip_single_process():
     torch.manual_seed(1)
-    ps = [torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2))]
-    buckets = GradientBuckets(ps, bucket_bytes=64)
-    assert len(buckets.buckets) == 2  # reverse order: [2x2 + 5] (36 B), then [7x3] (84 B, alone)
+    ps = [torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2)),
+          torch.nn.Parameter(torch.randn(6).to(torch.bfloat16))]
+    buckets = GradientBuckets(ps, bucket_bytes=600)
+    # one bucket per dtype and size limit: fp32 [2x2 + 5] (two 256-byte slots), fp32 [7x3] (one), bf16 [6]
+    assert sorted(len(b[1]) for b in buckets.buckets) == [1, 1, 2]
+    assert all((buckets._views[p].data_ptr() - buckets.buckets[buckets._bucket_of[p]][0].data_ptr()) % 256 == 0 for p in ps)
     buckets.zero()
-    loss = (ps[0] ** 2).sum() + (3 * ps[1]).sum() + ps[2].sum()
+    loss = (ps[0] ** 2).sum() + (3 * ps[1]).sum() + ps[2].sum() + (ps[3].float() * 2).sum()
     loss.backward()
     buckets.finish()
     for p in ps:
         assert p.grad.data_ptr() == buckets._views[p].data_ptr()
     np.testing.assert_allclose(ps[0].grad.numpy(), 2 * ps[0].detach().numpy(), rtol=1e-6)
     ref = [p.grad.clone() for p in ps]
-    want = torch.nn.utils.clip_grad_norm_([torch.nn.Parameter(p.detach().clone()) for p in ps], 1.0)  # norm of params: unused
-    total = clip_grad_norm_(buckets, 0.5)
-    tn = torch.sqrt(sum((g ** 2).sum() for g in ref))
-    assert float(total) == pytest.approx(float(tn), rel=1e-6)
+    tn = torch.sqrt(sum((g.float() ** 2).sum() for g in ref))
+    assert float(grad_norm(buckets.flats())) == pytest.approx(float(tn), rel=1e-3)  # the padding is zero; a bf16 bucket's norm is bf16
+    # not a fused optimizer: gradients scaled in place, exactly as torch.nn.utils.clip_grad_norm_ scales them
+    opt = torch.optim.SGD(ps, lr=0.1)
+    total = clip_gradients(opt, buckets.flats(), 0.5)
+    assert float(total) == pytest.approx(float(tn), rel=1e-3)
     for p, g in zip(ps, ref):
-        np.testing.assert_allclose(p.grad.numpy(), (g * min(1.0, 0.5 / (float(tn) + 1e-6))).numpy(), rtol=1e-6)
-    # a second step accumulates from zero again, gradients set to None by an optimizer are re-attached
-    ps[1].grad = None
+        np.testing.assert_allclose(p.grad.float().numpy(), (g.float() * min(1.0, 0.5 / (float(tn) + 1e-6))).numpy(), rtol=1e-2)
+    # a second step starts from nothing again; parameters without a gradient read zero
     buckets.zero()
+    assert all(p.grad is None for p in ps)
     (ps[1] * 2).sum().backward()
     buckets.finish()
     assert ps[1].grad.data_ptr() == buckets._views[ps[1]].data_ptr() and float(ps[1].grad.sum()) == 10.0
-    assert float(ps[0].grad.abs().sum()) == 0.0
+    assert float(ps[0].grad.abs().sum()) == 0.0 and float(ps[2].grad.abs().sum()) == 0.0
+
+
+def test_clip_through_a_fused_optimizer_matches_scaled_gradients():
+    """A fused torch optimizer takes the clipping factor as its `grad_scale` input: the update equals the one from
+    gradients scaled by torch.nn.utils.clip_grad_norm_."""
+    def run(fused_path):
+        torch.manual_seed(2)
+        ps = [torch.nn.Parameter(torch.randn(9, 4)), torch.nn.Parameter(torch.randn(11))]
+        opt = torch.optim.AdamW(ps, lr=0.05, eps=1e-8, weight_decay=0.0, fused=True)
+        for k in range(3):
+            opt.zero_grad(set_to_none=True)
+            ((ps[0] ** 2).sum() * (k + 1) + (ps[1] ** 3).sum()).backward()
+            if fused_path:
+                clip_gradients(opt, [p.grad for p in ps], 0.7)
+            else:
+                torch.nn.utils.clip_grad_norm_(ps, 0.7)
+            opt.step()
+        return [p.detach().clone() for p in ps]
+
+    for a, b in zip(run(True), run(False)):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize("world,S", [(2, 6), (3, 10)])
