@@ -37,8 +37,11 @@ __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
 // reads them next (cold, from another XCD's point of view) finds fastest.
 __device__ __forceinline__ void st16(f32x4_t* p, f32x4_t v) {
     if (BF_LN_NT_STORES == 1) __builtin_nontemporal_store(v, p);
-    else if (BF_LN_NT_STORES == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-    else if (BF_LN_NT_STORES == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    // (inline asm: there is no builtin for a flat-addressed store with these cache bits.  The trailing s_nop keeps the
+    // compiler's next instruction from overwriting the data registers before the store has read them — it does not pad
+    // hazards of instructions inside an asm statement)
+    else if (BF_LN_NT_STORES == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else if (BF_LN_NT_STORES == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     else *p = v;
 }
 __device__ __forceinline__ void store8(__bf16* p, const float (&v)[8]) {
