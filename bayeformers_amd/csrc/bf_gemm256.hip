@@ -95,8 +95,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
     const int wm = wid >> 2, wn = wid & 3;
     const int M = p.M, N = p.N, K = p.K;
 
-    const int prow = lane >> 3;
-    const int kc8 = ((lane & 7) ^ ((((wid & 1) << 2) + (lane >> 4)) & 7)) * 8;
 
     // One tile's DMA sources: wave-uniform sample bases (SGPRs) + eight 32-bit per-lane element offsets.
     struct Src {
@@ -106,6 +104,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
         unsigned xo[XPIECES], wo[4];
     };
     auto tile_setup = [&](const int4 d, Src& t, int& s, int& m0, int& n0, int& h) {
+        // the lane's place in a DMA piece, recomputed per tile from an opaque copy of the lane id: as kernel-lifetime
+        // values the two would sit in VGPRs through every k-loop (the fp32-output instantiations spilled two registers)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int prow = ln >> 3;
+        const int kc8 = ((ln & 7) ^ ((((wid & 1) << 2) + (ln >> 4)) & 7)) * 8;
         // the entry is the same for every lane: say so, so that everything derived from it lives in SGPRs
         s = __builtin_amdgcn_readfirstlane(d.x);
         const int z = __builtin_amdgcn_readfirstlane(d.z);
@@ -843,14 +847,14 @@ int bf_launch_gemm256(const GemmParams& p0, int w_dtype, int y_dtype, hipStream_
     if (get_schedule(p.S, p.layers, p.tiles_n, p.M, policy, stream, sc)) return 1;
     p.sched = sc.d_table;
     p.sched_rounds = sc.rounds;
-    // forward form: the five-slot ring (bf_gemm256_r5.hip) where it applies.  BF_NT_FORM: 0 = burst kernel, 1 = ring with
-    // global_load_lds pieces, 2 = ring with buffer_load ... lds pieces (developer builds: BF_GEMM_NT_FORM overrides)
+    // forward form: the five-slot ring (bf_gemm256_r5.hip) where it applies.  BF_NT_FORM: 0 = burst kernel, non-zero = ring
+    // (developer builds: BF_GEMM_NT_FORM overrides)
     int form = BF_NT_FORM;
 #ifdef BF_DEV
     const char* fe = getenv("BF_GEMM_NT_FORM");
     if (fe) form = atoi(fe);
 #endif
-    if (form && bf_gemm256_r5_supported(p, w_dtype, y_dtype)) return bf_launch_gemm256_r5(p, w_dtype, stream, sc.grid, form == 2);
+    if (form && bf_gemm256_r5_supported(p, w_dtype, y_dtype)) return bf_launch_gemm256_r5(p, w_dtype, stream, sc.grid);
     if (w_dtype == BF_DT_BF16) return launch256<__bf16>(p, y_dtype, stream, sc.grid);
     return launch256<_Float16>(p, y_dtype, stream, sc.grid);
 }

@@ -20,9 +20,9 @@ struct Gemm256Sched {
 };
 int bf_gemm256_get_schedule(int S, int layers, int tiles_n, int M, int policy, hipStream_t stream, Gemm256Sched& out);
 
-// the five-slot-ring forward kernel (bf_gemm256_r5.hip); `buf`: pieces by buffer_load ... lds instead of global_load_lds
+// the five-slot-ring forward kernel (bf_gemm256_r5.hip)
 bool bf_gemm256_r5_supported(const GemmParams& p, int w_dtype, int y_dtype);
-int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, int grid, bool buf);
+int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, int grid);
 
 namespace {
 

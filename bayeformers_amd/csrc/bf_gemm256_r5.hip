@@ -28,9 +28,10 @@ namespace {
 constexpr int SLOT_BYTES = 32768;  // one unit: 256 rows x 128 B (= X_BYTES)
 constexpr int NSLOT = 5;
 
-// BUF: the pieces are fetched with buffer_load ... lds through a per-tile buffer descriptor (32-bit per-lane byte offset
-// + scalar k offset: no 64-bit vector address arithmetic per piece) instead of global_load_lds.
-template <typename T, typename YT, bool BUF>
+// The pieces are fetched with buffer_load ... lds through a per-tile buffer descriptor (32-bit per-lane byte offset + scalar
+// k offset: no 64-bit vector address arithmetic per piece; measured +3-5 % over global_load_lds at K = 768, whose
+// instantiation also needed 9 spilled registers and is gone).
+template <typename T, typename YT>
 __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams p) {
     using frag = typename Mfma16<T>::frag;
 
@@ -43,11 +44,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
 
     // piece q = i * 8 + wid of a unit = rows 8 q .. 8 q + 7; lane -> (row lane >> 3, 16-byte position lane & 7) holding
     // source chunk position ^ ((row >> 1) & 7)
-    const int prow = lane >> 3;
-    const int kc8 = ((lane & 7) ^ ((((wid & 1) << 2) + (lane >> 4)) & 7)) * 8;
+    // (recomputed per tile from an opaque copy of the lane id — kernel-lifetime values would hold two VGPRs through every k-loop)
+    auto piece_lane = [&](int& prow, int& kc8) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        prow = ln >> 3;
+        kc8 = ((ln & 7) ^ ((((wid & 1) << 2) + (ln >> 4)) & 7)) * 8;
+    };
 
-    // DMA sources of the units still to be issued: wave-uniform operand bases + four per-lane offsets per operand (elements;
-    // bytes under BUF).  Only ONE such set exists: the W half is switched to the workgroup's next tile before the k-step
+    // DMA sources of the units still to be issued: wave-uniform operand bases + four per-lane BYTE offsets per operand.  Only ONE such set exists: the W half is switched to the workgroup's next tile before the k-step
     // that issues that tile's W(0), the x half one k-step later.
     const T* xb;
     const T* wb;
@@ -56,29 +61,28 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         const int s = __builtin_amdgcn_readfirstlane(d.x);
         const int n0 = (__builtin_amdgcn_readfirstlane(d.z) & 0xFFFFFF) * TN;
         wb = reinterpret_cast<const T*>(p.w) + (long long)s * N * K;
+        int prow, kc8;
+        piece_lane(prow, kc8);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            wo[i] = ((unsigned)min(n0 + (i * 8 + wid) * 8 + prow, N - 1) * (unsigned)K + kc8) * (BUF ? 2u : 1u);
+            wo[i] = ((unsigned)min(n0 + (i * 8 + wid) * 8 + prow, N - 1) * (unsigned)K + kc8) * 2u;
     };
     auto setup_x = [&](const int4 d) {
         const int m0 = __builtin_amdgcn_readfirstlane(d.w);
         xb = reinterpret_cast<const T*>(p.x) + (long long)__builtin_amdgcn_readfirstlane(d.y) * p.x_sstride;
+        int prow, kc8;
+        piece_lane(prow, kc8);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            xo[i] = ((unsigned)min(m0 + (i * 8 + wid) * 8 + prow, M - 1) * (unsigned)K + kc8) * (BUF ? 2u : 1u);
+            xo[i] = ((unsigned)min(m0 + (i * 8 + wid) * 8 + prow, M - 1) * (unsigned)K + kc8) * 2u;
     };
     auto piece = [&](const T* base, unsigned off, int kt, char* dst) {
 #ifdef BF_DEV
         if (p.flags & 1) return;   // ablation: no DMA in the k-loop
         if (p.flags & 64) kt = 0;  // ablation: every k-step re-reads k-step 0 (operands L2-hot)
 #endif
-        if constexpr (BUF) {
-            const __amdgpu_buffer_rsrc_t r =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, 0x7FFFFFFF, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, (int)off, kt * (TK * 2), 0, 0);
-        } else {
-            glds16(base + (long long)kt * TK + off, dst);
-        }
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, 0x7FFFFFFF, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, (int)off, kt * (TK * 2), 0, 0);
     };
     // this wave's pieces of unit X(kt) / W(kt) into ring slot `slot`; only the 4 h pieces of the tile's rows of x are
     // fetched (h4 = 4 h: an integral_constant inside a tile's k-loop, so a full-height tile issues without branches)
@@ -247,9 +251,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
 }
 
 template <typename T, typename YT>
-int launch_r5(const GemmParams& p, hipStream_t stream, int grid, bool buf) {
-    if (buf) hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, true>), dim3(grid), dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, false>), dim3(grid), dim3(512), 0, stream, p);
+int launch_r5(const GemmParams& p, hipStream_t stream, int grid) {
+    hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -259,12 +262,12 @@ int launch_r5(const GemmParams& p, hipStream_t stream, int grid, bool buf) {
 bool bf_gemm256_r5_supported(const GemmParams& p, int w_dtype, int y_dtype) {
     if (p.K < 2 * TK || p.segs > 1) return false;
     if (y_dtype != w_dtype) return false;  // fp32 outputs stay on the burst kernel
+    // an operand of one sample is addressed by 32-bit byte offsets
+    if ((long long)p.M * p.K >= (1ll << 30) || (long long)p.N * p.K >= (1ll << 30)) return false;
     return true;
 }
 
-int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, int grid, bool buf) {
-    // the buffer form addresses an operand by 32-bit byte offsets
-    if (buf && ((long long)p.M * p.K >= (1ll << 30) || (long long)p.N * p.K >= (1ll << 30))) buf = false;
-    if (w_dtype == BF_DT_BF16) return launch_r5<__bf16, __bf16>(p, stream, grid, buf);
-    return launch_r5<_Float16, _Float16>(p, stream, grid, buf);
+int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, int grid) {
+    if (w_dtype == BF_DT_BF16) return launch_r5<__bf16, __bf16>(p, stream, grid);
+    return launch_r5<_Float16, _Float16>(p, stream, grid);
 }

@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--samples", type=int, default=None, help="MC samples per GPU per step (default: workload's)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-mode", action="store_true",
+                    help="bert_base_train only: put the model in .train() like examples/bert_glue.py:221 (HF dropout p = 0.1 "
+                         "active: attention and embeddings take the framework's paths); default: dropout off")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group check only: every rank joins the group (RCCL on GPUs, gloo without), "
@@ -95,7 +98,7 @@ def build_bert(device, dtype):
     return bmodel, model, inputs, ids, labels, info
 
 
-def make_bert(device, S, dtype, train=False):
+def make_bert(device, S, dtype, train=False, train_mode=False):
     from bayeformers_amd.sampling import elbo, sample_bayesian
 
     B, L, n_batches = 32, 128, 2105  # SST-2: 67,349 train sentences / 32
@@ -115,6 +118,8 @@ def make_bert(device, S, dtype, train=False):
         # with weight_decay = 0 is the same update; fused = one multi-tensor kernel for all 85 parameter tensors)
         from bayeformers_amd.training import GradientBuckets, training_step
 
+        if train_mode:
+            bmodel.train()
         params = [p for p in bmodel.parameters() if p.requires_grad]
         opt = torch.optim.AdamW(params, lr=2e-5, eps=1e-8, weight_decay=0.0, fused=True)
         # world > 1: flat gradient buffers, all-reduced over the ranks while backward runs
@@ -147,7 +152,8 @@ def make_bert(device, S, dtype, train=False):
                           f"torch-CPU fp32, {dt:.1f}s"}
 
     cfgd = {"workload": "to_bayesian(BERT-base seq-cls, delta=0.05, freeze=True) " +
-                        ("training step: fwd+ELBO+backward+clip+AdamW, dropout off" if train else "fwd+ELBO"), "samples_per_gpu": S,
+                        (("training step: fwd+ELBO+backward+clip+AdamW, " + ("model.train(): dropout 0.1" if train_mode else "dropout off"))
+                         if train else "fwd+ELBO"), "samples_per_gpu": S,
             "batch": B, "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "bayesian_scalars": 85609730}
     cfgd.update(info)
     return step, cpu_baseline, cfgd, bmodel
@@ -453,7 +459,7 @@ def main():
     if args.workload == "bert_base":
         step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype)
     elif args.workload == "bert_base_train":
-        step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype, train=True)
+        step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype, train=True, train_mode=args.train_mode)
     elif args.workload == "bert_large_qa":
         step, cpu_baseline, cfgd, bmodel = make_bert_large_qa(device, S, dtype)
     elif args.workload == "linear768":
