@@ -33,10 +33,6 @@ GROUP_BYTES = 96 << 20
 # Sampled weights held at once: group g lives in arena g % R, R = as many arenas as fit in ARENA_BYTES.  MI355X has
 # 288 GB: BERT-base (S = 10: 1.7 GB of bf16 weights) and BERT-large (6 GB) fit whole, so ONE launch samples the model.
 ARENA_BYTES = int(os.environ.get("BF_PLAN_ARENA_BYTES", str(16 << 30)))
-# Developer experiment (profiles/r3r_side_stream_sampling.txt): sample only the first SIDE_CHUNK groups on
-# the compute stream and the rest, SIDE_CHUNK groups per launch, on a second stream, so that they run beside the
-# memory-bound kernels of the layers before them; a layer's first GEMM waits for its chunk's event.  0 = off (the product).
-SIDE_CHUNK = int(os.environ.get("BF_PLAN_SIDE_STREAM", "0"))
 
 
 class SamplePlan:
@@ -213,39 +209,9 @@ class SamplePlan:
             self.pending.add(gi)
             self.arena_owner[gi % len(self.arenas)] = (gi, token)
 
-    def _ensure_side(self, gi: int, token, seed: int, sample_base: int) -> None:
-        """SIDE_CHUNK > 0 and every group has its own arena: chunk 0 on the compute stream, the other chunks on a side
-        stream (enqueued at once, behind everything the compute stream has been given so far — the previous forward's
-        readers of the arenas included); a chunk's event is waited for when one of its layers runs."""
-        if getattr(self, "_side_token", None) != token:
-            self._side_token = token
-            if getattr(self, "_side_stream", None) is None:
-                self._side_stream = torch.cuda.Stream(device=self.device)
-            main = torch.cuda.current_stream(self.device)
-            n = len(self.groups)
-            self._sample_groups(0, min(SIDE_CHUNK, n) - 1, token, seed, sample_base)
-            self._side_events = {}
-            start = torch.cuda.Event()
-            start.record(main)
-            with torch.cuda.stream(self._side_stream):
-                self._side_stream.wait_event(start)
-                for a in range(SIDE_CHUNK, n, SIDE_CHUNK):
-                    b = min(a + SIDE_CHUNK, n) - 1
-                    self._sample_groups(a, b, token, seed, sample_base)
-                    ev = torch.cuda.Event()
-                    ev.record(self._side_stream)
-                    for g in range(a, b + 1):
-                        self._side_events[g] = ev
-        ev = self._side_events.pop(gi, None)
-        if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
-
     def ensure(self, layer, token, seed: int, sample_base: int, lp_buf: torch.Tensor):
         """Make sure `layer`'s group has been sampled for the forward identified by `token`; returns (W_s, b_s)."""
         gi = self.group_of[id(layer)]
-        if SIDE_CHUNK > 0 and len(self.arenas) >= len(self.groups):
-            self._ensure_side(gi, token, seed, sample_base)
-            return self.views[id(layer)]
         if self.arena_owner[gi % len(self.arenas)] != (gi, token):
             # this group and as many of the following ones as the arena ring holds, in one launch: everything that
             # read the arenas being overwritten was enqueued before this point
@@ -260,10 +226,6 @@ class SamplePlan:
         one bf_reduce_logprob launch per run of groups whose layers are consecutive rows (normally one per forward)."""
         if not self.pending:
             return
-        if SIDE_CHUNK > 0 and getattr(self, "_side_events", None):
-            for ev in set(self._side_events.values()):  # chunks none of whose layers ran: their partials are reduced below
-                torch.cuda.current_stream(self.device).wait_event(ev)
-            self._side_events = {}
         lib = _C.lib()
         stream = ops._stream_ptr()
         run = None  # (first plan-layer, number of layers, first row)
