@@ -36,6 +36,9 @@
 #ifndef BF_NT_FORM
 #define BF_NT_FORM 2
 #endif
+#ifndef BF_NN_FORM
+#define BF_NN_FORM 1
+#endif
 
 namespace {
 
@@ -933,6 +936,13 @@ int bf_launch_gemm256_nn(const void* d_x, const void* d_w, void* d_y, int dtype,
     if (get_schedule(p.S, 1, p.tiles_n, p.M, BF_SCHED_POLICY, stream, sc)) return 1;
     p.sched = sc.d_table;
     p.sched_rounds = sc.rounds;
+    // the five-slot ring (bf_gemm256_r5.hip) where it applies; BF_NN_FORM 0 = burst kernel (developer builds: BF_GEMM_NN_FORM)
+    int form = BF_NN_FORM;
+#ifdef BF_DEV
+    const char* fe = getenv("BF_GEMM_NN_FORM");
+    if (fe) form = atoi(fe);
+#endif
+    if (form && bf_gemm256_r5_supported(p, dtype, dtype)) return bf_launch_gemm256_r5_nn(p, dtype, stream, sc.grid);
     if (dtype == BF_DT_BF16) return launch256_nn<__bf16>(p, stream, sc.grid);
     return launch256_nn<_Float16>(p, stream, sc.grid);
 }

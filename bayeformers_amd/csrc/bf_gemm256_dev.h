@@ -23,6 +23,7 @@ int bf_gemm256_get_schedule(int S, int layers, int tiles_n, int M, int policy, h
 // the five-slot-ring forward kernel (bf_gemm256_r5.hip)
 bool bf_gemm256_r5_supported(const GemmParams& p, int w_dtype, int y_dtype);
 int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, int grid);
+int bf_launch_gemm256_r5_nn(const GemmParams& p, int dtype, hipStream_t stream, int grid);
 
 namespace {
 
@@ -96,7 +97,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef BF_NT_STORES
 #define BF_NT_STORES 1
 #endif
-constexpr bool NT_STORES = BF_NT_STORES;
+constexpr int NT_STORES = BF_NT_STORES;  // 0 plain, 1 nontemporal (product), 2 / 3 = sc1 / sc0 sc1 write-through (experiments)
+__device__ __forceinline__ void gemm_st16(f32x4_t* p, f32x4_t v) {
+    if (NT_STORES == 1) __builtin_nontemporal_store(v, p);
+    else if (NT_STORES == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else if (NT_STORES == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else *p = v;
+}
 
 
 // act() of a 16-byte chunk of YT outputs (8 x 16-bit or 4 x fp32), computed in fp32
@@ -189,8 +196,7 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
                 if (y2) {
                     YT* o2 = y2 + (unsigned)(m * N + n);
                     if (n_full) {
-                        if (NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(o2));
-                        else *reinterpret_cast<f32x4_t*>(o2) = v;
+                        gemm_st16(reinterpret_cast<f32x4_t*>(o2), v);
                     } else {
                         const YT* e = reinterpret_cast<const YT*>(&v);
                         for (int j = 0; j < EPC; ++j)
@@ -200,8 +206,7 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
                 }
                 YT* o = y + (unsigned)(m * N + n);
                 if (n_full) {
-                    if (NT_STORES) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(o));
-                    else *reinterpret_cast<f32x4_t*>(o) = v;
+                    gemm_st16(reinterpret_cast<f32x4_t*>(o), v);
                 } else {
                     const YT* e = reinterpret_cast<const YT*>(&v);
                     for (int j = 0; j < EPC; ++j)

@@ -31,7 +31,12 @@ constexpr int NSLOT = 5;
 // The pieces are fetched with buffer_load ... lds through a per-tile buffer descriptor (32-bit per-lane byte offset + scalar
 // k offset: no 64-bit vector address arithmetic per piece; measured +3-5 % over global_load_lds at K = 768, whose
 // instantiation also needed 9 spilled registers and is gone).
-template <typename T, typename YT>
+// TRW: W is contraction-major ([K][N] rows of the sampled weights as they lie: the NN form dx = dy W of the backward pass);
+// a W unit is then a [64 contraction rows][256] tile of 512-byte rows whose 32-byte granules are XOR-swizzled by the row
+// (on the DMA source address) and whose fragments come out through ds_read_b64_tr_b16, exactly as in bf_gemm256.hip.
+// SEG: the contraction runs over p.segs segments of K (x: [segs][S][M][K], w: [segs][S][K][N]) — the one input gradient
+// of the stacked query / key / value layers.
+template <typename T, typename YT, bool TRW = false, bool SEG = false>
 __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams p) {
     using frag = typename Mfma16<T>::frag;
 
@@ -61,11 +66,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         const int s = __builtin_amdgcn_readfirstlane(d.x);
         const int n0 = (__builtin_amdgcn_readfirstlane(d.z) & 0xFFFFFF) * TN;
         wb = reinterpret_cast<const T*>(p.w) + (long long)s * N * K;
-        int prow, kc8;
-        piece_lane(prow, kc8);
+        if constexpr (TRW) {
+            // piece q = i * 8 + wid = contraction rows 2 q, 2 q + 1 of the k-step; lane -> (row, 16-byte position) holding
+            // source chunk position ^ (key(row) << 1), key = row bits {0, 1, 3}; the key does not depend on i: one offset
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int tr_r = wid * 2 + (ln >> 5);
+            const int tr_c = (ln & 31) ^ (((tr_r & 3) | ((tr_r >> 1) & 4)) << 1);
+            wo[0] = ((unsigned)tr_r * (unsigned)N + (unsigned)min(n0 + tr_c * 8, N - 8)) * 2u;
+        } else {
+            int prow, kc8;
+            piece_lane(prow, kc8);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            wo[i] = ((unsigned)min(n0 + (i * 8 + wid) * 8 + prow, N - 1) * (unsigned)K + kc8) * 2u;
+            for (int i = 0; i < 4; ++i)
+                wo[i] = ((unsigned)min(n0 + (i * 8 + wid) * 8 + prow, N - 1) * (unsigned)K + kc8) * 2u;
+        }
     };
     auto setup_x = [&](const int4 d) {
         const int m0 = __builtin_amdgcn_readfirstlane(d.w);
@@ -76,26 +91,49 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         for (int i = 0; i < 4; ++i)
             xo[i] = ((unsigned)min(m0 + (i * 8 + wid) * 8 + prow, M - 1) * (unsigned)K + kc8) * 2u;
     };
-    auto piece = [&](const T* base, unsigned off, int kt, char* dst) {
+    // one 1 KiB piece: `base` + per-lane byte offset `off` + wave-uniform byte offset `soff` -> LDS `dst`
+    auto piece = [&](const T* base, unsigned off, int soff, char* dst) {
 #ifdef BF_DEV
-        if (p.flags & 1) return;   // ablation: no DMA in the k-loop
-        if (p.flags & 64) kt = 0;  // ablation: every k-step re-reads k-step 0 (operands L2-hot)
+        if (p.flags & 1) return;  // ablation: no DMA in the k-loop
 #endif
         const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, 0x7FFFFFFF, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, (int)off, kt * (TK * 2), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, (int)off, soff, 0, 0);
+    };
+    // segmented contraction: k-step kt lies in segment kt / (K / TK) (wave-uniform arithmetic)
+    auto segment = [&](int& kt) -> int {
+        if constexpr (SEG) {
+            const int nks = K / TK;
+            const int seg = (kt >= nks ? 1 : 0) + (kt >= 2 * nks ? 1 : 0) + (kt >= 3 * nks ? 1 : 0);
+            kt -= seg * nks;
+            return seg;
+        }
+        return 0;
     };
     // this wave's pieces of unit X(kt) / W(kt) into ring slot `slot`; only the 4 h pieces of the tile's rows of x are
     // fetched (h4 = 4 h: an integral_constant inside a tile's k-loop, so a full-height tile issues without branches)
     auto issue_x = [&](int kt, int slot, auto h4) {
+#ifdef BF_DEV
+        if (p.flags & 64) kt = 0;  // ablation: every k-step re-reads k-step 0 (operands L2-hot)
+#endif
         char* base = smem + slot * SLOT_BYTES + wid * 1024;
+        const int seg = segment(kt);
+        const T* xs = SEG ? xb + (long long)seg * p.x_seg_stride : xb;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i * 8 + 7 < h4 || i * 8 + wid < h4) piece(xb, xo[i], kt, base + i * 8192);
+            if (i * 8 + 7 < h4 || i * 8 + wid < h4) piece(xs, xo[i], kt * (TK * 2), base + i * 8192);
     };
     auto issue_w = [&](int kt, int slot) {
+#ifdef BF_DEV
+        if (p.flags & 64) kt = 0;
+#endif
         char* base = smem + slot * SLOT_BYTES + wid * 1024;
+        const int seg = segment(kt);
+        const T* ws = SEG ? wb + (long long)seg * p.w_seg_stride : wb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) piece(wb, wo[i], kt, base + i * 8192);
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (TRW) piece(ws, wo[0], (kt * TK + i * 16) * N * 2, base + i * 8192);
+            else piece(ws, wo[i], kt * (TK * 2), base + i * 8192);
+        }
     };
 
     // fragment reads: inline asm (the k-loop's own waits order them against the DMA and the MFMAs; the compiler's
@@ -111,8 +149,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(decltype(off)::value));
         return v;
     };
+    // contraction-major W unit: the 16 lanes of a group point at a [4 contraction rows][16 columns] block: lane -> row
+    // 8 lg + (li >> 2) of the 32-row half (the second read takes the 4 rows below: + 2 KiB, same key), 8 bytes (li & 3) of
+    // the block's 32-byte granule; granule' = granule ^ key(row).  Fragment block i of the wave: one XOR away.
+    const int tr_rl = ((lane & 15) >> 2) | (((lane >> 4) & 1) << 2);
+    const unsigned tr_w0 = lds0 + ((lane >> 4) * 8 + ((lane & 15) >> 2)) * 512 + (lane & 3) * 8 + (((wn * 4) ^ tr_rl) << 5);
+    auto tr_read = [&](unsigned a0, int blk, auto half) -> frag {
+        const unsigned a = a0 ^ (unsigned)(blk << 5);
+        constexpr int off = decltype(half)::value * 32 * 512;
+        s16x4_t lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"(off));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(off + 4 * 512));
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(frag, v);
+    };
 
-    const int nk = K / TK;
+    const int nk = SEG ? p.segs * (K / TK) : K / TK;
     const int4* __restrict__ sched = p.sched + blockIdx.x;
     const unsigned G = gridDim.x;
     int4 d = sched[0];
@@ -141,10 +193,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
             constexpr int H = decltype(hc)::value;
             f32x4_t acc[4][H];
             frag wf[4], xf[H];
-            auto read_frags = [&](unsigned aw, unsigned ax) {
-                static_for<0, 4>([&](auto ic) {
-                    wf[decltype(ic)::value] = lds_read(aw, std::integral_constant<int, decltype(ic)::value * 16 * ROW_BYTES>{});
-                });
+            auto read_frags = [&](int slot_w, int slot_x, auto half) {
+                constexpr int HF = decltype(half)::value;
+                const unsigned ax = xrow0 + slot_x * SLOT_BYTES + (HF ? foff1 : foff0);
+                if constexpr (TRW) {
+                    const unsigned aw = tr_w0 + slot_w * SLOT_BYTES;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wf[i] = tr_read(aw, i, half);
+                } else {
+                    const unsigned aw = wrow0 + slot_w * SLOT_BYTES + (HF ? foff1 : foff0);
+                    static_for<0, 4>([&](auto ic) {
+                        wf[decltype(ic)::value] = lds_read(aw, std::integral_constant<int, decltype(ic)::value * 16 * ROW_BYTES>{});
+                    });
+                }
                 static_for<0, H>([&](auto jc) {
                     xf[decltype(jc)::value] = lds_read(ax, std::integral_constant<int, decltype(jc)::value * 32 * ROW_BYTES>{});
                 });
@@ -166,7 +227,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                 if (ax >= NSLOT) ax -= NSLOT;
                 if (a3 >= NSLOT) a3 -= NSLOT;
                 if (a4 >= NSLOT) a4 -= NSLOT;
-                const unsigned sw = wrow0 + a * SLOT_BYTES, sx = xrow0 + ax * SLOT_BYTES;
                 auto dma0 = [&] {
                     if constexpr (MODE == 2) {
                         if (has_next) issue_x(0, a3, 4 * h2);
@@ -179,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 };
                 dma0();
-                read_frags(sw + foff0, sx + foff0);
+                read_frags(a, ax, std::integral_constant<int, 0>{});
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 mfmas();
@@ -187,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                 __builtin_amdgcn_s_barrier();
                 if constexpr (MODE == 0) issue_w(kt + 2, a4);
                 else if (has_next) issue_w(MODE == 1 ? 0 : 1, a4);
-                read_frags(sw + foff1, sx + foff1);
+                read_frags(a, ax, std::integral_constant<int, 1>{});
                 if (wm == 1) wait_all_but_newest();
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -250,9 +310,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     }
 }
 
-template <typename T, typename YT>
+template <typename T, typename YT, bool TRW, bool SEG>
 int launch_r5(const GemmParams& p, hipStream_t stream, int grid) {
-    hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT>), dim3(grid), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, TRW, SEG>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -260,7 +320,7 @@ int launch_r5(const GemmParams& p, hipStream_t stream, int grid) {
 }  // namespace
 
 bool bf_gemm256_r5_supported(const GemmParams& p, int w_dtype, int y_dtype) {
-    if (p.K < 2 * TK || p.segs > 1) return false;
+    if (p.K < 2 * TK) return false;
     if (y_dtype != w_dtype) return false;  // fp32 outputs stay on the burst kernel
     // an operand of one sample is addressed by 32-bit byte offsets
     if ((long long)p.M * p.K >= (1ll << 30) || (long long)p.N * p.K >= (1ll << 30)) return false;
@@ -268,6 +328,15 @@ bool bf_gemm256_r5_supported(const GemmParams& p, int w_dtype, int y_dtype) {
 }
 
 int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, int grid) {
-    if (w_dtype == BF_DT_BF16) return launch_r5<__bf16, __bf16>(p, stream, grid);
-    return launch_r5<_Float16, _Float16>(p, stream, grid);
+    if (p.segs > 1) BF_FAIL("bf_gemm256_r5: the forward form has no segments");
+    if (w_dtype == BF_DT_BF16) return launch_r5<__bf16, __bf16, false, false>(p, stream, grid);
+    return launch_r5<_Float16, _Float16, false, false>(p, stream, grid);
+}
+
+// NN form (x K-contiguous, W contraction-major as sampled, 16-bit out): y[s][m][k] = sum_n x[s][m][n] w[s][n][k]
+int bf_launch_gemm256_r5_nn(const GemmParams& p, int dtype, hipStream_t stream, int grid) {
+    const bool seg = p.segs > 1;
+    if (dtype == BF_DT_BF16)
+        return seg ? launch_r5<__bf16, __bf16, true, true>(p, stream, grid) : launch_r5<__bf16, __bf16, true, false>(p, stream, grid);
+    return seg ? launch_r5<_Float16, _Float16, true, true>(p, stream, grid) : launch_r5<_Float16, _Float16, true, false>(p, stream, grid);
 }
