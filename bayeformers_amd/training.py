@@ -29,10 +29,10 @@ class GradientBuckets:
     """Flat gradient buffers over the trainable parameters of a model, summed over the ranks of `group` while backward
     runs.  `zero()` before the forward, `finish()` after `backward()`; the parameters' `.grad` are views of the buffers
     (the optimizer updates from them directly).  Buckets hold one dtype each (the fp32 mu / rho masters apart from a
-    16-bit model's embeddings and LayerNorms) and every view starts on a 256-byte boundary, so the multi-tensor optimizer
-    kernels keep their vectorised path.  What it costs: one multi-tensor copy per bucket (the gradients backward produced
-    -> their slots), i.e. one extra read and write of the gradients per step — use it where there is something to
-    all-reduce (world > 1)."""
+    16-bit model's embeddings and LayerNorms); the slots are packed, odd-sized parameters last, so that all but those
+    start on a 256-byte boundary and the multi-tensor optimizer kernels keep their vectorised path.  What it costs: one
+    torch.cat per bucket (the gradients backward produced -> their slots), i.e. one extra read and write of the gradients per
+    step — use it where there is something to all-reduce (world > 1)."""
 
     ALIGN = 256  # bytes
 
@@ -52,7 +52,7 @@ class GradientBuckets:
         for ps in by_kind.values():
             cur, cur_bytes = [], 0
             for p in ps:
-                nb = self._padded(p) * p.element_size()
+                nb = p.numel() * p.element_size()
                 if cur and cur_bytes + nb > bucket_bytes:
                     self._close(cur)
                     cur, cur_bytes = [], 0
@@ -61,27 +61,29 @@ class GradientBuckets:
             if cur:
                 self._close(cur)
         self._works = []
-        self._seen = set()
-        self._hooks = [p.register_post_accumulate_grad_hook(self._arrived) for p in self.params]
-
-    def _padded(self, p) -> int:
-        q = self.ALIGN // p.element_size()
-        return (p.numel() + q - 1) // q * q
+        # tensor hooks (they see the gradient BEFORE it is accumulated): autograd keeps adopting the produced tensors as
+        # .grad; a post-accumulate hook made the training step 2 ms slower on its own
+        self._hooks = [p.register_hook(self._make_hook(p)) for p in self.params]
+        self._got = {}
 
     def _close(self, ps):
-        flat = torch.zeros(sum(self._padded(p) for p in ps), dtype=ps[0].dtype, device=ps[0].device)
+        # parameters whose size keeps the next one 256-byte aligned first, the odd-sized ones (a 2-element classifier bias)
+        # last: the slots are packed without padding, so that ONE torch.cat fills a bucket
+        q = self.ALIGN // ps[0].element_size()
+        ps = [p for p in ps if p.numel() % q == 0] + [p for p in ps if p.numel() % q != 0]
+        flat = torch.zeros(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
         off = 0
         for p in ps:
             self._views[p] = flat[off:off + p.numel()].view_as(p)
             self._bucket_of[p] = len(self.buckets)
-            off += self._padded(p)
+            off += p.numel()
         self.buckets.append([flat, ps, len(ps), False])
 
     def zero(self) -> None:
         """Start a step: gradients are None (autograd adopts the tensors backward produces, no accumulation kernels);
         a bucket is filled by ONE multi-tensor copy when its last gradient has arrived."""
         self._works = []
-        self._seen = set()
+        self._got = {}
         for b in self.buckets:
             b[2], b[3] = len(b[1]), False
         for p in self.params:
@@ -92,27 +94,29 @@ class GradientBuckets:
         if b[3]:
             return
         b[3] = True
-        have = [p for p in b[1] if p.grad is not None and p.grad is not self._views[p]]
-        if len(have) < len(b[1]):
+        have = [p for p in b[1] if p in self._got]
+        if len(have) == len(b[1]) and all(self._got[p].dtype == b[0].dtype for p in have):
+            # the usual case: one batched copy of the bucket's gradients into its flat buffer
+            torch.cat([self._got[p].reshape(-1) for p in b[1]], out=b[0])
+        else:
             b[0].zero_()  # some parameter of the bucket got no gradient this step: its slot must read zero
-        if have:
-            torch._foreach_copy_([self._views[p] for p in have], [p.grad for p in have])
-        for p in b[1]:
-            p.grad = self._views[p]
+            for p in have:
+                self._views[p].copy_(self._got[p])
         if self.distributed:
             self._works.append(dist.all_reduce(b[0], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def _arrived(self, p) -> None:
-        i = self._bucket_of[p]
-        if self.buckets[i][3]:
-            raise RuntimeError("GradientBuckets: a parameter received a gradient after its bucket had been sent — every "
-                               "trainable parameter must receive at most one accumulated gradient per backward()")
-        if p in self._seen:
-            return  # a parameter used twice: autograd has added the second gradient to the first
-        self._seen.add(p)
-        self.buckets[i][2] -= 1
-        if self.buckets[i][2] == 0:
-            self._launch(i)
+    def _make_hook(self, p):
+        def hook(grad):
+            i = self._bucket_of[p]
+            if self.buckets[i][3] or p in self._got:
+                raise RuntimeError("GradientBuckets: a parameter received a second gradient in one backward() (a module "
+                                   "used twice?) — every trainable parameter must be used once per step")
+            self._got[p] = grad
+            self.buckets[i][2] -= 1
+            if self.buckets[i][2] == 0:
+                self._launch(i)
+            return None
+        return hook
 
     def finish(self) -> None:
         """After backward(): send what has not been sent (parameters without a gradient this step) and wait."""
@@ -121,6 +125,9 @@ class GradientBuckets:
         for w in self._works:
             w.wait()
         self._works = []
+        self._got = {}
+        for p in self.params:  # the optimizer (and the clipping) read the reduced gradients from the flat buffers
+            p.grad = self._views[p]
 
     def flats(self) -> List[Tensor]:
         return [b[0] for b in self.buckets]

@@ -68,9 +68,8 @@ def test_gradient_buckets_and_clip_single_process():
     ps = [torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(2, 2)),
           torch.nn.Parameter(torch.randn(6).to(torch.bfloat16))]
     buckets = GradientBuckets(ps, bucket_bytes=600)
-    # one bucket per dtype and size limit: fp32 [2x2 + 5] (two 256-byte slots), fp32 [7x3] (one), bf16 [6]
-    assert sorted(len(b[1]) for b in buckets.buckets) == [1, 1, 2]
-    assert all((buckets._views[p].data_ptr() - buckets.buckets[buckets._bucket_of[p]][0].data_ptr()) % 256 == 0 for p in ps)
+    # one bucket per dtype and size limit (600 bytes): fp32 [2x2, 5, 7x3] = 120 bytes together, bf16 [6]
+    assert sorted(len(b[1]) for b in buckets.buckets) == [1, 3]
     buckets.zero()
     loss = (ps[0] ** 2).sum() + (3 * ps[1]).sum() + ps[2].sum() + (ps[3].float() * 2).sum()
     loss.backward()
