@@ -361,3 +361,25 @@ def test_sample_counter_wraps_modulo_2_32():
         lq = bo.gaussian_log_prob_f64(ew, mu, rho) + bo.gaussian_log_prob_f64(eb, bmu, brho)
         assert abs(lp[s, 1] / lq - 1) < 1e-6
     assert bf.random.get_state()[1] == (base + S) & 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("S,M,N,K", [(2, 300, 200, 128), (3, 1000, 776, 192), (1, 513, 259 * 8 // 8 * 8, 256), (10, 4096, 768, 768),
+                                     (2, 4096, 2304, 768), (2, 2048, 768, 3072)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_ring_kernel_is_bit_identical_to_the_burst_kernel(S, M, N, K, dt):
+    """The five-slot-ring forward kernel (16-bit outputs, csrc/bf_gemm256_r5.hip) and the burst kernel (which still serves
+    fp32 outputs, csrc/bf_gemm256.hip) run the same MFMA sequence: the ring's 16-bit result must be the burst kernel's
+    fp32 result rounded once — bit for bit, ragged tile edges included.  A wrong ring slot, a DMA piece read before it
+    landed or after it was overwritten would show here."""
+    g = torch.Generator(device="cuda").manual_seed(S * 1000 + M + N + K)
+    x = torch.randn(S, M, K, device="cuda", generator=g).to(dt)
+    w = (torch.randn(S, N, K, device="cuda", generator=g) * 0.1).to(dt)
+    b = torch.randn(S, N, device="cuda", generator=g)
+    y32 = ops.gemm_nt(x, w, b, S, M, N, K, M * K, torch.float32, 0)
+    for _ in range(3):  # a race would not fail every time
+        y16 = ops.gemm_nt(x, w, b, S, M, N, K, M * K, dt, 0)
+        assert torch.equal(y16, y32.to(dt))
+    # and against fp64 on a slice (both kernels could be wrong together)
+    ref = torch.einsum("mk,nk->mn", x[S - 1].double(), w[S - 1].double()) + b[S - 1].double()
+    tol = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    assert (y16[S - 1].double() - ref).abs().max().item() <= tol * ref.abs().max().item() + 1e-5 * K ** 0.5
