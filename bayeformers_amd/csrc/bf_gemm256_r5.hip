@@ -1,6 +1,7 @@
 // bf_gemm256_r5.hip — the forward form (NT: x [M][K], W_s [N][K], both K-contiguous) of the 256-wide sampled-weight GEMM
 // with its LDS run as a FIVE-SLOT RING of 32 KiB operand units: y[s] = x[s] W_s^T + b_s, F.linear at
-// /root/reference/bayeformers/nn/layers/linear.py:104 for all S samples in one launch.
+// /root/reference/bayeformers/nn/layers/linear.py:104 for all S samples in one launch.  The same body with the W unit
+// contraction-major (template flag TRW) is the NN form of the backward pass, dx[s] = dy[s] W_s.
 //
 // Same tile, waves, fragments, swizzle, schedule and epilogue as bf_gemm256.hip (read its header first).  What differs is
 // how a k-step's operands reach LDS.  There, a k-step's 64 KiB stage (x rows + W rows) is DMA'd in ONE burst of 8 pieces
