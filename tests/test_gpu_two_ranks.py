@@ -1,0 +1,100 @@
+"""The S-sharded harness and training step with the REAL HIP kernels under torch.distributed: two ranks that share the one
+GPU of the test box (gloo backend on CUDA tensors — RCCL refuses two ranks on one device; what differs from an N-GPU run is
+only the transport of the collectives).  Rank r runs its slice of the Monte-Carlo samples through the fused path; the
+all-reduced means, the all-gathered per-sample outputs, and — for the training step — the bucketed, all-reduced gradients
+and the updated parameters must equal the single-process run's."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EED
+
+
+def _build():
+    import bayeformers_amd as bf
+    from transformers import BertConfig, BertForSequenceClassification
+
+    cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, vocab_size=1000,
+                     max_position_embeddings=64)
+    torch.manual_seed(0)
+    model = BertForSequenceClassification(cfg).eval()
+    bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().cuda().to(torch.bfloat16)
+    assert bf.fuse_activations(bmodel) == 2 and bf.fuse_residual_layernorm(bmodel) == 4
+    assert bf.fuse_shared_inputs(bmodel) == 2 and bf.fuse_attention(bmodel) and bf.fuse_embeddings(bmodel) == 1
+    torch.manual_seed(7)
+    ids = torch.randint(0, cfg.vocab_size, (4, 32)).cuda()
+    labels = torch.randint(0, 2, (4,)).cuda()
+    inputs = {"input_ids": ids, "attention_mask": torch.ones(4, 32, dtype=torch.long, device="cuda")}
+    return bmodel, inputs, labels
+
+
+def _run(S, steps):
+    import bayeformers_amd as bf
+    from bayeformers_amd.sampling import sample_bayesian
+    from bayeformers_amd.training import GradientBuckets, training_step
+
+    bmodel, inputs, labels = _build()
+    bf.set_compute_dtype("bf16")
+    bf.manual_seed(SEED)
+    with torch.no_grad():
+        raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S, gather_raw=True)
+    fwd = (raw[0].float().cpu().numpy(), mean[0].float().cpu().numpy(), float(lp), float(lq))
+    params = [p for p in bmodel.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.5)
+    buckets = GradientBuckets(params, bucket_bytes=1 << 20)
+    grads = None
+    for _ in range(steps):
+        loss = training_step(bmodel, inputs, S, lambda m: torch.nn.functional.cross_entropy(m[0].float(), labels), opt,
+                             n_batches=100, buckets=buckets, max_grad_norm=1.0)
+        if grads is None:
+            grads = {n: p.grad.detach().float().cpu().numpy().copy() for n, p in bmodel.named_parameters() if p.grad is not None}
+    after = {n: p.detach().float().cpu().numpy().copy() for n, p in bmodel.named_parameters() if p.requires_grad}
+    return fwd, float(loss), grads, after
+
+
+def _worker(rank, world, port, S, steps, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank,) + _run(S, steps))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_match_single_process():
+    S, steps, world = 5, 2, 2  # uneven shards: 3 + 2 samples
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, S, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    fwd, loss, grads, after = _run(S, steps)
+    for rank, f, l, g, a in res:
+        # forward: every sample's outputs are bit-identical whatever rank ran it; the reduced quantities agree to rounding
+        assert np.array_equal(f[0], fwd[0]), rank
+        np.testing.assert_allclose(f[1], fwd[1], rtol=1e-2, atol=1e-3)
+        assert f[2] == pytest.approx(fwd[2], rel=1e-12) and f[3] == pytest.approx(fwd[3], rel=1e-12)
+        assert l == pytest.approx(loss, rel=1e-5)
+        # training: the ranks' summed gradients = the single-process gradients (bf16 activations: the per-rank partial
+        # sums are rounded separately), and every rank holds the same updated parameters
+        assert g.keys() == grads.keys()
+        for n in grads:
+            scale = np.abs(grads[n]).max() + 1e-30
+            assert np.abs(g[n] - grads[n]).max() <= 3e-2 * scale, (rank, n)
+        for n in after:
+            assert np.array_equal(a[n], res[0][4][n]), (rank, n)
