@@ -388,7 +388,7 @@ def launch_ranks(args) -> int:
     import subprocess
 
     have = visible_gpus()
-    if not args.dry_run and have is not None and have < args.gpus:
+    if not args.dry_run and have is not None and have < args.gpus and os.environ.get("BF_BENCH_SHARE_GPU") is None:
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
     with socket.socket() as sock:
@@ -436,10 +436,18 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo")
         return dry_run(args, world, rank, torch.device("cpu"))
+    # developer switches for exercising the N-rank path on a ONE-GPU box (never set by the driver): all ranks on cuda:0 and
+    # gloo collectives on the CUDA tensors (RCCL refuses two ranks on one device); the numbers of such a run mean nothing
+    share_gpu = os.environ.get("BF_BENCH_SHARE_GPU") is not None
+    if share_gpu:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group(os.environ.get("BF_BENCH_BACKEND", "gloo"))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         if dist.get_world_size() != args.gpus:
             print(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
             sys.exit(2)
