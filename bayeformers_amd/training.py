@@ -81,7 +81,7 @@ class GradientBuckets:
 
     def zero(self) -> None:
         """Start a step: gradients are None (autograd adopts the tensors backward produces, no accumulation kernels);
-        a bucket is filled by ONE multi-tensor copy when its last gradient has arrived."""
+        a bucket is filled by ONE torch.cat when its last gradient has arrived."""
         self._works = []
         self._got = {}
         for b in self.buckets:
