@@ -379,6 +379,9 @@ def test_ring_kernel_is_bit_identical_to_the_burst_kernel(S, M, N, K, dt):
     for _ in range(3):  # a race would not fail every time
         y16 = ops.gemm_nt(x, w, b, S, M, N, K, M * K, dt, 0)
         assert torch.equal(y16, y32.to(dt))
+    # one x shared by all samples (sample stride 0), no bias
+    x0 = x[0].contiguous()
+    assert torch.equal(ops.gemm_nt(x0, w, None, S, M, N, K, 0, dt, 0), ops.gemm_nt(x0, w, None, S, M, N, K, 0, torch.float32, 0).to(dt))
     # and against fp64 on a slice (both kernels could be wrong together)
     ref = torch.einsum("mk,nk->mn", x[S - 1].double(), w[S - 1].double()) + b[S - 1].double()
     tol = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
