@@ -22,6 +22,9 @@
 //     m-bands its 32 CUs re-read stay in its private 4 MiB L2 from one round to the next.
 // Requirements: K % 64 == 0, 16-byte aligned operands; M and N are arbitrary (edge rows are clamped on load and
 // masked on store).  Everything else goes to the generic kernel in bf_gemm.hip.
+// Since round 3 the forward with 16-bit outputs and the NN input-gradient form run bf_gemm256_r5.hip (the same tile, waves,
+// schedule and epilogue with the operands streamed through a five-slot LDS ring, K >= 128); this file keeps the schedule
+// builder, the fp32-output forward, K = 64, operands past 2^30 elements, and the TN weight-gradient form with its unit ring.
 #include <stdlib.h>
 
 #include <algorithm>
