@@ -176,6 +176,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     int n0 = (__builtin_amdgcn_readfirstlane(d.z) & 0xFFFFFF) * TN;
     setup_w(d);
     setup_x(d);
+#ifdef BF_DEV
+    // experiment: the workgroups of an XCD (blockIdx % 8) start (blockIdx / 8) * k * 64 cycles apart, k = flags bits 8..11
+    if (p.flags & 0xF00) {
+        const int steps = (int)(blockIdx.x >> 3) * ((p.flags >> 8) & 15);
+        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+#endif
     int a = 0;  // ring slot of W of the k-step about to run; X of that step sits in a + 1, X(+1) goes to a + 3, W(+2) to a + 4
     issue_w(0, 0);
     issue_x(0, 1, 4 * h);
@@ -236,6 +243,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                     }
                 };
                 auto wait_all_but_newest = [&] {
+#ifdef BF_DEV
+                    // ablation (WRONG results): the first two k-steps of a tile do not wait for the previous tile's stores
+                    if ((p.flags & 32) && MODE == 0 && kt < 2) { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); return; }
+#endif
                     if (MODE == 0 || has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 };

@@ -23,7 +23,9 @@ struct GemmParams {
     int segs;
     long long x_seg_stride, w_seg_stride;
     int flags;  // developer ablation bits, honoured by -DBF_DEV builds only (tools/): 1 = no DMA in the k-loop,
-                // 8 = no epilogue, 16 = no row mask, 64 = every k-step's DMA re-reads k-step 0 (operands L2-hot)
+                // 8 = no epilogue, 16 = no global stores, 64 = every k-step's DMA re-reads k-step 0 (operands L2-hot);
+                // ring kernel: 32 = the first two k-steps of a tile wait with vmcnt(24) (not held up by the previous tile's
+                // stores), bits 8..11 = k: the workgroups of an XCD start k * 64 cycles apart
 };
 
 // fast 256-wide LDS-DMA kernel (bf_gemm256.hip)
