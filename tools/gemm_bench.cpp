@@ -8,6 +8,8 @@
 // 128x128 kernel, 1 = round-1 fixed-tile kernel, 2 = scheduled kernel).  Every configuration is checked against
 // variant 0, then all of them are timed in interleaved rounds in this one process; median and best are reported.
 // A fourth field selects the forward form (BF_GEMM_NT_FORM): "2:12:0:1" = scheduled kernel, policy 12, no ablation, five-slot ring.
+// BF_BENCH_FLUSH=1|2|3|4: every timed launch is timed alone, after 512 MiB were written (nothing of the problem left in the
+// Infinity Cache): 1 = all cold, 2 = W read once more after the flush (W cache-hot), 3 = x hot, 4 = W and x hot.
 // BF_GEMM_ABLATE bits (dev build): 1 no DMA in the k-loop, 8 no epilogue, 16 no global stores, 64 L2-hot DMA.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -42,6 +44,12 @@ static float bf2f(uint16_t h) {
     float f;
     memcpy(&f, &u, 4);
     return f;
+}
+
+__global__ void touch_kernel(const uint4* __restrict__ p, size_t n, unsigned* sink) {
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc ^= p[i].x;
+    if (acc == 0x12345678u) *sink = acc;
 }
 
 struct Config {
@@ -166,6 +174,29 @@ int main(int argc, char** argv) {
         }
         printf("\n");
         std::vector<std::vector<double>> t(configs.size());
+        const int flush = getenv("BF_BENCH_FLUSH") ? atoi(getenv("BF_BENCH_FLUSH")) : 0;
+        if (flush) {
+            static void* big = nullptr;
+            static unsigned* sink = nullptr;
+            if (!big) {
+                CK(hipMalloc(&big, (size_t)512 << 20));
+                CK(hipMalloc((void**)&sink, 4));
+            }
+            for (int rd = 0; rd < 3 * rounds + 1; ++rd)
+                for (size_t ci = 0; ci < configs.size(); ++ci) {
+                    select(configs[ci]);
+                    CK(hipMemsetAsync(big, rd & 0xFF, (size_t)512 << 20, nullptr));
+                    if (flush == 2 || flush == 4) hipLaunchKernelGGL(touch_kernel, dim3(2048), dim3(256), 0, nullptr, (const uint4*)dw, nw * 2 / 16, sink);
+                    if (flush == 3 || flush == 4) hipLaunchKernelGGL(touch_kernel, dim3(2048), dim3(256), 0, nullptr, (const uint4*)dx, nx * 2 / 16, sink);
+                    CK(hipEventRecord(e0, nullptr));
+                    call(dy1);
+                    CK(hipEventRecord(e1, nullptr));
+                    CK(hipEventSynchronize(e1));
+                    float ms = 0;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (rd) t[ci].push_back(ms);
+                }
+        } else
         for (int rd = 0; rd < rounds + 1; ++rd)
             for (size_t ci = 0; ci < configs.size(); ++ci) {
                 select(configs[ci]);
