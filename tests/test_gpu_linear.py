@@ -386,3 +386,36 @@ def test_ring_kernel_is_bit_identical_to_the_burst_kernel(S, M, N, K, dt):
     ref = torch.einsum("mk,nk->mn", x[S - 1].double(), w[S - 1].double()) + b[S - 1].double()
     tol = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
     assert (y16[S - 1].double() - ref).abs().max().item() <= tol * ref.abs().max().item() + 1e-5 * K ** 0.5
+
+
+@pytest.mark.parametrize("S,M,N,K,what", [
+    (3, (1 << 19) + 300, 256, 1024, "ring kernel, samples 1 and 2 start beyond 2^30 / 2^31 bytes of x"),
+    (1, (1 << 20) + 300, 256, 1024, "one sample of x >= 2^30 elements: beyond the ring kernel's 32-bit byte offsets -> burst kernel"),
+    (2, (1 << 17) + 44, 8192, 128, "outputs: a sample of y is 2^31 bytes, the second starts beyond 2^32 bytes"),
+    (1, (1 << 18) + 8, 8192, 128, "a sample of y >= 2^31 elements: beyond the tiled kernels' output index -> generic kernel"),
+])
+def test_operands_across_the_32_bit_boundaries(S, M, N, K, what):
+    """Offsets inside one sample are 32-bit in the tiled kernels (byte offsets of the DMA pieces, element indices of the
+    output rows), sample bases are 64-bit: operands whose extents straddle 2^30 / 2^31 / 2^32 must come out right in their
+    first and last rows and on both sides of every boundary, or be routed to a kernel that takes them
+    (csrc/bf_gemm256.hip: bf_gemm256_supported, csrc/bf_gemm256_r5.hip: bf_gemm256_r5_supported)."""
+    dt = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.empty(S, M, K, device="cuda", dtype=dt)
+    for s in range(S):  # filled per sample: no fp32 temporary of the whole tensor
+        x[s] = torch.randn(M, K, device="cuda", generator=g).to(dt)
+    w = (torch.randn(S, N, K, device="cuda", generator=g) * 0.1).to(dt)
+    b = torch.randn(S, N, device="cuda", generator=g)
+    y = ops.gemm_nt(x, w, b, S, M, N, K, M * K, dt, 0)
+    rows = {0, 1, 255, 256, M - 257, M - 2, M - 1}
+    for boundary in (1 << 29, 1 << 30, 1 << 31, 1 << 32):  # in elements and in bytes, of x rows and of y rows
+        for per_row in (K, 2 * K, N, 2 * N):
+            r = boundary // per_row
+            rows.update(q for q in (r - 1, r, r + 1) if 0 <= q < M)
+    idx = torch.tensor(sorted(rows), device="cuda")
+    for s in range(S):
+        ref = x[s, idx].double() @ w[s].double().T + b[s].double()
+        err = (y[s, idx].double() - ref).abs().max().item()
+        assert err <= 2.0 ** -8 * ref.abs().max().item() + 1e-5 * K ** 0.5, (what, s, err)
+    del x, y
+    torch.cuda.empty_cache()
