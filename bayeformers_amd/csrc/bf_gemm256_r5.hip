@@ -220,6 +220,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
             auto mfmas = [&] {
+#ifdef BF_DEV
+                if (p.flags & 8192) __builtin_amdgcn_s_setprio(0);  // experiment: no priority for the MFMA slot
+                else
+#endif
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -250,25 +254,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                     if (MODE == 0 || has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 };
+#ifdef BF_DEV
+                // experiment (flags bit 12): one barrier per k-step from the tile's second k-step on — the one that carries
+                // the landed / released units (group 0: after M1, group 1: after L1); the slots in between run unlocked
+                const bool relaxed = (p.flags & 4096) != 0;
+                const bool lock = !(relaxed && kt > 0);
+#else
+                constexpr bool relaxed = false, lock = true;
+#endif
                 dma0();
                 read_frags(a, ax, std::integral_constant<int, 0>{});
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
+                if (lock) __builtin_amdgcn_s_barrier();
                 mfmas();
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
+                if (lock) __builtin_amdgcn_s_barrier();
                 if constexpr (MODE == 0) issue_w(kt + 2, a4);
                 else if (has_next) issue_w(MODE == 1 ? 0 : 1, a4);
                 read_frags(a, ax, std::integral_constant<int, 1>{});
                 if (wm == 1) wait_all_but_newest();
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
+                if (lock || wm == 1) __builtin_amdgcn_s_barrier();
                 mfmas();
                 if (wm == 0) wait_all_but_newest();
                 __builtin_amdgcn_sched_barrier(0);
                 // (group 1 does not meet group 0 again before the tile-end barrier: its last slot ends without one, which
                 // also keeps the two groups' barrier counts equal)
-                if (!(MODE == 2 && wm == 1)) __builtin_amdgcn_s_barrier();
+                if (!(MODE == 2 && wm == 1) && !(relaxed && wm == 1)) __builtin_amdgcn_s_barrier();
                 a += 2;
                 if (a >= NSLOT) a -= NSLOT;
             };

@@ -25,7 +25,8 @@ struct GemmParams {
     int flags;  // developer ablation bits, honoured by -DBF_DEV builds only (tools/): 1 = no DMA in the k-loop,
                 // 8 = no epilogue, 16 = no global stores, 64 = every k-step's DMA re-reads k-step 0 (operands L2-hot);
                 // ring kernel: 32 = the first two k-steps of a tile wait with vmcnt(24) (not held up by the previous tile's
-                // stores), bits 8..11 = k: the workgroups of an XCD start k * 64 cycles apart
+                // stores), bits 8..11 = k: the workgroups of an XCD start k * 64 cycles apart, 4096 = one barrier per k-step from a
+                // tile's second k-step on, 8192 = no s_setprio around the MFMA slots
 };
 
 // fast 256-wide LDS-DMA kernel (bf_gemm256.hip)
