@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--workload", default="bert_base", choices=["bert_base", "bert_large_qa", "linear768", "linear768_m32", "mlp", "bert_base_train"])
     ap.add_argument("--samples", type=int, default=None, help="MC samples per GPU per step (default: workload's)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --samples is the TOTAL number of MC samples per step, sharded over the ranks "
+                         "(uneven shards allowed: BASELINE.json configs[4] asks for S=10 on 8 GPUs = 2,2,1,1,1,1,1,1); "
+                         "the default is weak scaling, --samples per GPU, which is what the driver's scaling run measures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-mode", action="store_true",
                     help="bert_base_train only: put the model in .train() like examples/bert_glue.py:221 (HF dropout p = 0.1 "
@@ -60,9 +64,17 @@ def parse():
     return ap.parse_args()
 
 
+_STRONG = False  # --strong: S is the total per step
+
+
 def _world() -> int:
-    """Ranks of the S-shard group.  Weak scaling: S is the number of Monte-Carlo samples PER GPU, a step draws S * world
-    samples and sample_bayesian hands every rank its S of them."""
+    """What a workload multiplies its S by to get the samples of a step.  Weak scaling (default): S is the number of
+    Monte-Carlo samples PER GPU, a step draws S * world samples and sample_bayesian hands every rank its S of them.
+    --strong: S is the total, sample_bayesian shards it (unevenly if it must)."""
+    return 1 if _STRONG else _ranks()
+
+
+def _ranks() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
@@ -123,7 +135,7 @@ def make_bert(device, S, dtype, train=False, train_mode=False):
         params = [p for p in bmodel.parameters() if p.requires_grad]
         opt = torch.optim.AdamW(params, lr=2e-5, eps=1e-8, weight_decay=0.0, fused=True)
         # world > 1: flat gradient buffers, all-reduced over the ranks while backward runs
-        buckets = GradientBuckets(params) if _world() > 1 or os.environ.get("BF_BENCH_TRAIN_BUCKETS") is not None else None
+        buckets = GradientBuckets(params) if _ranks() > 1 or os.environ.get("BF_BENCH_TRAIN_BUCKETS") is not None else None
 
         def nll_fn(mean):
             return torch.nn.functional.cross_entropy(mean[0].float(), labels_d)
@@ -418,7 +430,9 @@ def dry_run(args, world, rank, device):
 
 
 def main():
+    global _STRONG
     args = parse()
+    _STRONG = bool(args.strong)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -597,15 +611,20 @@ def main():
                 roofline["traffic_detail"] = {"unit": "bytes per GEMM launch (mean over the step's launches)",
                                               "hbm_fetch": round(tr["fetch_bytes"]), "hbm_write": round(tr["write_bytes"]),
                                               "algorithmic": alg_gemm_bytes(bmodel, cfgd, S, dtype)}
-        total_samples = S * world * args.steps
         n_ranks = dist.get_world_size() if world > 1 else 1
+        per_step = S if args.strong else S * n_ranks
+        total_samples = per_step * args.steps
+        if args.strong:
+            from bayeformers_amd.sampling import shard_span
+
+            cfgd["samples_per_gpu"] = [shard_span(S, r, n_ranks)[1] for r in range(n_ranks)]
         cfgd.update({"parallelism": f"mc-sample-shard x{n_ranks}", "last_elbo": last, "hip_graph": bool(use_graph),
-                     "samples_total": total_samples, "samples_per_step": S * n_ranks,
+                     "samples_total": total_samples, "samples_per_step": per_step,
                      "allreduce_ms_per_step": round(allreduce_ms, 4) if allreduce_ms is not None else None})
         metric = "MC-samples/sec (fwd+ELBO+backward+AdamW)" if args.workload.endswith("_train") else "MC-samples/sec (fwd+ELBO)"
         out = {"metric": metric, "value": round(total_samples / dt, 3), "unit": "MC-samples/s",
                "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+               "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": cfgd, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
