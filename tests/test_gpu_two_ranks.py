@@ -98,3 +98,31 @@ def test_two_ranks_on_one_gpu_match_single_process():
             assert np.abs(g[n] - grads[n]).max() <= 3e-2 * scale, (rank, n)
         for n in after:
             assert np.array_equal(a[n], res[0][4][n]), (rank, n)
+
+
+def test_bench_strong_scaling_shards_one_total_unevenly():
+    """`bench.py --strong --samples 5 --gpus 2` (BASELINE configs[4]'s kind of split: the step's samples are a TOTAL,
+    sharded 3 + 2) must report the same ELBO as the one-rank run of the same 5 samples, and say what it did."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--workload", "mlp", "--samples", "5", "--steps", "2", "--warmup", "1",
+            "--no-traffic", "--no-cpu-baseline", "--graph", "off"]  # a captured step runs extra steps before the timed ones
+
+    def run(extra, env_extra):
+        env = dict(os.environ, **env_extra)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        out = subprocess.run(base + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    one = run([], {})
+    two = run(["--gpus", "2", "--strong"], {"BF_BENCH_SHARE_GPU": "1", "BF_BENCH_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and one["scaling"] == "weak" and one["config"]["samples_per_step"] == 5
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["samples_per_gpu"] == [3, 2] and two["config"]["samples_per_step"] == 5
+    assert two["config"]["samples_total"] == 10
+    assert abs(two["config"]["last_elbo"] - one["config"]["last_elbo"]) <= 1e-9 * abs(one["config"]["last_elbo"])
