@@ -166,16 +166,18 @@ def _embeddings_forward(self, input_ids=None, token_type_ids=None, position_ids=
         # repeat of it (the block is deterministic without dropout, every copy gets the same rows): the table gradients
         # are then scattered from B*T rows instead of S*B*T, after one sum over the copies
         rep = getattr(input_ids, "_bf_repeat", None) if input_ids is not None else None
-        if rep is not None and inputs_embeds is None and not (self.training and self.dropout.p > 0):
-            S, orig = rep
+        orig = rep[1]() if rep is not None else None  # (samples, weak reference to the tensor the ids repeat)
+        if orig is not None and inputs_embeds is None and not (self.training and self.dropout.p > 0):
+            S = rep[0]
             B = orig.shape[0]
 
             def one_copy(t):  # a per-row companion of the ids: None, its own original, or rows that cannot differ
                 if t is None or t.shape[0] == 1:
                     return t, True
                 r = getattr(t, "_bf_repeat", None)
-                if r is not None and r[0] == S and r[1].shape[0] == B:
-                    return r[1], True
+                src = r[1]() if r is not None else None
+                if src is not None and r[0] == S and src.shape[0] == B:
+                    return src, True
                 if t.shape[0] == S * B and t.stride(0) == 0:
                     return t[:B], True
                 return None, False

@@ -730,17 +730,23 @@ int get_schedule(int S, int layers, int tiles_n, int M, int policy, hipStream_t 
     if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
         BF_FAIL("bf_gemm_nt: the first launch of a shape (S=%d M=%d) builds its tile schedule and allocates device "
                 "memory; call bf_gemm_prepare() for it, or run the step once, before capturing it into a graph", S, M);
-    // (variable-length batches: every new M is a new shape — keep the cache bounded; an evicted table is rebuilt on demand.
-    // Kernels already enqueued keep reading theirs: the memory is released with hipFreeAsync-like ordering by freeing only
-    // after a device synchronisation, which 256 evictions apart is rare enough not to matter)
-    if (g_sched.size() >= 256) {
-        BF_HIP_CHECK(hipDeviceSynchronize());
-        for (auto& kv : g_sched) (void)hipFree(kv.second.d_table);
-        g_sched.clear();
-    }
+    // Tables are NEVER freed or rewritten: a captured HIP graph keeps the raw d_table pointer in its kernel arguments
+    // (bf_gemm_prepare / bench --graph), so a table must stay valid for the life of the process.  Variable-length batches
+    // make every new M a new shape; a table is a few KB to a few hundred KB, so the cache is bounded by BYTES per device
+    // (default 1 GiB, BF_GEMM_SCHED_CACHE_BYTES) and a shape past the bound is refused loudly instead of evicting.
+    static std::map<int, size_t> bytes_of;
+    static const size_t cap = [] {
+        const char* e = getenv("BF_GEMM_SCHED_CACHE_BYTES");
+        const long long v = e ? atoll(e) : 0;
+        return v > 0 ? (size_t)v : ((size_t)1 << 30);
+    }();
     std::vector<int4> table;
     Sched sc;
     build_schedule(S, layers, tiles_n, M, n_cu, policy, table, sc.rounds, sc.grid);
+    if (bytes_of[dev] + table.size() * sizeof(int4) > cap)
+        BF_FAIL("bf_gemm_nt: the tile schedules of this device already hold %zu bytes (%zu shapes in the process); raise "
+                "BF_GEMM_SCHED_CACHE_BYTES (now %zu) or bucket the batch sizes", bytes_of[dev], g_sched.size(), cap);
+    bytes_of[dev] += table.size() * sizeof(int4);
     BF_HIP_CHECK(hipMalloc((void**)&sc.d_table, table.size() * sizeof(int4)));
     BF_HIP_CHECK(hipMemcpy(sc.d_table, table.data(), table.size() * sizeof(int4), hipMemcpyHostToDevice));
     g_sched[key] = sc;

@@ -62,7 +62,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     // that issues that tile's W(0), the x half one k-step later.
     const T* xb;
     const T* wb;
-    unsigned xo[4], wo[4];
+    unsigned xo, wo;  // per-lane byte offset of piece 0 (rows 8 wid .. 8 wid + 7); piece i lies 64 rows = `rowblk` bytes further
+    const unsigned rowblk = 64u * (unsigned)K * 2u;
+    // An operand is fetched through a buffer descriptor that ends with the sample's operand: rows past M (N) of a partial
+    // tile are out of range and arrive as zeros (their products land in rows / columns the epilogue masks) — no per-row
+    // clamp, so ONE offset register per operand instead of four.
+    unsigned x_bytes, w_bytes;
     auto setup_w = [&](const int4 d) {
         const int s = __builtin_amdgcn_readfirstlane(d.x);
         const int n0 = (__builtin_amdgcn_readfirstlane(d.z) & 0xFFFFFF) * TN;
@@ -74,13 +79,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
             asm volatile("" : "+v"(ln));
             const int tr_r = wid * 2 + (ln >> 5);
             const int tr_c = (ln & 31) ^ (((tr_r & 3) | ((tr_r >> 1) & 4)) << 1);
-            wo[0] = ((unsigned)tr_r * (unsigned)N + (unsigned)min(n0 + tr_c * 8, N - 8)) * 2u;
+            wo = ((unsigned)tr_r * (unsigned)N + (unsigned)min(n0 + tr_c * 8, N - 8)) * 2u;
+            w_bytes = 0x7FFFFFFF;
         } else {
             int prow, kc8;
             piece_lane(prow, kc8);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                wo[i] = ((unsigned)min(n0 + (i * 8 + wid) * 8 + prow, N - 1) * (unsigned)K + kc8) * 2u;
+            wo = ((unsigned)(n0 + wid * 8 + prow) * (unsigned)K + kc8) * 2u;
+            w_bytes = (unsigned)N * (unsigned)K * 2u;
         }
     };
     auto setup_x = [&](const int4 d) {
@@ -88,16 +93,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         xb = reinterpret_cast<const T*>(p.x) + (long long)__builtin_amdgcn_readfirstlane(d.y) * p.x_sstride;
         int prow, kc8;
         piece_lane(prow, kc8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            xo[i] = ((unsigned)min(m0 + (i * 8 + wid) * 8 + prow, M - 1) * (unsigned)K + kc8) * 2u;
+        xo = ((unsigned)(m0 + wid * 8 + prow) * (unsigned)K + kc8) * 2u;
+        x_bytes = (unsigned)M * (unsigned)K * 2u;
     };
-    // one 1 KiB piece: `base` + per-lane byte offset `off` + wave-uniform byte offset `soff` -> LDS `dst`
-    auto piece = [&](const T* base, unsigned off, int soff, char* dst) {
+    // one 1 KiB piece: `base` (a buffer of `bytes`) + per-lane byte offset `off` + wave-uniform byte offset `soff` -> LDS `dst`
+    auto piece = [&](const T* base, unsigned bytes, unsigned off, int soff, char* dst) {
 #ifdef BF_DEV
         if (p.flags & 1) return;  // ablation: no DMA in the k-loop
 #endif
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)bytes, 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, (int)off, soff, 0, 0);
     };
     // segmented contraction: k-step kt lies in segment kt / (K / TK) (wave-uniform arithmetic)
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         const T* xs = SEG ? xb + (long long)seg * p.x_seg_stride : xb;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i * 8 + 7 < h4 || i * 8 + wid < h4) piece(xs, xo[i], kt * (TK * 2), base + i * 8192);
+            if (i * 8 + 7 < h4 || i * 8 + wid < h4) piece(xs, x_bytes, xo + i * rowblk, kt * (TK * 2), base + i * 8192);
     };
     auto issue_w = [&](int kt, int slot) {
 #ifdef BF_DEV
@@ -132,8 +136,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         const T* ws = SEG ? wb + (long long)seg * p.w_seg_stride : wb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if constexpr (TRW) piece(ws, wo[0], (kt * TK + i * 16) * N * 2, base + i * 8192);
-            else piece(ws, wo[i], kt * (TK * 2), base + i * 8192);
+            if constexpr (TRW) piece(ws, w_bytes, wo, (kt * TK + i * 16) * N * 2, base + i * 8192);
+            else piece(ws, w_bytes, wo + i * rowblk, kt * (TK * 2), base + i * 8192);
         }
     };
 
@@ -166,9 +170,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     };
 
     const int nk = SEG ? p.segs * (K / TK) : K / TK;
-    const int4* __restrict__ sched = p.sched + blockIdx.x;
+    // the schedule is read through the scalar cache (it was written before the launch): entries arrive in SGPRs
+    typedef int sched_i32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) sched_i32x4 sched_entry;
+    sched_entry* sched = (sched_entry*)(uintptr_t)(p.sched + blockIdx.x);
+    auto entry = [&](unsigned i) -> int4 {
+        const sched_i32x4 e = sched[i];
+        return int4{e.x, e.y, e.z, e.w};
+    };
     const unsigned G = gridDim.x;
-    int4 d = sched[0];
+    int4 d = entry(0);
     if ((d.z >> 24) == 0) return;
     int s = __builtin_amdgcn_readfirstlane(d.x);
     int h = __builtin_amdgcn_readfirstlane(d.z) >> 24;
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     int round = 0;
     for (;;) {
         int4 dn = {0, 0, 0, 0};
-        if (round + 1 < p.sched_rounds) dn = sched[(unsigned)(round + 1) * G];
+        if (round + 1 < p.sched_rounds) dn = entry((unsigned)(round + 1) * G);
         const int h2 = __builtin_amdgcn_readfirstlane(dn.z) >> 24;
         const bool has_next = h2 != 0;
 
@@ -217,6 +228,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                 static_for<0, H>([&](auto jc) {
                     xf[decltype(jc)::value] = lds_read(ax, std::integral_constant<int, decltype(jc)::value * 32 * ROW_BYTES>{});
                 });
+#ifdef BF_DEV
+                if (p.flags & 16384) return;  // ablation (WRONG results): the L slot does not wait for its fragment reads
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
             auto mfmas = [&] {
@@ -347,7 +361,8 @@ bool bf_gemm256_r5_supported(const GemmParams& p, int w_dtype, int y_dtype) {
     if (p.K < 2 * TK) return false;
     if (y_dtype != w_dtype) return false;  // fp32 outputs stay on the burst kernel
     // an operand of one sample is addressed by 32-bit byte offsets
-    if ((long long)p.M * p.K >= (1ll << 30) || (long long)p.N * p.K >= (1ll << 30)) return false;
+    // (rows of a partial last tile are addressed past M / N before the buffer's range check drops them: + one tile)
+    if ((long long)(p.M + 256) * p.K >= (1ll << 30) || (long long)(p.N + 256) * p.K >= (1ll << 30)) return false;
     return true;
 }
 

@@ -46,6 +46,7 @@ class _ForwardContext:
         self.token = next(_TOKENS)
         self.shared_out = {}  # id(first layer of a stacked run) -> (input identity, [L, S, M, N] outputs)
         self.counter = bfr.counter_snapshot()  # device-counter mode: the counter value this forward's kernels added
+        self.graph_tasks = set()  # ids of the backward passes that reached this forward's outputs (bfr.remember_context)
 
     @contextlib.contextmanager
     def replay(self):
@@ -150,13 +151,21 @@ class Model(Module):
         base = bfr.reserve_samples(total) + start
         self._last_base, self._last_seed, self._last_S = base, bfr.STATE.seed, S
         self._last_counter = bfr.counter_snapshot() if bfr.STATE.kl_gradient else None
-        bfr.STATE.ctx = _ForwardContext(base, S, slots, plan, self._lp_buf)
+        ctx = bfr.STATE.ctx = _ForwardContext(base, S, slots, plan, self._lp_buf)
+        out = None
         try:
-            return super(Model, self).__call__(*args, **kwargs)
+            out = super(Model, self).__call__(*args, **kwargs)
+            return out
         finally:
             if plan is not None:
                 plan.finish(self._lp_buf)  # one log-prob reduction for all the groups this forward sampled
-            bfr.STATE.last_ctx, bfr.STATE.ctx = bfr.STATE.ctx, None
+            bfr.STATE.ctx = None
+            # what a finished forward keeps is what a checkpointed block's recomputation needs (sample indices, slots,
+            # plan, counter): NOT the stacked query/key/value outputs and their inputs — a replay re-keys on data_ptr and
+            # computes them again anyway, and holding them would pin ~3 GB of a BERT-base step until the next forward
+            ctx.shared_out = {}
+            if torch.is_grad_enabled() and out is not None:
+                bfr.remember_context(ctx, out)
             bfr.commit_samples(total)
 
     @contextlib.contextmanager

@@ -27,7 +27,7 @@ class _State:
         self.seed = DEFAULT_SEED
         self.next_sample = 0
         self.ctx = None  # (sample_base, S) while a bnn.Model forward is running
-        self.last_ctx = None  # the context of the last finished bnn.Model forward (recompute_context)
+        self.live_ctxs = []  # finished grad-enabled bnn.Model forwards whose graphs may still run backward (recompute_context)
         self.compute_dtype = torch.bfloat16
         self.next_layer_id = 0
         self.device_counter = None  # 1-element int32 device tensor when the sample counter lives on the GPU
@@ -100,18 +100,64 @@ def get_compute_dtype() -> torch.dtype:
     return STATE.compute_dtype
 
 
-def recompute_context():
-    """The context of the last bnn.Model forward, when a Bayesian layer is called with no forward running WHILE autograd
-    executes a backward pass: that is the recomputation of a checkpointed block (torch.utils.checkpoint), which must draw
-    the epsilon of the forward it repeats — the same sample indices, the same (device) counter value — not fresh ones."""
-    c = STATE.last_ctx
-    if c is None:
-        return None
+def _graph_task_id() -> int:
     try:
-        in_backward = torch._C._current_graph_task_id() != -1
+        return torch._C._current_graph_task_id()
     except AttributeError:  # pragma: no cover - private API of the installed torch
-        in_backward = False
-    return c if in_backward else None
+        return -1
+
+
+LIVE_CONTEXTS = 4  # finished forwards remembered for the recomputation of their checkpointed blocks
+
+
+def remember_context(ctx, output) -> None:
+    """Called at the end of a grad-enabled bnn.Model forward: keeps its (slimmed) context for `recompute_context` and
+    binds it to the autograd graph it produced — a hook on the grad_fn of every output tensor stamps the context with the
+    id of the backward pass that reaches it, so a checkpointed block recomputed during THAT backward finds the forward it
+    belongs to even when other forwards (a second loss, an evaluation pass, another model) ran in between."""
+    def tensors(o, depth=0):
+        if isinstance(o, torch.Tensor):
+            yield o
+        elif depth < 3 and isinstance(o, dict):
+            for v in o.values():
+                yield from tensors(v, depth + 1)
+        elif depth < 3 and isinstance(o, (tuple, list)):
+            for v in o:
+                yield from tensors(v, depth + 1)
+
+    def stamp(*_):
+        tid = _graph_task_id()
+        if tid != -1:
+            ctx.graph_tasks.add(tid)
+
+    seen = set()
+    for t in tensors(output):
+        fn = t.grad_fn
+        if fn is not None and id(fn) not in seen:
+            seen.add(id(fn))
+            fn.register_prehook(stamp)
+    STATE.live_ctxs.append(ctx)
+    del STATE.live_ctxs[:-LIVE_CONTEXTS]
+
+
+def recompute_context():
+    """The context of the bnn.Model forward a Bayesian layer belongs to when it is called with no forward running WHILE
+    autograd executes a backward pass: that is the recomputation of a checkpointed block (torch.utils.checkpoint), which
+    must draw the epsilon of the forward it repeats — the same sample indices, the same (device) counter value — not fresh
+    ones.  The forward is the one whose outputs this backward pass has reached (`remember_context`); if that is not
+    unique (two forwards of checkpointed models in one backward, e.g. loss1 + loss2) the call raises instead of guessing."""
+    tid = _graph_task_id()
+    if tid == -1 or not STATE.live_ctxs:
+        return None
+    hit = [c for c in STATE.live_ctxs if tid in c.graph_tasks]
+    if len(hit) == 1:
+        return hit[0]
+    if not hit and len(STATE.live_ctxs) == 1:
+        return STATE.live_ctxs[0]  # the loss was built on something other than the model's outputs: the only candidate
+    raise RuntimeError(
+        "bayeformers_amd: a Bayesian layer is being recomputed during backward (a checkpointed block) and "
+        f"{len(hit) or len(STATE.live_ctxs)} finished bnn.Model forwards could own it; run backward() after each "
+        "grad-enabled forward of a checkpointed model (evaluation passes belong under torch.no_grad())")
 
 
 def new_layer_id() -> int:

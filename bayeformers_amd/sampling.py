@@ -39,7 +39,9 @@ def _repeat_cached(v: Tensor, samples: int) -> Tensor:
             and hit[4]._version == hit[5]):
         return hit[4]
     out = v.repeat(samples, *([1] * (v.dim() - 1)))
-    out._bf_repeat = (samples, v)  # what it is made of: consumers that are the same for every copy use the original
+    # what it is made of (consumers that are the same for every copy use the original) — by WEAK reference, like the cache
+    # entry: the copy must not keep its source alive
+    out._bf_repeat = (samples, weakref.ref(v))
     if out.numel() * out.element_size() > (64 << 20):
         return out  # large inputs are not worth pinning
     if key not in _REPEAT_CACHE and len(_REPEAT_CACHE) >= _REPEAT_CACHE_SIZE:

@@ -15,6 +15,7 @@ point-to-point (7 links of ~153 GB/s per GPU) and a ring all-reduce is bound per
 (default 128 MiB: BERT-base's 342 MB of d rho in three) beat DDP's 25 MiB default; the last bucket — the first
 layers' gradients — is the only one that cannot hide under backward.
 """
+import weakref
 from typing import Callable, Iterable, List, Optional
 
 import torch
@@ -23,6 +24,9 @@ from torch import Tensor
 
 from .nn.model import Model
 from .sampling import elbo, sample_bayesian
+
+
+_BUCKETS_OF: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()  # optimizer -> the buckets training_step built for it
 
 
 class GradientBuckets:
@@ -174,6 +178,17 @@ def training_step(model: Model, inputs, samples: int, nll_fn: Callable, optimize
 
     nll_fn(mean_outputs) -> scalar negative log-likelihood of the MEAN outputs (a tuple, as sample_bayesian returns).
     Every rank ends the step with the same parameters.  Returns the (detached) ELBO loss."""
+    if buckets is None:
+        # S-sharded ranks each hold the gradient of THEIR samples: without a reduction they would step apart.  The
+        # buckets of an optimizer are built once and kept with it.
+        sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if sharded:
+            buckets = _BUCKETS_OF.get(optimizer)
+            if buckets is None or buckets.group is not group:
+                if buckets is not None:
+                    buckets.remove()
+                buckets = _BUCKETS_OF[optimizer] = GradientBuckets(
+                    [p for g in optimizer.param_groups for p in g["params"]], group=group)
     if buckets is not None:
         buckets.zero()
     else:
@@ -187,5 +202,12 @@ def training_step(model: Model, inputs, samples: int, nll_fn: Callable, optimize
         grads = buckets.flats() if buckets is not None else [p.grad for g in optimizer.param_groups for p in g["params"]
                                                              if p.grad is not None]
         clip_gradients(optimizer, grads, max_grad_norm)
-    optimizer.step()
+    try:
+        optimizer.step()
+    finally:
+        # the clipping factor belongs to THIS step (torch.amp's GradScaler removes the two attributes the same way): a
+        # later step without clipping must not divide its gradients by a stale one
+        for name in ("grad_scale", "found_inf"):
+            if hasattr(optimizer, name):
+                delattr(optimizer, name)
     return loss.detach()

@@ -151,3 +151,55 @@ def test_header_is_plain_c_and_every_entry_links_from_c(tmp_path):
                     "-L", libdir, "-lbayeformers_amd", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert out[-1] == str(len(names)) and int(out[0]) == _C.lib().bf_version()
+
+
+def test_recompute_context_is_bound_to_the_graph_that_runs_backward():
+    """A checkpointed block recomputed during backward must replay the sample indices of the forward that backward belongs
+    to — not those of whatever bnn.Model forward finished last (an evaluation pass, another model, a second loss)."""
+    import torch.utils.checkpoint as cp
+
+    from bayeformers_amd import random as bfr
+    from bayeformers_amd.nn.model import Model
+
+    seen = []
+
+    class Probe(torch.nn.Module):
+        """Stands in for a Bayesian layer: outside a running forward it asks for the recompute context, like
+        bnn.Linear.forward does, and records the sample base it would draw epsilon from."""
+
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(3))
+
+        def forward(self, x):
+            ctx = bfr.STATE.ctx if bfr.STATE.ctx is not None else bfr.recompute_context()
+            seen.append(None if ctx is None else ctx.sample_base)
+            return x * self.w
+
+    class Net(Model):
+        def __init__(self):
+            super().__init__()
+            self.p = Probe()
+
+        def forward(self, x):
+            return cp.checkpoint(self.p, x, use_reentrant=False)
+
+    bfr.manual_seed(5)
+    a, b = Net(), Net()
+    x = torch.randn(2, 3, requires_grad=True)
+    ya = a(x)            # sample base 0
+    with torch.no_grad():
+        a(x)             # an evaluation pass in between: base 1, must not be picked up
+    yb = b(x)            # another model: base 2
+    del seen[:]
+    ya.sum().backward()  # recomputes a's block
+    assert seen == [0], seen
+    del seen[:]
+    yb.sum().backward()
+    assert seen == [2], seen
+    # two forwards of checkpointed models in ONE backward: ambiguous -> loud
+    y1, y2 = a(x), b(x)
+    with pytest.raises(RuntimeError, match="could own it"):
+        (y1.sum() + y2.sum()).backward()
+    # a finished forward keeps no activations
+    assert all(c.shared_out == {} for c in bfr.STATE.live_ctxs) and len(bfr.STATE.live_ctxs) <= bfr.LIVE_CONTEXTS

@@ -36,14 +36,15 @@ class NoisyNet(bnn.Model):
         return y.reshape(S * B, 3)
 
 
-def _run(S, steps, group_used):
+def _run(S, steps, group_used, own_buckets=True):
     torch.manual_seed(0)
     x = torch.randn(4, 5)
     labels = torch.tensor([0, 2, 1, 1])
     model = NoisyNet()
     params = list(model.parameters())
     opt = torch.optim.SGD(params, lr=0.5)
-    buckets = GradientBuckets(params, bucket_bytes=300)  # small buckets: w alone, b + unused together
+    # small buckets: w alone, b + unused together; own_buckets=False: training_step has to see to the reduction itself
+    buckets = GradientBuckets(params, bucket_bytes=300) if own_buckets else None
     bfr.manual_seed(11)
     grads = None
     for _ in range(steps):
@@ -54,11 +55,11 @@ def _run(S, steps, group_used):
     return float(loss), [g.numpy() for g in grads], [p.detach().numpy().copy() for p in (model.w, model.b)]
 
 
-def _worker(rank, world, port, q, S, steps):
+def _worker(rank, world, port, q, S, steps, own_buckets=True):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank,) + _run(S, steps, True))
+        q.put((rank,) + _run(S, steps, True, own_buckets))
     finally:
         dist.destroy_process_group()
 
@@ -116,17 +117,19 @@ def test_clip_through_a_fused_optimizer_matches_scaled_gradients():
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("world,S", [(2, 6), (3, 10)])
-def test_sharded_training_step_matches_single_process(world, S):
+@pytest.mark.parametrize("world,S,own_buckets", [(2, 6, True), (3, 10, True), (2, 5, False)])
+def test_sharded_training_step_matches_single_process(world, S, own_buckets):
     """Two optimisation steps (ELBO of the mean logits, backward, clip at 0.05, SGD) on `world` ranks that each
     backpropagate their own slice of the S samples: the first step's summed gradients and the parameters after both steps
-    equal the single-process run's on every rank (S = 10 over 3 ranks: shards of 4, 3, 3)."""
+    equal the single-process run's on every rank (S = 10 over 3 ranks: shards of 4, 3, 3).  own_buckets=False: the caller
+    passes no GradientBuckets — training_step must still reduce the gradients over the ranks (it builds the buckets of the
+    optimizer itself), or the ranks would step apart."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, S, 2)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, S, 2, own_buckets)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
@@ -140,3 +143,53 @@ def test_sharded_training_step_matches_single_process(world, S):
             np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-7)
         for a, b in zip(w, params):
             np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-7)
+
+
+def test_clipping_factor_does_not_outlive_its_step():
+    """clip_gradients hands a fused optimizer its factor through `grad_scale`; training_step removes it after the update,
+    so a later step without clipping is not divided by a stale factor."""
+    torch.manual_seed(0)
+    x = torch.randn(4, 5)
+    labels = torch.tensor([0, 2, 1, 1])
+
+    def nll(mean):
+        return torch.nn.functional.cross_entropy(mean[0], labels)
+
+    def run(clip_first):
+        model = NoisyNet()
+        opt = torch.optim.AdamW(list(model.parameters()), lr=0.05, weight_decay=0.0, fused=True)
+        bfr.manual_seed(11)
+        if clip_first:
+            training_step(model, x, 3, nll, opt, n_batches=7, max_grad_norm=0.01)
+            assert not hasattr(opt, "grad_scale") and not hasattr(opt, "found_inf")
+            return None
+        return model, opt
+
+    run(True)
+    # two optimizers from the same start: one clipped step then an unclipped one == the same two steps where the second
+    # never saw a grad_scale attribute (checked above); here: an unclipped step right after a clipped one changes the
+    # parameters exactly as torch's own unclipped update would
+    model, opt = run(False)
+    training_step(model, x, 3, nll, opt, n_batches=7, max_grad_norm=0.01)
+    before = [p.detach().clone() for p in model.parameters()]
+    state = {k: {n: (v.clone() if torch.is_tensor(v) else v) for n, v in st.items()} for k, st in opt.state.items()}
+    training_step(model, x, 3, nll, opt, n_batches=7, max_grad_norm=None)
+    after = [p.detach().clone() for p in model.parameters()]
+    # reference: restore, recompute the same gradients, plain optimizer.step()
+    with torch.no_grad():
+        for p, b in zip(model.parameters(), before):
+            p.copy_(b)
+    for k, st in state.items():
+        for n, v in st.items():
+            if torch.is_tensor(v):
+                opt.state[k][n].copy_(v)
+            else:
+                opt.state[k][n] = v
+    bfr.manual_seed(11, next_sample=3)
+    from bayeformers_amd.sampling import elbo, sample_bayesian
+    opt.zero_grad(set_to_none=True)
+    _, mean, lp, lq = sample_bayesian(model, x, 3)
+    elbo(lp, lq, nll(mean).double(), 7).backward()
+    opt.step()
+    for a, p in zip(after, model.parameters()):
+        np.testing.assert_allclose(a.numpy(), p.detach().numpy(), rtol=1e-6, atol=1e-8)
