@@ -81,6 +81,9 @@ SYMBOLS = {
     "bf_add_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, ctypes.c_float, _vp]),
     "bf_profile_enable": (_i, [_i]),
     "bf_profile_reset": (_i, []),
+    "bf_probe_stream_read": (_i, [_vp, _sz, _vp, _vp]),
+    "bf_fused_small_max_rows": (_i, []),
+    "bf_set_fused_small_max_rows": (_i, [_i]),
     "bf_profile_read": (_i, [_i, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
                              ctypes.POINTER(ctypes.c_double)]),
 }

@@ -85,6 +85,19 @@ double sample_work_bytes(const bf_tensor_t* t, int n, int S) {
 }
 }  // namespace
 
+__global__ __launch_bounds__(256) void bf_probe_read_kernel(const uint4* __restrict__ p, size_t n, unsigned* sink) {
+    unsigned acc = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // four independent 16-byte loads in flight per lane
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc ^= a.x ^ b.y ^ c.z ^ d.w;
+    }
+    for (; i < n; i += stride) acc ^= p[i].x;
+    if (acc == 0x9E3779B9u) *sink = acc;  // never true for the buffers bench.py fills; keeps the loads alive
+}
+
 extern "C" {
 
 int bf_profile_enable(int on) {
@@ -123,6 +136,19 @@ int bf_profile_read(int kind, uint64_t* launches, double* total_ms, double* tota
 }
 
 int bf_version(void) { return BF_VERSION_MAJOR * 1000 + BF_VERSION_MINOR; }
+
+// Measurement utility (bench.py's traffic leg): one streaming pass of 16-byte loads over `bytes` of device memory, the
+// access shape of the GEMM's LDS-DMA pieces and of the sampling kernel's parameter reads.  Run under a PMC pass it
+// calibrates the L2's fabric-side counters on a known byte count and on data of a known home: a buffer far larger than
+// the 256 MiB Infinity Cache comes from HBM, a 96 MiB buffer read again comes from the cache.
+int bf_probe_stream_read(const void* d_buf, size_t bytes, void* d_sink, void* stream) {
+    if (!d_buf || !d_sink || bytes < 16) BF_FAIL("bf_probe_stream_read: NULL buffer / sink or fewer than 16 bytes");
+    if ((uintptr_t)d_buf & 15) BF_FAIL("bf_probe_stream_read: the buffer must be 16-byte aligned");
+    hipLaunchKernelGGL(bf_probe_read_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)d_buf, bytes / 16, (unsigned*)d_sink);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 
 int bf_set_sample_counter(const uint32_t* d_counter) {
     g_sample_counter[current_device_slot()] = d_counter;

@@ -225,8 +225,7 @@ __global__ __launch_bounds__(NW * 64) void fused_small_kernel(const FusedParams 
             }
         }
     }
-    if (wid < MB) {
-        const int mb = wid;
+    for (int mb = wid; mb < MB; mb += NW) {
         f32x4_t v = bias;
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += *reinterpret_cast<const f32x4_t*>(&red[w][mb][lane][0]);
@@ -270,7 +269,9 @@ int launch_nw(const FusedParams& p, int MB, dim3 grid, hipStream_t stream) {
         case 1: hipLaunchKernelGGL((fused_small_kernel<T, XT, 1, NW>), grid, dim3(NW * 64), 0, stream, p); break;
         case 2: hipLaunchKernelGGL((fused_small_kernel<T, XT, 2, NW>), grid, dim3(NW * 64), 0, stream, p); break;
         case 3: hipLaunchKernelGGL((fused_small_kernel<T, XT, 3, NW>), grid, dim3(NW * 64), 0, stream, p); break;
-        default: hipLaunchKernelGGL((fused_small_kernel<T, XT, 4, NW>), grid, dim3(NW * 64), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((fused_small_kernel<T, XT, 4, NW>), grid, dim3(NW * 64), 0, stream, p); break;
+        case 5: case 6: hipLaunchKernelGGL((fused_small_kernel<T, XT, 6, NW>), grid, dim3(NW * 64), 0, stream, p); break;
+        default: hipLaunchKernelGGL((fused_small_kernel<T, XT, 8, NW>), grid, dim3(NW * 64), 0, stream, p); break;
     }
     BF_HIP_CHECK(hipGetLastError());
     return 0;
@@ -296,13 +297,24 @@ void mixture_consts(const bf_prior_t& pr, float& a1, float& b1, float& a2, float
 
 }  // namespace
 
-// Is the single-kernel path applicable?  (M <= 64, K % 32 == 0, 16-byte aligned operands, 16-bit MFMA operands.)
+// Rows per sample up to which the single fused kernel is dispatched (the kernel itself takes up to 128: 8 MFMA column
+// blocks per sampled weight fragment).  The default is the measured crossover against sampling launch + tiled GEMM
+// (profiles/r4*_mid_m_crossover.txt); bf_set_fused_small_max_rows() moves it (tools/crossover_bench.py).
+static int g_fused_small_max_rows = 64;
+extern "C" int bf_fused_small_max_rows(void) { return g_fused_small_max_rows; }
+extern "C" int bf_set_fused_small_max_rows(int rows) {
+    if (rows < 0 || rows > 128) BF_FAIL("bf_set_fused_small_max_rows: 0 .. 128 (got %d)", rows);
+    g_fused_small_max_rows = rows;
+    return 0;
+}
+
+// Is the single-kernel path applicable?  (M <= bf_fused_small_max_rows(), K % 32 == 0, 16-byte aligned operands, 16-bit MFMA operands.)
 bool bf_fused_small_supported(int x_dtype, int y_dtype, int compute_dtype, int64_t x_sample_stride, const void* d_x,
                               const bf_tensor_t* weight, const bf_tensor_t* bias, int S, int M, int N, int K) {
     if (compute_dtype != BF_DT_BF16 && compute_dtype != BF_DT_F16) return false;
     if (x_dtype != compute_dtype && x_dtype != BF_DT_F32) return false;
     if (y_dtype != x_dtype) return false;
-    if (M < 1 || M > 64 || K % 32 != 0 || S > 65535) return false;
+    if (M < 1 || M > g_fused_small_max_rows || K % 32 != 0 || S > 65535) return false;
     const size_t xs = bf_dtype_size(x_dtype);
     uintptr_t bits = (uintptr_t)d_x | (uintptr_t)weight->d_mu | (uintptr_t)weight->d_rho | (uintptr_t)((size_t)x_sample_stride * xs);
     if (weight->prior.kind == BF_PRIOR_GAUSSIAN) bits |= (uintptr_t)weight->prior.d_mu | (uintptr_t)weight->prior.d_rho;

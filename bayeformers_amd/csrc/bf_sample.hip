@@ -37,6 +37,15 @@ constexpr int kEPT = 4 * kGPT;         // scalars per thread
 constexpr int kMaxSChunk = 32;
 constexpr int kMaxSeg = 2;
 constexpr int OUT_NONE = -1;
+// A Gaussian prior whose mean IS the posterior's mean and whose sigma is one constant — MOPED with a frozen mean,
+// /root/reference/bayeformers/nn/layers/linear.py:147-150 (prior.mu shares the pretrained tensor, prior.rho = 1): the
+// caller asserts it through bf_prior_t (pi = 1, sigma1 = sigma_p; include/bayeformers_amd.h).  The kernel then reads
+// 8 instead of 16 bytes per scalar and W - mu_p is sigma * eps: log p = -log sqrt(2 pi) - log sigma_p - (sigma eps)^2 / (2 sigma_p^2).
+constexpr int PRIOR_GAUSS_ALIAS = 3;
+
+__host__ inline int effective_prior(const bf_prior_t& pr) {
+    return (pr.kind == BF_PRIOR_GAUSSIAN && pr.pi == 1.0f && pr.sigma1 > 0.0f) ? PRIOR_GAUSS_ALIAS : pr.kind;
+}
 
 struct SegDesc {
     const float* mu;
@@ -155,6 +164,7 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][k
                 sigma[j][i] = softplus_fast(rho[i]);
                 if (i < nvalid[j]) constq += -kLogSqrt2Pi - log_fast(sigma[j][i]);
             }
+            if constexpr (PRIOR == PRIOR_GAUSS_ALIAS) constp += (float)nvalid[j] * a.b1;  // b1 = -log sqrt(2 pi) - log sigma_p
             if constexpr (PRIOR == BF_PRIOR_GAUSSIAN) {
                 float prho[4];
                 load4(a.mu_p, e0[j], nvalid[j], a.vec_in, pmu[j]);
@@ -213,6 +223,11 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][k
                     const f32x2_t d01 = w01 - f32x2_t{pmu[j][0], pmu[j][1]}, d23 = w23 - f32x2_t{pmu[j][2], pmu[j][3]};
                     p2 = __builtin_elementwise_fma(d01 * d01, f32x2_t{-pinv[j][0], -pinv[j][1]}, p2);
                     p2 = __builtin_elementwise_fma(d23 * d23, f32x2_t{-pinv[j][2], -pinv[j][3]}, p2);
+                } else if constexpr (PRIOR == PRIOR_GAUSS_ALIAS) {
+                    // W - mu_p = sigma eps; the common factor -1 / (2 sigma_p^2) is applied once per sample below
+                    const f32x2_t d01 = f32x2_t{sigma[j][0], sigma[j][1]} * z01, d23 = f32x2_t{sigma[j][2], sigma[j][3]} * z23;
+                    p2 = __builtin_elementwise_fma(d01, d01, p2);
+                    p2 = __builtin_elementwise_fma(d23, d23, p2);
                 }
                 if (outp) {
                     const unsigned long long idx = (unsigned long long)s * a.n + e0[j];
@@ -226,7 +241,7 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][k
             // final fp64 pass adds 16 terms per scalar instead of 4 (the two cross-row steps, the readlane and their
             // moves were ~10 of the ~150 instructions a wave spends per sample)
             const float lq = row_sum(-0.5f * (q2[0] + q2[1]));
-            const float lp = row_sum(p2[0] + p2[1]);
+            const float lp = row_sum(PRIOR == PRIOR_GAUSS_ALIAS ? -a.a1 * (p2[0] + p2[1]) : p2[0] + p2[1]);  // a1 = 1 / (2 sigma_p^2)
             if ((lane & 15) == 15) *reinterpret_cast<f32x2_t*>(&red[wid][lane >> 4][s - s_begin][0]) = f32x2_t{lp, lq};
         }
     } else
@@ -255,6 +270,9 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][k
                 } else if constexpr (PRIOR == BF_PRIOR_GAUSSIAN) {
                     const float dlt = w[i] - pmu[j][i];
                     tp = -(dlt * dlt) * pinv[j][i];
+                } else if constexpr (PRIOR == PRIOR_GAUSS_ALIAS) {
+                    const float dlt = sigma[j][i] * z[i];
+                    tp = -(dlt * dlt) * a.a1;
                 }
                 if (i < nvalid[j]) {
                     lq += tq;
@@ -352,7 +370,8 @@ __global__ __launch_bounds__(kThreads) void bf_sample_table_kernel(const TableEn
     a.sample_base = sample_base + (counter ? *counter : 0u);
     a.partial_row = partials + (size_t)gb * S * 2;
     const int pk = __builtin_amdgcn_readfirstlane(e.prior_kind);
-    if (pk == BF_PRIOR_GAUSSIAN) sample_body<BF_PRIOR_GAUSSIAN, OUT_RUNTIME>(a, red, cst);
+    if (pk == PRIOR_GAUSS_ALIAS) sample_body<PRIOR_GAUSS_ALIAS, OUT_RUNTIME>(a, red, cst);
+    else if (pk == BF_PRIOR_GAUSSIAN) sample_body<BF_PRIOR_GAUSSIAN, OUT_RUNTIME>(a, red, cst);
     else if (pk == BF_PRIOR_MIXTURE) sample_body<BF_PRIOR_MIXTURE, OUT_RUNTIME>(a, red, cst);
     else sample_body<BF_PRIOR_NONE, OUT_RUNTIME>(a, red, cst);
 }
@@ -456,7 +475,7 @@ static int launch_group(const bf_tensor_t* tensors, int first, int count, uint32
     // this group's blocks write partial rows [blk_offset, blk_offset + blk)
     p.partials = partials + (size_t)blk_offset * (size_t)S * 2;
     uint32_t blk = 0;
-    const int prior_kind = tensors[first].prior.kind;
+    const int prior_kind = effective_prior(tensors[first].prior);
     for (int t = 0; t < count; ++t) {
         const bf_tensor_t& T = tensors[first + t];
         SegDesc& sg = p.seg[t];
@@ -482,6 +501,11 @@ static int launch_group(const bf_tensor_t* tensors, int first, int count, uint32
         p.b1 = (float)(log(pi) - log(s1) - 0.91893853320467274178);
         p.b2 = (float)(log1p(-pi) - log(s2) - 0.91893853320467274178);
     }
+    if (prior_kind == PRIOR_GAUSS_ALIAS) {
+        const double sp = tensors[first].prior.sigma1;
+        p.a1 = (float)(0.5 / (sp * sp));
+        p.b1 = (float)(-0.91893853320467274178 - log(sp));
+    }
     p.nblk = blk;
     const int ny = pick_ny(blk, S);
     p.ny = ny;
@@ -490,6 +514,7 @@ static int launch_group(const bf_tensor_t* tensors, int first, int count, uint32
     switch (prior_kind) {
         case BF_PRIOR_MIXTURE: launch_prior<BF_PRIOR_MIXTURE>(out_dt, grid, stream, p); break;
         case BF_PRIOR_GAUSSIAN: launch_prior<BF_PRIOR_GAUSSIAN>(out_dt, grid, stream, p); break;
+        case PRIOR_GAUSS_ALIAS: launch_prior<PRIOR_GAUSS_ALIAS>(out_dt, grid, stream, p); break;
         default: launch_prior<BF_PRIOR_NONE>(out_dt, grid, stream, p); break;
     }
     BF_HIP_CHECK(hipGetLastError());
@@ -561,7 +586,7 @@ int bf_table_build(const bf_tensor_t* tensors, int n_tensors, void* h_blob, size
         memset(&e, 0, sizeof(e));
         e.mu = T.d_mu; e.rho = T.d_rho; e.mu_p = T.prior.d_mu; e.rho_p = T.prior.d_rho;
         e.out = T.d_sample_out; e.n = T.n; e.stream = T.stream_id; e.block_begin = blk;
-        e.prior_kind = T.prior.kind; e.out_dt = T.out_dtype;
+        e.prior_kind = effective_prior(T.prior); e.out_dt = T.out_dtype;
         uintptr_t align_bits = (uintptr_t)T.d_mu | (uintptr_t)T.d_rho;
         if (T.prior.kind == BF_PRIOR_GAUSSIAN) align_bits |= (uintptr_t)T.prior.d_mu | (uintptr_t)T.prior.d_rho;
         e.vec_in = (align_bits & 15) == 0;
@@ -573,6 +598,11 @@ int bf_table_build(const bf_tensor_t* tensors, int n_tensors, void* h_blob, size
             e.a2 = (float)(-0.5 / (s2 * s2));
             e.b1 = (float)(log(pi) - log(s1) - 0.91893853320467274178);
             e.b2 = (float)(log1p(-pi) - log(s2) - 0.91893853320467274178);
+        }
+        if (e.prior_kind == PRIOR_GAUSS_ALIAS) {
+            const double sp = T.prior.sigma1;
+            e.a1 = (float)(0.5 / (sp * sp));
+            e.b1 = (float)(-0.91893853320467274178 - log(sp));
         }
         if (h_block_begin) h_block_begin[t] = blk;
         const uint32_t nb = blocks_for(T.n);
@@ -632,8 +662,10 @@ int bf_launch_sample_logprob(const bf_tensor_t* tensors, int n_tensors, int S, u
     double* partials = reinterpret_cast<double*>(d_workspace);
     // one launch when the two tensors can share a kernel instantiation: same prior kind (and identical mixture
     // constants), second tensor written as fp32 (or not at all)
-    bool together = n_tensors == 2 && tensors[0].prior.kind == tensors[1].prior.kind &&
+    bool together = n_tensors == 2 && effective_prior(tensors[0].prior) == effective_prior(tensors[1].prior) &&
                     (!tensors[1].d_sample_out || tensors[1].out_dtype == BF_DT_F32);
+    if (together && effective_prior(tensors[0].prior) == PRIOR_GAUSS_ALIAS)
+        together = tensors[0].prior.sigma1 == tensors[1].prior.sigma1;
     if (together && tensors[0].prior.kind == BF_PRIOR_MIXTURE)
         together = tensors[0].prior.pi == tensors[1].prior.pi && tensors[0].prior.sigma1 == tensors[1].prior.sigma1 &&
                    tensors[0].prior.sigma2 == tensors[1].prior.sigma2;

@@ -47,6 +47,11 @@ def philox_normal_host(n: int, seed: int, sample: int, stream_id: int, offset: i
     return out
 
 
+def fused_small_max_rows() -> int:
+    """Rows per sample up to which bf_linear_fwd is ONE fused kernel (bf_fused_small_max_rows, the measured crossover)."""
+    return _C.lib().bf_fused_small_max_rows()
+
+
 def philox_normal(n: int, S: int, seed: int, sample_base: int, stream_id: int, device="cuda") -> Tensor:
     """Device epsilon: [S, n] fp32 (test hook for the RNG contract)."""
     out = torch.empty((int(S), int(n)), dtype=torch.float32, device=device)
@@ -55,7 +60,32 @@ def philox_normal(n: int, S: int, seed: int, sample_base: int, stream_id: int, d
     return out
 
 
-def fill_prior(dst: "_C.bf_prior_t", prior) -> bool:
+def prior_alias(gaussian, prior) -> Optional[float]:
+    """sigma_p when `prior` is the MOPED prior of a FROZEN mean — Gaussian(mu = the posterior's mean, rho = one constant),
+    /root/reference/bayeformers/nn/layers/linear.py:147-150 with freeze=True — else None.  The sampling kernel then reads
+    8 instead of 16 bytes per scalar (bf_prior_t.pi == 1).  Checked on the tensors' CONTENTS (after a device move the two
+    means are equal copies, no longer one storage), once per state: the verdict is cached with the tensors' addresses and
+    version counters, so an in-place edit of either (an optimizer step on a trainable mean, load_state_dict) is seen and
+    re-checked.  A trainable mean is never aliased: it leaves the prior's at its first update."""
+    mu, pmu, prho = gaussian.mu, prior.mu, prior.rho
+    if mu.requires_grad or pmu.shape != mu.shape or prho.shape != mu.shape or pmu.dtype != torch.float32:
+        return None
+    state = (mu.data_ptr(), mu._version, pmu.data_ptr(), pmu._version, prho.data_ptr(), prho._version)
+    hit = getattr(prior, "_bf_alias", None)
+    if hit is not None and hit[0] == state:
+        return hit[1]
+    with torch.no_grad():
+        sigma_p = None
+        lo, hi = torch.aminmax(prho)
+        if bool(lo == hi) and (pmu.data_ptr() == mu.data_ptr() or torch.equal(pmu, mu)):
+            sigma_p = float(torch.nn.functional.softplus(lo.float()))
+            if not (sigma_p > 0.0 and sigma_p < float("inf")):
+                sigma_p = None
+    prior._bf_alias = (state, sigma_p)
+    return sigma_p
+
+
+def fill_prior(dst: "_C.bf_prior_t", prior, gaussian=None) -> bool:
     """Describe a prior module to the kernels.  Returns False for a user-defined Parameter (generic path)."""
     from .nn.parameters.base import NoneParameter
     from .nn.parameters.gaussian import Gaussian, ScaledGaussianMixture
@@ -69,6 +99,8 @@ def fill_prior(dst: "_C.bf_prior_t", prior) -> bool:
         _require_device(prior.mu, "prior.mu")
         dst.kind = _C.BF_PRIOR_GAUSSIAN
         dst.d_mu, dst.d_rho = prior.mu.data_ptr(), prior.rho.data_ptr()
+        sigma_p = prior_alias(gaussian, prior) if gaussian is not None else None
+        dst.pi, dst.sigma1 = (1.0, sigma_p) if sigma_p is not None else (0.0, 0.0)
         return True
     if prior is None or isinstance(prior, NoneParameter):
         dst.kind = _C.BF_PRIOR_NONE
@@ -86,10 +118,9 @@ def fill_tensor(dst: "_C.bf_tensor_t", gaussian, prior, stream_id: int) -> bool:
     dst.stream_id = stream_id
     dst.d_sample_out = None
     dst.out_dtype = _C.BF_DT_F32
-    known = fill_prior(dst.prior, prior)
     if isinstance(prior, type(gaussian)) and prior.mu.numel() != mu.numel():
         raise _C.BayeFormersAMDError("Gaussian prior must have the shape of the parameter it is a prior of")
-    return known
+    return fill_prior(dst.prior, prior, gaussian)
 
 
 def sample_logprob(gaussians, priors, stream_ids, S: int, seed: int, sample_base: int, out_dtype=None):

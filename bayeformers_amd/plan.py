@@ -175,6 +175,11 @@ class SamplePlan:
         key = [S, cdt, len(layers), tuple(tuple(l.layer_id for l in t) for t in shared)]
         for l in layers:
             key.append(l.layer_id)
+            # the table bakes in whether a Gaussian prior is the alias of its posterior's frozen mean (ops.prior_alias)
+            if isinstance(l.weight_prior, Gaussian):
+                key.append(ops.prior_alias(l.weight, l.weight_prior))
+            if isinstance(l.bias_prior, Gaussian) and isinstance(l.bias, Gaussian):
+                key.append(ops.prior_alias(l.bias, l.bias_prior))
             for g in (l.weight, l.bias, l.weight_prior, l.bias_prior):
                 if isinstance(g, Gaussian):
                     key.append(g.mu.data_ptr())

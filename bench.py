@@ -35,6 +35,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_TFLOPS = 2500.0   # MI355X dense bf16/fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_TFLOPS_F32 = 157.3  # fp32-input MFMA (v_mfma_f32_16x16x4_f32): --dtype fp32, the reference's own precision
 PEAK_HBM_GBS = 8000.0  # HBM3E spec
 
 
@@ -55,6 +56,8 @@ def parse():
                     help="bert_base_train only: put the model in .train() like examples/bert_glue.py:221 (HF dropout p = 0.1 "
                          "active: attention and embeddings take the framework's paths); default: dropout off")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--calibrate-traffic", action="store_true",
+                    help="(set by the PMC child passes) run the known-size streaming reads that calibrate the counters first")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group check only: every rank joins the group (RCCL on GPUs, gloo without), "
                          "one all-reduce, rank 0 prints a JSON line with n_gpus; no kernels run")
@@ -78,8 +81,48 @@ def _ranks() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-class Workload:
-    """name, S (per GPU), dtype, step() -> python float (the ELBO), config dict, cpu_baseline() -> dict."""
+def honoured_env():
+    """Every BF_* variable set in this process's environment: they are developer switches that change what is built or
+    timed (BF_BENCH_NO_*_FUSION, BF_BENCH_TRAIN_*, BF_BENCH_SHARE_GPU, BF_PLAN_ARENA_BYTES, BF_LIB_PATH, ...), so a line
+    produced under any of them says so in its `config` (an empty dict = the defaults the driver measures)."""
+    return {k: os.environ[k] for k in sorted(os.environ) if k.startswith("BF_")}
+
+
+def timed_cpu(fn, n):
+    """cpu_baseline timing (core count stated, mean and min of >= 5 after a warm-up): `fn` is
+    first timed once at 8, 32 and all host threads — the port is memory-bound and oversubscribes on a many-core host, so
+    'all threads' is not its best — then `n` times at the best count.  Returns (threads, [seconds], {threads: seconds})."""
+    nproc = os.cpu_count() or 1
+    cands = sorted({min(t, nproc) for t in (8, 32, nproc)})
+    prev = torch.get_num_threads()
+    sweep = {}
+    try:
+        torch.set_num_threads(cands[0])
+        fn()  # warm-up (allocations, oneDNN primitives)
+        for t in cands:
+            torch.set_num_threads(t)
+            t0 = time.perf_counter()
+            fn()
+            sweep[t] = time.perf_counter() - t0
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        times = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            times.append(time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(prev)
+    return best, times, sweep
+
+
+def cpu_line(units_per_call, times, best, sweep, what):
+    mean = sum(times) / len(times)
+    return {"value": units_per_call / mean, "unit": "MC-samples/s", "cores": best, "kind": "port",
+            "best": units_per_call / min(times), "host_threads_available": os.cpu_count(),
+            "thread_sweep_s_per_call": {str(t): round(v, 3) for t, v in sweep.items()},
+            "sample": f"{what}: mean of {len(times)} after a warm-up, torch-CPU fp32 at {best} threads "
+                      f"(best of the sweep), {sum(times):.1f}s"}
 
 
 def build_bert(device, dtype):
@@ -151,17 +194,15 @@ def make_bert(device, S, dtype, train=False, train_mode=False):
         if train:
             return None
         omodel = to_oracle(model, delta=0.05).eval()
-        n = 5  # one warm-up, then the mean of >= 5 (about 25 s of CPU work on the GPU box's host)
-        with torch.no_grad():
-            omodel(input_ids=ids, attention_mask=torch.ones(B, L, dtype=torch.long))  # warm-up sample
-            t0 = time.perf_counter()
-            for _ in range(n):
-                out = omodel(input_ids=ids, attention_mask=torch.ones(B, L, dtype=torch.long))
+        mask = torch.ones(B, L, dtype=torch.long)
+
+        def one_sample():
+            with torch.no_grad():
+                omodel(input_ids=ids, attention_mask=mask)
                 log_probs(omodel)
-            dt = time.perf_counter() - t0
-        return {"value": n / dt, "unit": "MC-samples/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": f"{n} serial MC samples (fwd + log-probs) of the same BERT-base B=32 L=128 batch, "
-                          f"torch-CPU fp32, {dt:.1f}s"}
+
+        best, times, sweep = timed_cpu(one_sample, 5)
+        return cpu_line(1, times, best, sweep, "serial MC samples (fwd + log-probs) of the same BERT-base B=32 L=128 batch")
 
     cfgd = {"workload": "to_bayesian(BERT-base seq-cls, delta=0.05, freeze=True) " +
                         (("training step: fwd+ELBO+backward+clip+AdamW, " + ("model.train(): dropout 0.1" if train_mode else "dropout off"))
@@ -205,13 +246,15 @@ def make_bert_large_qa(device, S, dtype):
         from oracle.model_oracle import log_probs, to_oracle
 
         omodel = to_oracle(model, delta=0.05).eval()
-        with torch.no_grad():
-            t0 = time.perf_counter()
-            omodel(input_ids=ids, attention_mask=torch.ones(B, L, dtype=torch.long))
-            log_probs(omodel)
-            dt = time.perf_counter() - t0
-        return {"value": 1 / dt, "unit": "MC-samples/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": f"1 MC sample (fwd + log-probs) of the same BERT-large B=16 L=384 batch, torch-CPU fp32, {dt:.1f}s"}
+        mask = torch.ones(B, L, dtype=torch.long)
+
+        def one_sample():
+            with torch.no_grad():
+                omodel(input_ids=ids, attention_mask=mask)
+                log_probs(omodel)
+
+        best, times, sweep = timed_cpu(one_sample, 2)
+        return cpu_line(1, times, best, sweep, "serial MC samples (fwd + log-probs) of the same BERT-large B=16 L=384 batch")
 
     cfgd = {"workload": "to_bayesian(BERT-large QA, delta=0.05, freeze=True) fwd+ELBO", "samples_per_gpu": S, "batch": B,
             "allreduce_values": 2 * B * L + 2,
@@ -247,15 +290,12 @@ def make_linear(device, S, dtype, M):
         mu_w, rho_w = layer.weight.mu.detach().cpu(), layer.weight.rho.detach().cpu()
         mu_b, rho_b = layer.bias.mu.detach().cpu(), layer.bias.rho.detach().cpu()
         prior = ("mixture", 0.5, 1.0, float(torch.tensor(-6.0).exp()))
-        n = 3 if M <= 64 else 2
-        with torch.no_grad():
-            bo.cpu_reference_step(x, mu_w, rho_w, mu_b, rho_b, S, prior)
-            t0 = time.perf_counter()
-            for _ in range(n):
+        def one_step():
+            with torch.no_grad():
                 bo.cpu_reference_step(x, mu_w, rho_w, mu_b, rho_b, S, prior)
-            dt = time.perf_counter() - t0
-        return {"value": n * S / dt, "unit": "MC-samples/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": f"{n} steps of S={S} serial samples, x=[{M},768], torch-CPU fp32, {dt:.1f}s"}
+
+        best, times, sweep = timed_cpu(one_step, 5)
+        return cpu_line(S, times, best, sweep, f"steps of S={S} serial samples, x=[{M},768]")
 
     cfgd = {"workload": f"bnn.Linear(768,768) default init + mixture prior, x=[{M},768], fwd+ELBO",
             "samples_per_gpu": S, "batch": M}
@@ -283,16 +323,15 @@ def make_mlp(device, S, dtype):
         from oracle.model_oracle import log_probs, to_oracle
 
         om = to_oracle(mlp, delta=0.05)
-        n = 20
-        with torch.no_grad():
-            om(x)
-            t0 = time.perf_counter()
-            for _ in range(n * S):
-                om(x)
-                log_probs(om)
-            dt = time.perf_counter() - t0
-        return {"value": n * S / dt, "unit": "MC-samples/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": f"{n} steps of S={S} serial samples, MLP 784-512-512-10 B=128, torch-CPU fp32, {dt:.1f}s"}
+
+        def steps20():
+            with torch.no_grad():
+                for _ in range(20 * S):
+                    om(x)
+                    log_probs(om)
+
+        best, times, sweep = timed_cpu(steps20, 5)
+        return cpu_line(20 * S, times, best, sweep, f"blocks of 20 steps of S={S} serial samples, MLP 784-512-512-10 B=128")
 
     return step, cpu_baseline, {"workload": "to_bayesian(MLP 784-512-512-10, delta=0.05) fwd+ELBO", "samples_per_gpu": S,
                                 "batch": 128}, bmodel
@@ -320,13 +359,40 @@ def alg_gemm_bytes(bmodel, cfgd, S, dtype):
     return round(sum(tot) / len(tot)) if tot else None
 
 
+def calibration_probes(device):
+    """Inside a rocprofv3 --pmc child pass (--calibrate-traffic): streaming reads whose byte count and home are known, ahead
+    of the workload, so that the SAME pass yields the counters' calibration: a 2 GiB buffer (eight times the 256 MiB
+    Infinity Cache: served by HBM) read once, then a 96 MiB buffer (three times the aggregate L2, well inside the Infinity
+    Cache) read three times — its third pass comes from the cache.  Kernel: bf_probe_read_kernel (bf_probe_stream_read)."""
+    from bayeformers_amd import _C
+
+    lib = _C.lib()
+    big = torch.full((2 << 30,), 1, dtype=torch.uint8, device=device)
+    small = torch.full((96 << 20,), 1, dtype=torch.uint8, device=device)
+    sink = torch.zeros(1, dtype=torch.int32, device=device)
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    _C.check(lib.bf_probe_stream_read(big.data_ptr(), big.numel(), sink.data_ptr(), st), "bf_probe_stream_read")
+    for _ in range(3):
+        _C.check(lib.bf_probe_stream_read(small.data_ptr(), small.numel(), sink.data_ptr(), st), "bf_probe_stream_read")
+    torch.cuda.synchronize()
+    del big, small
+    torch.cuda.empty_cache()
+
+
+PROBE_BYTES = (2 << 30, 96 << 20, 96 << 20, 96 << 20)  # calibration_probes' four dispatches, in order
+
+
 def measure_traffic(args):
-    """roofline.traffic: HBM bytes per GEMM launch from the PMC counters, collected as MI355X_MICROARCH.md's HBM
+    """roofline.traffic: HBM-side bytes per GEMM launch from the PMC counters, collected as MI355X_MICROARCH.md's HBM
     section prescribes — FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (kernel-trace only) over a short
     run of this same workload, values in KiB, FETCH_SIZE doubled (gfx950 reports half the bytes of wide 16 B/lane
-    reads, which is what the LDS-DMA loads are; calibrated here on the sampling kernel's known 16 B/scalar reads),
-    WRITE_SIZE as is for the 16-byte epilogue stores (calibrated on their known byte count).  Returns None if the
-    profiler is unavailable."""
+    reads, which is what the LDS-DMA loads are; re-measured in the same pass on bf_probe_read_kernel's known byte
+    counts and reported as `fetch_unit_check`), WRITE_SIZE as is for the 16-byte epilogue stores.
+    A third pass (TCC_EA0_RDREQ_sum, TCC_EA0_RDREQ_LEVEL_sum) gives the mean time an L2 read request spends on the fabric
+    (LEVEL / REQ, L2 clocks): rocprofv3 lists no memory-side (Infinity Cache / UMC) counter on gfx950, and FETCH_SIZE
+    counts cache hits and HBM reads alike, so the split is an ESTIMATE by interpolation between the two calibration
+    streams of that pass (2 GiB from HBM, 96 MiB from the Infinity Cache).  Returns None if the profiler is unavailable."""
     import csv
     import glob
     import shutil
@@ -336,14 +402,17 @@ def measure_traffic(args):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None
-    out = {}
+    out, probe = {}, {}
     tmp = tempfile.mkdtemp(prefix="bf_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    is_gemm = lambda name: "gemm256_ring5" in name or "gemm256_sched" in name
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "t", "--",
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_LEVEL_sum")):
+            d = os.path.join(tmp, counters[0])
+            cmd = [rocprof, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "t", "--",
                    sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "2", "--warmup", "1",
                    "--no-cpu-baseline", "--no-traffic", "--graph", "off"]
+            if counters[0] != "WRITE_SIZE":
+                cmd.append("--calibrate-traffic")
             if args.samples:
                 cmd += ["--samples", str(args.samples)]
             if args.dtype:
@@ -351,18 +420,47 @@ def measure_traffic(args):
             env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)
-            subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+            try:
+                subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+            except Exception:
+                if counters[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    raise
+                continue  # the latency pass is optional
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            vals = []
+            vals = {c: [] for c in counters}
+            pvals = {c: [] for c in counters}
             for f in files:
                 for r in csv.DictReader(open(f)):
-                    if ("gemm256_ring5" in r["Kernel_Name"] or "gemm256_sched" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
-                        vals.append(float(r["Counter_Value"]))
-            if not vals:
-                return None
-            out[counter] = sum(vals) / len(vals) * 1024.0
-        return {"bytes_per_launch": 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"], "fetch_bytes": 2.0 * out["FETCH_SIZE"],
-                "write_bytes": out["WRITE_SIZE"]}
+                    c = r["Counter_Name"]
+                    if c not in vals:
+                        continue
+                    if is_gemm(r["Kernel_Name"]):
+                        vals[c].append(float(r["Counter_Value"]))
+                    elif "bf_probe_read_kernel" in r["Kernel_Name"]:
+                        pvals[c].append((int(r.get("Dispatch_Id", 0) or 0), float(r["Counter_Value"])))
+            for c in counters:
+                if vals[c]:
+                    out[c] = sum(vals[c]) / len(vals[c])
+                probe[c] = [v for _, v in sorted(pvals[c])]
+        if "FETCH_SIZE" not in out or "WRITE_SIZE" not in out:
+            return None
+        res = {"bytes_per_launch": 2.0 * out["FETCH_SIZE"] * 1024.0 + out["WRITE_SIZE"] * 1024.0,
+               "fetch_bytes": 2.0 * out["FETCH_SIZE"] * 1024.0, "write_bytes": out["WRITE_SIZE"] * 1024.0}
+        pf = probe.get("FETCH_SIZE") or []
+        if len(pf) == len(PROBE_BYTES):
+            # bytes of a known streaming read per byte FETCH_SIZE reports (the guide's gfx950 correction says 2)
+            res["fetch_unit_check"] = round(PROBE_BYTES[0] / (pf[0] * 1024.0), 3)
+        req, lvl = probe.get("TCC_EA0_RDREQ_sum") or [], probe.get("TCC_EA0_RDREQ_LEVEL_sum") or []
+        if len(req) == len(PROBE_BYTES) and len(lvl) == len(PROBE_BYTES) and "TCC_EA0_RDREQ_sum" in out and min(req) > 0:
+            lat_hbm, lat_cache = lvl[0] / req[0], lvl[3] / req[3]
+            lat_gemm = out["TCC_EA0_RDREQ_LEVEL_sum"] / out["TCC_EA0_RDREQ_sum"]
+            res["ea_read_latency_clk"] = {"hbm_stream_2GiB": round(lat_hbm, 1), "infinity_cache_stream_96MiB": round(lat_cache, 1),
+                                          "gemm": round(lat_gemm, 1)}
+            if lat_hbm > lat_cache:
+                f = min(1.0, max(0.0, (lat_hbm - lat_gemm) / (lat_hbm - lat_cache)))
+                res["infinity_cache_hit_fraction_est"] = round(f, 3)
+                res["hbm_read_bytes_est"] = (1.0 - f) * res["fetch_bytes"]
+        return res
     except Exception:
         return None
     finally:
@@ -418,15 +516,49 @@ def launch_ranks(args) -> int:
 
 
 def dry_run(args, world, rank, device):
-    """Process-group check: one all-reduce over all ranks, rank 0 reports how many took part."""
-    t = torch.ones(1, dtype=torch.float64, device=device)
+    """Process-group preflight: the SAME group the real run builds (RCCL through init_process_group("nccl", device_id=...)
+    on GPUs) carries the real run's two kinds of message once — the packed fp64 ELBO buffer (66 values, latency-bound)
+    and one 128 MiB gradient bucket (bandwidth-bound, asynchronous like training.GradientBuckets sends it) — and rank 0
+    prints who took part, so an environment problem shows up in seconds, before any model is built."""
+    line = {"metric": "dry-run", "value": None, "n_gpus": world, "steps": 0, "warmup": 0,
+            "backend": dist.get_backend() if world > 1 else None}
+    packed = torch.ones(66, dtype=torch.float64, device=device)
+    bucket = torch.ones((128 << 20) // 4, dtype=torch.float32, device=device)
+    times = {}
     if world > 1:
-        dist.all_reduce(t)
+        for name, t in (("packed_fp64_66", packed), ("bucket_128MiB", bucket)):
+            dist.all_reduce(t)  # first call: communicator / ring set-up
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+            t.fill_(1)
+            t0 = time.perf_counter()
+            work = dist.all_reduce(t, async_op=True)
+            work.wait()
+            if device.type == "cuda":
+                torch.cuda.synchronize()
+            times[name] = round(1e3 * (time.perf_counter() - t0), 3)
+        names = [None] * world
+        me = {"rank": rank, "device": str(device),
+              "gpu": torch.cuda.get_device_name(device) if device.type == "cuda" else "cpu",
+              "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+        dist.all_gather_object(names, me)
+        line["ranks"] = names
+    line["ranks_counted"] = int(packed[0].item())
+    line["bucket_ranks_counted"] = int(bucket[-1].item())
+    line["allreduce_ms"] = times or None
+    if device.type == "cuda":
+        try:
+            line["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # pragma: no cover
+            line["rccl_version"] = None
+    ok = line["ranks_counted"] == world and line["bucket_ranks_counted"] == world
+    line["ok"] = ok
     if rank == 0:
-        print(json.dumps({"metric": "dry-run", "value": None, "n_gpus": world, "ranks_counted": int(t.item()),
-                          "backend": dist.get_backend() if world > 1 else None, "steps": 0, "warmup": 0}), flush=True)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
 
 
 def main():
@@ -473,6 +605,8 @@ def main():
     import bayeformers_amd as bf
     from bayeformers_amd import _C
 
+    if args.calibrate_traffic:
+        calibration_probes(device)
     defaults = {"bert_base": (10, "bf16"), "bert_base_train": (10, "bf16"), "bert_large_qa": (10, "fp16"), "linear768": (10, "bf16"), "linear768_m32": (10, "bf16"), "mlp": (5, "bf16")}
     S = args.samples or defaults[args.workload][0]
     dtype = args.dtype or defaults[args.workload][1]
@@ -528,6 +662,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    local_dt = dt
     last = float(elbo_host[args.steps - 1])
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -567,14 +702,31 @@ def main():
         torch.cuda.synchronize()
         allreduce_ms = e0.elapsed_time(e1) / 50
 
+    # every rank's GEMM / sampling time per step (a straggler shows in the N-rank line)
+    by_rank = None
+    if world > 1:
+        mine = torch.tensor([prof["gemm"][1] / prof_steps, prof["sample"][1] / prof_steps, 1e3 * local_dt / args.steps],
+                            dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        by_rank = {"gemm_ms_per_step": [round(float(t[0]), 3) for t in allr],
+                   "sample_ms_per_step": [round(float(t[1]), 3) for t in allr],
+                   "ms_per_step": [round(float(t[2]), 3) for t in allr]}
+
     if rank == 0:
+        peak = PEAK_TFLOPS_F32 if dtype == "fp32" else PEAK_TFLOPS
         gn, gms, gflop = prof["gemm"]
         sn, sms, sbytes = prof["sample"]
+        aliased = False
         plan = getattr(bmodel, "_plan", None)
         if sbytes == 0 and plan is not None:
             # cross-layer launches: algorithmic bytes = mu,rho (+ Gaussian prior mu,rho) read once, S samples written
+            from bayeformers_amd import ops as bf_ops
             from bayeformers_amd.nn import Gaussian
-            per_read = 16 if isinstance(plan.layers[0].weight_prior, Gaussian) else 8
+            l0 = plan.layers[0]
+            # a Gaussian prior is read too (16 B per scalar) unless it is the alias of the frozen posterior mean (MOPED)
+            per_read = 16 if isinstance(l0.weight_prior, Gaussian) and bf_ops.prior_alias(l0.weight, l0.weight_prior) is None else 8
+            aliased = isinstance(l0.weight_prior, Gaussian) and per_read == 8
             esz = 4 if dtype == "fp32" else 2
             sbytes = float(plan.scalars) * (per_read + S * esz) * prof_steps
         fn, fms, fflop = prof["fused"]
@@ -587,12 +739,17 @@ def main():
             gn, gms, gflop = fn, fms, fflop
             kernel, bound, fused = fused["kernel"], "latency", None
         else:
-            kernel = "gemm256_ring5_kernel (sampled-weight GEMM, five-slot LDS ring; mean over the step's tiled-GEMM launches)"
+            kernel = ("gemm_f32_kernel (sampled-weight GEMM on the exact fp32-input MFMA; mean over the step's GEMM launches)"
+                      if dtype == "fp32" else
+                      "gemm256_ring5_kernel (sampled-weight GEMM, five-slot LDS ring; mean over the step's tiled-GEMM launches)")
             bound = "mfma"
         tflops = gflop / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+        # the north star asks for ONE fused reparameterise + GEMM kernel; here the weights are sampled by their own launch
+        # (DESIGN.md section 4.3), so the fraction a fused kernel would be held to is flop / (GEMM time + sampling time)
+        tflops_ws = gflop / ((gms + sms) * 1e-3) / 1e12 if gms + sms > 0 else 0.0
         roofline = {"bound": bound, "kernel": kernel,
-                    "achieved": round(tflops, 2), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tflops / PEAK_TFLOPS, 4), "traffic": None,
+                    "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(tflops / peak, 4), "frac_with_sampling": round(tflops_ws / peak, 4), "traffic": None,
                     "launches_per_step": gn // prof_steps, "avg_launch_us": round(1e3 * gms / max(gn, 1), 2),
                     "flop_per_step": gflop / prof_steps, "gemm_ms_per_step": round(gms / prof_steps, 3),
                     "fused_small_kernel": fused,
@@ -600,7 +757,7 @@ def main():
                                       "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                       "frac": round(sbytes / (sms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if sms > 0 else 0.0,
                                       "launches_per_step": sn // prof_steps, "ms_per_step": round(sms / prof_steps, 3),
-                                      "bytes_per_step": sbytes / prof_steps}}
+                                      "bytes_per_step": sbytes / prof_steps, "moped_prior_aliased": aliased}}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
@@ -608,9 +765,20 @@ def main():
             tr = measure_traffic(args)
             if tr is not None:
                 roofline["traffic"] = round(tr["bytes_per_launch"])
-                roofline["traffic_detail"] = {"unit": "bytes per GEMM launch (mean over the step's launches)",
-                                              "hbm_fetch": round(tr["fetch_bytes"]), "hbm_write": round(tr["write_bytes"]),
-                                              "algorithmic": alg_gemm_bytes(bmodel, cfgd, S, dtype)}
+                detail = {"unit": "bytes per GEMM launch (mean over the step's launches)",
+                          "fabric_fetch": round(tr["fetch_bytes"]), "hbm_write": round(tr["write_bytes"]),
+                          "algorithmic": alg_gemm_bytes(bmodel, cfgd, S, dtype)}
+                if "hbm_read_bytes_est" in tr:
+                    # FETCH_SIZE counts the L2's fabric-side reads, Infinity-Cache hits included; split by the mean fabric
+                    # read latency of the launches between an HBM stream and an Infinity-Cache stream (measure_traffic)
+                    detail.update({"hbm_read": round(tr["hbm_read_bytes_est"]),
+                                   "infinity_cache_hit_fraction": tr["infinity_cache_hit_fraction_est"],
+                                   "ea_read_latency_clk": tr["ea_read_latency_clk"],
+                                   "hbm_read_method": "estimate: interpolation of TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ between "
+                                                      "calibration streams in the same pass; no memory-side counter is exposed"})
+                if "fetch_unit_check" in tr:
+                    detail["fetch_unit_check"] = tr["fetch_unit_check"]
+                roofline["traffic_detail"] = detail
         n_ranks = dist.get_world_size() if world > 1 else 1
         per_step = S if args.strong else S * n_ranks
         total_samples = per_step * args.steps
@@ -618,7 +786,9 @@ def main():
             from bayeformers_amd.sampling import shard_span
 
             cfgd["samples_per_gpu"] = [shard_span(S, r, n_ranks)[1] for r in range(n_ranks)]
-        cfgd.update({"parallelism": f"mc-sample-shard x{n_ranks}", "last_elbo": last, "hip_graph": bool(use_graph),
+        if by_rank is not None:
+            roofline["by_rank"] = by_rank
+        cfgd.update({"env": honoured_env(), "parallelism": f"mc-sample-shard x{n_ranks}", "last_elbo": last, "hip_graph": bool(use_graph),
                      "samples_total": total_samples, "samples_per_step": per_step,
                      "allreduce_ms_per_step": round(allreduce_ms, 4) if allreduce_ms is not None else None})
         metric = "MC-samples/sec (fwd+ELBO+backward+AdamW)" if args.workload.endswith("_train") else "MC-samples/sec (fwd+ELBO)"

@@ -43,6 +43,11 @@ typedef struct bf_prior {
     float sigma2;        /* mixture: std of the second component */
     const float* d_mu;   /* gaussian: device, prior mean, same shape as the tensor */
     const float* d_rho;  /* gaussian: device, prior rho (sigma_p = softplus(rho)), same shape */
+    /* gaussian, optional assertion by the caller: pi == 1 says that d_mu[i] equals the tensor's d_mu[i] and
+     * softplus(d_rho[i]) equals sigma1 for every i — the MOPED prior of a frozen mean
+     * (/root/reference/bayeformers/nn/layers/linear.py:147-150: prior.mu is the pretrained tensor the posterior mean shares,
+     * prior.rho = ones).  bf_sample_logprob / bf_sample_logprob_table then read neither (8 instead of 16 bytes per
+     * scalar); every other entry point ignores the assertion and reads d_mu / d_rho, which stay valid.  pi == 0: no claim. */
 } bf_prior_t;
 
 /* One Gaussian variational parameter (a weight or a bias): Gaussian(mu, rho) of
@@ -308,6 +313,20 @@ enum { BF_PROF_SAMPLE = 0, BF_PROF_GEMM = 1, BF_PROF_FUSED_SMALL = 2, BF_PROF_FU
 int bf_profile_enable(int on);
 int bf_profile_reset(void);
 int bf_profile_read(int kind, uint64_t* launches, double* total_ms, double* total_work);
+
+/* Rows per sample (M) up to which bf_linear_fwd runs as its single fused kernel (sampling + log-probs + MFMA in one
+ * launch, no sampled weights in memory) instead of sampling launch + tiled GEMM.  The built-in default is the measured
+ * crossover; the setter (0 .. 128, 0 = never) is a tuning knob for tools/crossover_bench.py.  Python's bnn.Linear asks
+ * the getter, so that layers it keeps out of the cross-layer sampling plan are exactly those the kernel will take. */
+int bf_fused_small_max_rows(void);
+int bf_set_fused_small_max_rows(int rows);
+
+/* Measurement utility, not part of the path: one streaming pass of 16-byte loads over `bytes` (a multiple of 16) of device
+ * memory (kernel bf_probe_read_kernel).  bench.py runs it inside its rocprofv3 --pmc child passes to calibrate the L2's
+ * fabric-side read counters on a known byte count and on data whose home is known (a 2 GiB buffer: HBM; a 96 MiB buffer
+ * read again: the 256 MiB Infinity Cache), which is what lets roofline.traffic_detail split the GEMM's fabric fetch into
+ * HBM reads and Infinity-Cache hits (rocprofv3 exposes no memory-side counter on gfx950).  d_sink: 4 writable bytes. */
+int bf_probe_stream_read(const void* d_buf, size_t bytes, void* d_sink, void* stream);
 
 #ifdef __cplusplus
 }

@@ -126,6 +126,49 @@ def linear_cases():
     return cases
 
 
+
+# ---------------------------------------------------------------------------------------------- C2 at size: 768 -> 768
+def linear768_cases():
+    """BASELINE configs[1] at FULL size, from the real reference: bnn.Linear(768, 768) with the default
+    Uniform init + mixture prior, and the MOPED variant (nn.Linear with w ~ N(0, 0.02^2), delta = 0.05, freeze=True);
+    x ~ N(0, 1) of [32, 768] and [4096, 768]; S = 10.  Stored: the seeds that rebuild layer and inputs (with checksums),
+    the per-sample log-probs, and a subset of the output rows (the full [10, 4096, 768] would be 126 MB)."""
+    S, N, K = 10, 768, 768
+    rows = {32: np.array([0, 31]), 4096: np.array([0, 256, 2049, 4095])}
+    out = {"S": S, "N": N, "K": K, "rows_32": rows[32], "rows_4096": rows[4096]}
+
+    def build(kind):
+        if kind == "mixture":
+            torch.manual_seed(768)
+            return rbnn.Linear(K, N)
+        torch.manual_seed(769)
+        freq = torch.nn.Linear(K, N)
+        with torch.no_grad():
+            freq.weight.normal_(0.0, 0.02)
+            freq.bias.normal_(0.0, 0.02)
+        return rbnn.Linear.from_frequentist(freq, delta=0.05, freeze=True)
+
+    for kind, base in (("mixture", 0), ("moped", 40)):
+        layer = build(kind)
+        out[f"{kind}/checksum"] = checksum(layer)
+        out[f"{kind}/base"] = base
+        clock = {"seed": SEED, "sample": base}
+        inject(layer, clock)
+        for M in (32, 4096):
+            x = torch.randn(M, K, generator=torch.Generator().manual_seed(1000 + M))
+            out[f"x{M}_sum"] = float(x.double().abs().sum())
+            ys, lps, lqs = [], [], []
+            with torch.no_grad():
+                for s in range(S):
+                    clock["sample"] = base + s
+                    ys.append(t2n(layer(x))[rows[M]])
+                    lps.append(float(layer.log_prior))
+                    lqs.append(float(layer.log_variational_posterior))
+            out[f"{kind}/y{M}"] = np.stack(ys)
+            out[f"{kind}/log_prior"] = np.array(lps, np.float64)  # the same for both M (same weights, same eps)
+            out[f"{kind}/lvp"] = np.array(lqs, np.float64)
+    return out
+
 # ---------------------------------------------------------------------------------------------- C1: MLP
 class MLP(torch.nn.Module):
     """The 784-512-512-10 MLP of /root/reference/examples/mlp_mnist.py:16-26 (architecture only)."""
@@ -408,8 +451,12 @@ def main():
     ap.add_argument("--only-c4", action="store_true", help="BASELINE config 4: BERT-base, S = 64 (about 6 minutes of CPU)")
     ap.add_argument("--only-checkpoint", action="store_true")
     ap.add_argument("--only-bert-train", action="store_true")
+    ap.add_argument("--only-linear768", action="store_true", help="BASELINE config 2 at full size (a few seconds of CPU)")
     args = ap.parse_args()
     torch.set_num_threads(8)
+    if args.only_linear768:
+        np.savez_compressed(os.path.join(HERE, "linear768_c2.npz"), **linear768_cases())
+        return
     if args.only_c4:
         np.savez_compressed(os.path.join(HERE, "bert_c4.npz"), **bert_case(False, samples=64))
         return
@@ -428,6 +475,7 @@ def main():
     print("eps KAT"); np.savez_compressed(os.path.join(HERE, "eps_kat.npz"), seed=SEED,
                                          z_s0_str0=bo.normals(64, SEED, 0, 0), z_s9_str5_off3=bo.normals(64, SEED, 9, 5, 3))
     print("linear cases"); np.savez_compressed(os.path.join(HERE, "linear_cases.npz"), **linear_cases())
+    print("linear 768 C2"); np.savez_compressed(os.path.join(HERE, "linear768_c2.npz"), **linear768_cases())
     print("grad cases"); np.savez_compressed(os.path.join(HERE, "linear_grads.npz"), **grad_cases())
     print("conversion"); np.savez_compressed(os.path.join(HERE, "conversion.npz"), **conversion_case())
     print("checkpoint"); np.savez_compressed(os.path.join(HERE, "checkpoint.npz"), **checkpoint_case())

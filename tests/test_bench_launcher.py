@@ -29,6 +29,10 @@ def test_gpus_2_launches_two_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     out = last_json(r.stdout)
     assert out["n_gpus"] == 2 and out["ranks_counted"] == 2 and out["backend"] == "gloo"
+    # the preflight carries the real run's two messages (packed fp64 ELBO buffer, one 128 MiB gradient bucket) and says who
+    # took part
+    assert out["ok"] and out["bucket_ranks_counted"] == 2 and set(out["allreduce_ms"]) == {"packed_fp64_66", "bucket_128MiB"}
+    assert [r["rank"] for r in out["ranks"]] == [0, 1]
 
 
 def test_single_rank_needs_no_launcher():

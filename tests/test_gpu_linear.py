@@ -253,33 +253,88 @@ def test_gemm_tn_detects_transposes_and_rejects_shapes():
                         torch.zeros(shape[0], shape[1], shape[3], device="cuda").bfloat16())
 
 
+@pytest.mark.parametrize("kind", ["mixture", "moped"])
 @pytest.mark.parametrize("M", [32, 4096])
-def test_full_size_layer_768(M):
-    """BASELINE config 2: bnn.Linear(768, 768), S = 10, default init + mixture prior, x ~ N(0,1) [M, 768]."""
-    S, N, K = 10, 768, 768
-    torch.manual_seed(0)
-    layer = bnn.Linear(K, N).cuda()
+def test_full_size_layer_768(golden_dir, kind, M):
+    """BASELINE config 2 at full size against the REAL reference's outputs (tests/golden/linear768_c2.npz):
+    bnn.Linear(768, 768), S = 10, default init + mixture prior and the MOPED variant (delta = 0.05, freeze=True: the
+    aliased-prior fast path of the sampling kernel), x ~ N(0,1) [M, 768].  Every sample's W is compared with the oracle's
+    Gaussian.sample, the outputs with the reference's rows, the log-probs with the reference's values."""
+    from util import linear768_input, linear768_layer, module_checksum
+
+    g = np.load(f"{golden_dir}/linear768_c2.npz")
+    S, N, K = int(g["S"]), 768, 768
+    base = int(g[f"{kind}/base"])
+    layer = linear768_layer(kind)
+    assert module_checksum(layer) == float(g[f"{kind}/checksum"])
+    layer = layer.cuda()
     layer.layer_id = 0
-    x = torch.randn(M, K).cuda()
-    y, lp = run_layer(layer, x, S, 0)
+    if kind == "moped":  # a frozen mean under its MOPED prior: the kernel reads 8 instead of 16 bytes per scalar
+        assert ops.prior_alias(layer.weight, layer.weight_prior) == pytest.approx(float(np.log1p(np.exp(np.float32(1.0)))), rel=1e-6)
+        assert ops.prior_alias(layer.bias, layer.bias_prior) is not None
+    x = linear768_input(M)
+    rows = g[f"rows_{M}"]
+    y_ref = g[f"{kind}/y{M}"]                      # [S, len(rows), 768] from the reference
     mu_w, rho_w = layer.weight.mu.detach().cpu(), layer.weight.rho.detach().cpu()
-    mu_b, rho_b = layer.bias.mu.detach().cpu(), layer.bias.rho.detach().cpu()
-    pw = ("mixture", 0.5, 1.0, float(np.float32(np.exp(-6))))
-    Ws, bs = ops.sample_logprob([layer.weight, layer.bias], [layer.weight_prior, layer.bias_prior], [0, 1], S, SEED, 0,
-                                out_dtype=torch.float32)[0]
+    sig = bo.sigma(rho_w)
+    y, lp = run_layer(layer, x.cuda(), S, base)     # bf16 MFMA path (M = 32: the single fused kernel)
+    bf.set_compute_dtype("fp32")
+    try:
+        y32, lp32 = run_layer(layer, x.cuda(), S, base)
+    finally:
+        bf.set_compute_dtype("bf16")
+    Ws = ops.sample_logprob([layer.weight], [layer.weight_prior], [0], S, SEED, base, out_dtype=torch.float32)[0][0].cpu()
+    tol16 = 2.0 ** -7 * float(x.norm(dim=1).max()) * float((mu_w.abs() + 4 * sig).norm(dim=1).max())
     for s in range(S):
-        eps_w = bo.eps_tensor((N, K), SEED, s, 0, 0)
-        eps_b = bo.eps_tensor((N,), SEED, s, 0, 1)
-        lp64, lq64 = bo.linear_logprobs_f64(mu_w, rho_w, mu_b, rho_b, eps_w, eps_b, pw)
-        assert float(lp[s, 0]) == pytest.approx(lp64, rel=LOGPROB_RTOL)
-        assert float(lp[s, 1]) == pytest.approx(lq64, rel=LOGPROB_RTOL)
-        # y against an fp64 matmul of the kernel's own fp32 samples (checked against the oracle above at small size)
-        ref = x.double() @ Ws[s].double().T + bs[s].double()
-        err = (y[s].double() - ref).abs().max().item()
-        assert err < 2.0 ** -7 * float(x.norm(dim=1).max()) * float(Ws[s].norm(dim=1).max())
-        if s == 0:
-            W = bo.gaussian_sample(mu_w, rho_w, eps_w)
-            assert (Ws[0].cpu() - W).abs().max().item() < 1e-6
+        assert float(lp[s, 0]) == pytest.approx(g[f"{kind}/log_prior"][s], rel=LOGPROB_RTOL)
+        assert float(lp[s, 1]) == pytest.approx(g[f"{kind}/lvp"][s], rel=LOGPROB_RTOL)
+        assert float(lp32[s, 0]) == pytest.approx(g[f"{kind}/log_prior"][s], rel=LOGPROB_RTOL)
+        assert float(lp32[s, 1]) == pytest.approx(g[f"{kind}/lvp"][s], rel=LOGPROB_RTOL)
+        W = bo.gaussian_sample(mu_w, rho_w, bo.eps_tensor((N, K), SEED, base + s, 0, 0))
+        assert bool(((Ws[s] - W).abs() <= 4e-6 * sig + 1e-7 * W.abs()).all())          # EVERY sample's weights
+        ref = torch.from_numpy(y_ref[s])
+        scale = float(ref.abs().max())
+        assert (y32[s].cpu()[rows] - ref).abs().max().item() <= Y_FP32_RTOL * scale     # exact-fp32 path vs the reference
+        assert (y[s].float().cpu()[rows] - ref).abs().max().item() < tol16              # bf16 path, stated tolerance
+
+
+def test_moped_alias_path_equals_general_path_and_tracks_edits(golden_dir):
+    """The aliased MOPED prior (frozen mean, constant prior sigma: /root/reference/bayeformers/nn/layers/linear.py:147-150)
+    gives the log-probs of the general Gaussian-prior path; a trainable mean is never aliased; an in-place edit of the prior
+    ends the alias and the kernel follows the edited prior."""
+    from util import linear768_layer
+
+    g = np.load(f"{golden_dir}/linear768_c2.npz")
+    S, base = 4, int(g["moped/base"])
+    layer = linear768_layer("moped").cuda()
+    layer.layer_id = 0
+    gs, prs = [layer.weight, layer.bias], [layer.weight_prior, layer.bias_prior]
+    lp_alias = ops.sample_logprob(gs, prs, [0, 1], S, SEED, base, out_dtype=None)[1].cpu()
+    assert ops.prior_alias(layer.weight, layer.weight_prior) is not None
+    layer.weight.mu.requires_grad_(True)
+    layer.bias.mu.requires_grad_(True)
+    assert ops.prior_alias(layer.weight, layer.weight_prior) is None
+    lp_general = ops.sample_logprob(gs, prs, [0, 1], S, SEED, base, out_dtype=None)[1].cpu()
+    for s in range(S):
+        assert float(lp_alias[s, 0]) == pytest.approx(float(lp_general[s, 0]), rel=LOGPROB_RTOL)
+        assert float(lp_alias[s, 0]) == pytest.approx(g["moped/log_prior"][s], rel=LOGPROB_RTOL)
+        assert float(lp_alias[s, 1]) == float(lp_general[s, 1])
+    # edited prior: no longer one constant sigma
+    layer.weight.mu.requires_grad_(False)
+    layer.bias.mu.requires_grad_(False)
+    assert ops.prior_alias(layer.weight, layer.weight_prior) is not None
+    with torch.no_grad():
+        layer.weight_prior.rho[5, 7] = 3.0
+        layer.weight_prior.mu[2, 3] += 0.25
+    assert ops.prior_alias(layer.weight, layer.weight_prior) is None
+    lp_edit = ops.sample_logprob(gs, prs, [0, 1], 1, SEED, base, out_dtype=None)[1].cpu()
+    t = lambda p: p.detach().cpu()
+    eps_w, eps_b = bo.eps_tensor((768, 768), SEED, base, 0, 0), bo.eps_tensor((768,), SEED, base, 0, 1)
+    lp64, lq64 = bo.linear_logprobs_f64(t(layer.weight.mu), t(layer.weight.rho), t(layer.bias.mu), t(layer.bias.rho), eps_w,
+                                        eps_b, ("gaussian", t(layer.weight_prior.mu), t(layer.weight_prior.rho)),
+                                        ("gaussian", t(layer.bias_prior.mu), t(layer.bias_prior.rho)))
+    assert float(lp_edit[0, 0]) == pytest.approx(lp64, rel=LOGPROB_RTOL) and float(lp_edit[0, 0]) != float(lp_alias[0, 0])
+    assert float(lp_edit[0, 1]) == pytest.approx(lq64, rel=LOGPROB_RTOL)
 
 
 @pytest.mark.parametrize("S,M,N,K", [(2, 300, 200, 128), (1, 40, 24, 72), (2, 513, 259, 192)])

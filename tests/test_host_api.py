@@ -203,3 +203,39 @@ def test_recompute_context_is_bound_to_the_graph_that_runs_backward():
         (y1.sum() + y2.sum()).backward()
     # a finished forward keeps no activations
     assert all(c.shared_out == {} for c in bfr.STATE.live_ctxs) and len(bfr.STATE.live_ctxs) <= bfr.LIVE_CONTEXTS
+
+
+def test_moped_prior_alias_is_decided_on_contents_and_tracks_edits():
+    """ops.prior_alias: the sampling kernel may skip the prior's mu / rho (8 instead of 16 bytes per scalar) exactly when
+    the prior is N(the posterior's frozen mean, one constant sigma) — what to_bayesian(delta, freeze=True) builds
+    (/root/reference/bayeformers/nn/layers/linear.py:140-150)."""
+    import copy
+
+    import bayeformers_amd as bf
+    from bayeformers_amd import ops
+
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(12, 9), torch.nn.Tanh(), torch.nn.Linear(9, 4))
+    frozen = bf.to_bayesian(copy.deepcopy(net), delta=0.05, freeze=True)
+    lin = frozen.model[0]
+    sp = float(torch.nn.functional.softplus(torch.tensor(1.0)))
+    assert ops.prior_alias(lin.weight, lin.weight_prior) == pytest.approx(sp, rel=1e-7)
+    assert ops.prior_alias(lin.bias, lin.bias_prior) == pytest.approx(sp, rel=1e-7)
+    # equal copies instead of one storage (what a device move leaves behind): still an alias
+    lin.weight_prior.mu.data = lin.weight_prior.mu.data.clone()
+    assert lin.weight_prior.mu.data_ptr() != lin.weight.mu.data_ptr()
+    assert ops.prior_alias(lin.weight, lin.weight_prior) is not None
+    # a trainable mean is never aliased
+    trainable = bf.to_bayesian(copy.deepcopy(net), delta=0.05, freeze=False)
+    assert ops.prior_alias(trainable.model[0].weight, trainable.model[0].weight_prior) is None
+    # in-place edits (optimizer steps, load_state_dict) bump the version counter: seen, re-checked
+    with torch.no_grad():
+        lin.weight_prior.rho[0, 0] = 2.0
+    assert ops.prior_alias(lin.weight, lin.weight_prior) is None
+    with torch.no_grad():
+        lin.weight_prior.rho[0, 0] = 1.0
+        lin.weight.mu[1, 1] += 1.0
+    assert ops.prior_alias(lin.weight, lin.weight_prior) is None
+    with torch.no_grad():
+        lin.weight_prior.mu.copy_(lin.weight.mu)
+    assert ops.prior_alias(lin.weight, lin.weight_prior) is not None

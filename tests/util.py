@@ -66,3 +66,27 @@ def run_layer(layer, x, S, base, seed=SEED):
     with torch.no_grad(), model.monte_carlo(S):
         y = model(x.repeat(S, *([1] * (x.dim() - 1))))
     return y.view(S, -1, layer.out_features), model.log_prob_samples().clone()
+
+
+def linear768_layer(kind):
+    """The layer of tests/golden/linear768_c2.npz (BASELINE configs[1] at full size), rebuilt from its seeds with THIS
+    package's classes — the constructor and MOPED conversion are bit-identical to the reference's
+    (tests/test_host_api.py), which the fixture's checksum confirms.  Mirrors make_golden.linear768_cases.build."""
+    K = N = 768
+    if kind == "mixture":
+        torch.manual_seed(768)
+        return bnn.Linear(K, N)
+    torch.manual_seed(769)
+    freq = torch.nn.Linear(K, N)
+    with torch.no_grad():
+        freq.weight.normal_(0.0, 0.02)
+        freq.bias.normal_(0.0, 0.02)
+    return bnn.Linear.from_frequentist(freq, delta=0.05, freeze=True)
+
+
+def linear768_input(M):
+    return torch.randn(M, 768, generator=torch.Generator().manual_seed(1000 + M))
+
+
+def module_checksum(module):
+    return float(sum(p.detach().double().abs().sum() for p in module.parameters()))
