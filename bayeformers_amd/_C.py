@@ -64,8 +64,6 @@ SYMBOLS = {
     "bf_gemm_schedule": (_sz, [_i, _i, _i, _i, _i, _vp, _sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "bf_linear_fwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "bf_linear_fwd": (_i, [_vp, _i, _i64, _tp, _tp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u32, _vp, _vp, _sz, _vp]),
-    "bf_linear_fwd_ws_workspace_bytes": (_sz, [_i, _i]),
-    "bf_linear_fwd_ws": (_i, [_vp, _i, _i64, _tp, _tp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u32, _i, _vp, _vp, _sz, _vp]),
     "bf_linear_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "bf_linear_bwd": (_i, [_vp, _i64, _vp, _i, _tp, _tp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u64, _u32, _i, _vp,
                            _vp, _sz, _vp]),
@@ -84,6 +82,7 @@ SYMBOLS = {
     "bf_probe_stream_read": (_i, [_vp, _sz, _vp, _vp]),
     "bf_fused_small_max_rows": (_i, []),
     "bf_set_fused_small_max_rows": (_i, [_i]),
+    "bf_fused_small_rows_for": (_i, [_i, _i]),
     "bf_profile_read": (_i, [_i, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
                              ctypes.POINTER(ctypes.c_double)]),
 }
@@ -91,6 +90,12 @@ BF_PROF_SAMPLE, BF_PROF_GEMM, BF_PROF_FUSED_SMALL, BF_PROF_FUSED_WS = 0, 1, 2, 3
 BF_ACT_NONE, BF_ACT_GELU = 0, 1
 
 ABI_VERSION = 2  # bf_version() of the library these bindings describe (include/bayeformers_amd.h: BF_VERSION_*)
+
+# developer-build entry points (csrc/bf_dev_api.h): bound when the loaded library has them (BF_LIB_PATH=..._dev.so)
+DEV_SYMBOLS = {
+    "bf_linear_fwd_ws_workspace_bytes": (_sz, [_i, _i]),
+    "bf_linear_fwd_ws": (_i, [_vp, _i, _i64, _tp, _tp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u32, _i, _vp, _vp, _sz, _vp]),
+}
 
 _lib = None
 
@@ -112,6 +117,11 @@ def lib():
             fn = getattr(l, name)  # AttributeError here = header/library drift
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in DEV_SYMBOLS.items():
+            fn = getattr(l, name, None)
+            if fn is not None:
+                fn.restype = res
+                fn.argtypes = args
         if l.bf_version() != ABI_VERSION:  # a stale .so called through newer signatures corrupts the stack: refuse it
             raise BayeFormersAMDError(
                 f"{LIB_PATH} is version {l.bf_version()}, these bindings expect {ABI_VERSION}: rebuild it with "

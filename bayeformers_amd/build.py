@@ -17,10 +17,11 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libbayeformers_amd.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-# (bf_fused_ws.hip — the weight-stationary single-kernel variant of NS-1 — is built and tested (tests/test_gpu_fused_ws.py)
-# but nothing dispatches to it: measured 2.1-3.3x slower than sampling launch + 256-wide GEMM, DESIGN.md section 4.3.
-# It stays in the library as the measured alternative the north-star sentence asks about.)
-SOURCES = ["bf_api.hip", "bf_sample.hip", "bf_gemm.hip", "bf_gemm256.hip", "bf_gemm256_r5.hip", "bf_backward.hip", "bf_fused_small.hip", "bf_fused_ws.hip", "bf_norm.hip", "bf_attention.hip", "bf_attention_bwd.hip"]
+# The product library carries only code something dispatches to.  bf_fused_ws.hip — the weight-stationary single-kernel
+# variant of NS-1, measured slower than both alternatives at every M (profiles/r4b_mid_m_crossover.txt)
+# — and the round-1 GEMM kernel are DEV_SOURCES: built into libbayeformers_amd_dev.so only (tests/test_gpu_fused_ws.py and
+# the tools/ micro-benchmarks select it with BF_LIB_PATH).
+SOURCES = ["bf_api.hip", "bf_sample.hip", "bf_gemm.hip", "bf_gemm256.hip", "bf_gemm256_r5.hip", "bf_backward.hip", "bf_fused_small.hip", "bf_norm.hip", "bf_attention.hip", "bf_attention_bwd.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 
@@ -49,7 +50,7 @@ def _stale(target, deps):
 # (BF_GEMM_VARIANT, BF_GEMM_ABLATE, BF_GEMM_SCHED, BF_ATTN_ABLATE) and the round-1 GEMM kernel that the product
 # library compiles out.  Select it with BF_LIB_PATH=bayeformers_amd/lib/libbayeformers_amd_dev.so.
 DEV_LIB = os.path.join(LIBDIR, "libbayeformers_amd_dev.so")
-DEV_SOURCES = ["bf_gemm256_r1.hip"]
+DEV_SOURCES = ["bf_gemm256_r1.hip", "bf_fused_ws.hip"]
 
 
 def build(force=False, verbose=True, dev=False):

@@ -4,6 +4,9 @@
 #include <string.h>
 
 #include "bf_common.h"
+#ifdef BF_DEV
+#include "bf_dev_api.h"
+#endif
 #include "bf_gemm_params.h"
 #include "bf_philox.h"
 
@@ -351,6 +354,7 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
                              (hipStream_t)stream);
 }
 
+#ifdef BF_DEV  // csrc/bf_dev_api.h
 size_t bf_linear_fwd_ws_workspace_bytes(int S, int N) {
     if (S < 1 || N < 1) return 0;
     return bf_align_up(bf_fused_ws_partial_rows(N) * (size_t)S * 2 * sizeof(double), 256);
@@ -375,6 +379,7 @@ int bf_linear_fwd_ws(const void* d_x, int x_dtype, int64_t x_sample_stride, cons
     return bf_launch_reduce_partials(reinterpret_cast<const double*>(d_workspace),
                                      (uint32_t)bf_fused_ws_partial_rows(N), S, d_logprob_out, (hipStream_t)stream);
 }
+#endif  // BF_DEV
 
 int bf_kl_grad(const bf_tensor_t* tensor, int S, uint64_t seed, uint32_t sample_base, const double* d_g,
                float* d_dmu, float* d_drho, void* stream) {

@@ -297,15 +297,22 @@ void mixture_consts(const bf_prior_t& pr, float& a1, float& b1, float& a2, float
 
 }  // namespace
 
-// Rows per sample up to which the single fused kernel is dispatched (the kernel itself takes up to 128: 8 MFMA column
-// blocks per sampled weight fragment).  The default is the measured crossover against sampling launch + tiled GEMM
-// (profiles/r4*_mid_m_crossover.txt); bf_set_fused_small_max_rows() moves it (tools/crossover_bench.py).
-static int g_fused_small_max_rows = 64;
+// Rows per sample up to which the single fused kernel is dispatched for an N x K layer.  The kernel itself takes up to 128
+// (8 MFMA column blocks per sampled weight fragment); the measured crossover against sampling launch + tiled GEMM
+// (profiles/r4b_mid_m_crossover.txt, r4c_mlp_fused_threshold_ab.txt): up to 64 rows it wins or ties at every layer size
+// (one launch instead of three), from 65 to 128 rows only for layers of at most 512 x 512 weights (BASELINE configs[0]'s
+// hidden layers) — wider layers re-read x once per 16 output features and fall behind the tiled GEMM.
+// bf_set_fused_small_max_rows() caps both (tools/crossover_bench.py, BF_FUSED_SMALL_MAX_ROWS).
+static int g_fused_small_max_rows = 128;
 extern "C" int bf_fused_small_max_rows(void) { return g_fused_small_max_rows; }
 extern "C" int bf_set_fused_small_max_rows(int rows) {
     if (rows < 0 || rows > 128) BF_FAIL("bf_set_fused_small_max_rows: 0 .. 128 (got %d)", rows);
     g_fused_small_max_rows = rows;
     return 0;
+}
+extern "C" int bf_fused_small_rows_for(int N, int K) {
+    const int by_size = (long long)N * K <= 512ll * 512ll ? 128 : 64;
+    return by_size < g_fused_small_max_rows ? by_size : g_fused_small_max_rows;
 }
 
 // Is the single-kernel path applicable?  (M <= bf_fused_small_max_rows(), K % 32 == 0, 16-byte aligned operands, 16-bit MFMA operands.)
@@ -314,14 +321,13 @@ bool bf_fused_small_supported(int x_dtype, int y_dtype, int compute_dtype, int64
     if (compute_dtype != BF_DT_BF16 && compute_dtype != BF_DT_F16) return false;
     if (x_dtype != compute_dtype && x_dtype != BF_DT_F32) return false;
     if (y_dtype != x_dtype) return false;
-    if (M < 1 || M > g_fused_small_max_rows || K % 32 != 0 || S > 65535) return false;
+    if (M < 1 || M > bf_fused_small_rows_for(N, K) || K % 32 != 0 || S > 65535) return false;
     const size_t xs = bf_dtype_size(x_dtype);
     uintptr_t bits = (uintptr_t)d_x | (uintptr_t)weight->d_mu | (uintptr_t)weight->d_rho | (uintptr_t)((size_t)x_sample_stride * xs);
     if (weight->prior.kind == BF_PRIOR_GAUSSIAN) bits |= (uintptr_t)weight->prior.d_mu | (uintptr_t)weight->prior.d_rho;
     if (bits & 15) return false;
     if (((size_t)K * xs) % 16 != 0) return false;
     (void)bias;
-    (void)N;
     return true;
 }
 

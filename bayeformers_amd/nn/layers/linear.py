@@ -205,7 +205,7 @@ class Linear(KernelLayer):
         need_grad = torch.is_grad_enabled() and any(
             t is not None and t.requires_grad for t in (x2, self.weight.mu, self.weight.rho, mu_b, rho_b))
         rows_per_sample = x2.shape[0] // S
-        small = rows_per_sample <= ops.fused_small_max_rows() and self.in_features % 32 == 0 and x2.dtype != torch.float64
+        small = rows_per_sample <= ops.fused_small_rows(self.out_features, self.in_features) and self.in_features % 32 == 0 and x2.dtype != torch.float64
         if small != self._small_m:
             self._small_m = small  # the model rebuilds its sampling plan without / with this layer next forward
         if ctx is not None and ctx.plan is not None and not small and id(self) in ctx.plan.group_of:

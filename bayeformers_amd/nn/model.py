@@ -142,7 +142,7 @@ class Model(Module):
                 shared = tuple(sorted({id(l._shared_input): l._shared_input for l in pl
                                        if l._shared_input is not None}.values(), key=lambda t: t[0].layer_id))
                 key = SamplePlan.make_key(pl, S, cdt, shared)
-                if self._plan is None or self._plan.key != key:
+                if self._plan is None or self._plan.key != key or not self._plan.alias_valid():
                     self._plan = SamplePlan(pl, S, cdt, layers[0].weight.mu.device, index=[i for i, _ in planned],
                                             shared=shared)
                 plan = self._plan

@@ -5,6 +5,7 @@ step of the Monte-Carlo forward path runs in the HIP kernels of csrc/.  There is
 are not on a ROCm device raise.
 """
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -47,9 +48,20 @@ def philox_normal_host(n: int, seed: int, sample: int, stream_id: int, offset: i
     return out
 
 
-def fused_small_max_rows() -> int:
-    """Rows per sample up to which bf_linear_fwd is ONE fused kernel (bf_fused_small_max_rows, the measured crossover)."""
-    return _C.lib().bf_fused_small_max_rows()
+_FUSED_ROWS_SET = False
+
+
+def fused_small_rows(N: int, K: int) -> int:
+    """Rows per sample up to which bf_linear_fwd runs an N x K layer as ONE fused kernel (bf_fused_small_rows_for: the
+    measured crossover; BF_FUSED_SMALL_MAX_ROWS caps it for developer A/B runs)."""
+    global _FUSED_ROWS_SET
+    lib = _C.lib()
+    if not _FUSED_ROWS_SET:
+        _FUSED_ROWS_SET = True
+        v = os.environ.get("BF_FUSED_SMALL_MAX_ROWS")
+        if v is not None:
+            _C.check(lib.bf_set_fused_small_max_rows(int(v)), "bf_set_fused_small_max_rows")
+    return lib.bf_fused_small_rows_for(int(N), int(K))
 
 
 def philox_normal(n: int, S: int, seed: int, sample_base: int, stream_id: int, device="cuda") -> Tensor:
@@ -60,6 +72,9 @@ def philox_normal(n: int, S: int, seed: int, sample_base: int, stream_id: int, d
     return out
 
 
+_NO_ALIAS = os.environ.get("BF_NO_PRIOR_ALIAS") is not None  # developer A/B: always read the prior's mu / rho
+
+
 def prior_alias(gaussian, prior) -> Optional[float]:
     """sigma_p when `prior` is the MOPED prior of a FROZEN mean — Gaussian(mu = the posterior's mean, rho = one constant),
     /root/reference/bayeformers/nn/layers/linear.py:147-150 with freeze=True — else None.  The sampling kernel then reads
@@ -68,7 +83,7 @@ def prior_alias(gaussian, prior) -> Optional[float]:
     version counters, so an in-place edit of either (an optimizer step on a trainable mean, load_state_dict) is seen and
     re-checked.  A trainable mean is never aliased: it leaves the prior's at its first update."""
     mu, pmu, prho = gaussian.mu, prior.mu, prior.rho
-    if mu.requires_grad or pmu.shape != mu.shape or prho.shape != mu.shape or pmu.dtype != torch.float32:
+    if _NO_ALIAS or mu.requires_grad or pmu.shape != mu.shape or prho.shape != mu.shape or pmu.dtype != torch.float32:
         return None
     state = (mu.data_ptr(), mu._version, pmu.data_ptr(), pmu._version, prho.data_ptr(), prho._version)
     hit = getattr(prior, "_bf_alias", None)
@@ -277,6 +292,9 @@ def linear_forward_ws(layer, x: Tensor, S: int, seed: int, sample_base: int, lp_
     sampling launch + GEMM for large M.  Same arguments and results as linear_forward; 16-bit x only."""
     from .nn.parameters.base import NoneParameter
 
+    if not hasattr(_C.lib(), "bf_linear_fwd_ws"):
+        raise _C.BayeFormersAMDError("bf_linear_fwd_ws is a developer-build entry point: python -m bayeformers_amd.build --dev, "
+                                     "then BF_LIB_PATH=bayeformers_amd/lib/libbayeformers_amd_dev.so")
     _require_device(x, "input")
     K, N = layer.in_features, layer.out_features
     x = x if x.is_contiguous() else x.contiguous()

@@ -120,6 +120,10 @@ class SamplePlan:
         # table: entries in layer order (weight, then bias)
         n_entries = sum(1 + (self.slices[id(l)][2] is not None) for l in layers)
         arr = (_C.bf_tensor_t * n_entries)()
+        # The table bakes in which Gaussian priors are aliases of their posterior's frozen mean (ops.prior_alias: the kernel
+        # then reads neither the prior's mu nor its rho).  That was decided on the tensors' contents: `alias_watch` keeps
+        # their version counters, and Model rebuilds the plan when one of them moved (alias_valid).
+        self.alias_watch = []
         self.views = {}
         first_entry_of_layer = []
         e = 0
@@ -130,6 +134,7 @@ class SamplePlan:
             N, K = l.out_features, l.in_features
             if not ops.fill_tensor(arr[e], l.weight, l.weight_prior, 2 * l.layer_id):
                 raise _C.BayeFormersAMDError("SamplePlan: user-defined priors are not plannable")
+            self._watch(arr[e], l.weight, l.weight_prior)
             wv = arena[woff:woff + S * N * K * esz].view(cdt).view(S, N, K)
             arr[e].d_sample_out, arr[e].out_dtype = wv.data_ptr(), ops._TORCH2BF[cdt]
             e += 1
@@ -137,6 +142,7 @@ class SamplePlan:
             if boff is not None:
                 if not ops.fill_tensor(arr[e], l.bias, l.bias_prior, 2 * l.layer_id + 1):
                     raise _C.BayeFormersAMDError("SamplePlan: user-defined priors are not plannable")
+                self._watch(arr[e], l.bias, l.bias_prior)
                 bv = arena[boff:boff + S * N * 4].view(torch.float32).view(S, N)
                 arr[e].d_sample_out, arr[e].out_dtype = bv.data_ptr(), _C.BF_DT_F32
                 e += 1
@@ -168,6 +174,18 @@ class SamplePlan:
             li += len(g)
         self.scalars = sum(l.weight.mu.numel() + (l.out_features if self.slices[id(l)][2] is not None else 0) for l in layers)
 
+    def _watch(self, entry, gaussian, prior) -> None:
+        if entry.prior.kind == _C.BF_PRIOR_GAUSSIAN and entry.prior.pi == 1.0:
+            for t in (gaussian.mu, prior.mu, prior.rho):
+                self.alias_watch.append((t, t._version))
+
+    def alias_valid(self) -> bool:
+        """False once a tensor behind an aliased prior was edited in place since the table was built."""
+        for t, v in self.alias_watch:
+            if t._version != v:
+                return False
+        return True
+
     @staticmethod
     def make_key(layers, S, cdt, shared=()):
         from .nn.parameters.gaussian import Gaussian
@@ -175,11 +193,6 @@ class SamplePlan:
         key = [S, cdt, len(layers), tuple(tuple(l.layer_id for l in t) for t in shared)]
         for l in layers:
             key.append(l.layer_id)
-            # the table bakes in whether a Gaussian prior is the alias of its posterior's frozen mean (ops.prior_alias)
-            if isinstance(l.weight_prior, Gaussian):
-                key.append(ops.prior_alias(l.weight, l.weight_prior))
-            if isinstance(l.bias_prior, Gaussian) and isinstance(l.bias, Gaussian):
-                key.append(ops.prior_alias(l.bias, l.bias_prior))
             for g in (l.weight, l.bias, l.weight_prior, l.bias_prior):
                 if isinstance(g, Gaussian):
                     key.append(g.mu.data_ptr())

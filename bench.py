@@ -90,10 +90,10 @@ def honoured_env():
 
 def timed_cpu(fn, n):
     """cpu_baseline timing (core count stated, mean and min of >= 5 after a warm-up): `fn` is
-    first timed once at 8, 32 and all host threads — the port is memory-bound and oversubscribes on a many-core host, so
-    'all threads' is not its best — then `n` times at the best count.  Returns (threads, [seconds], {threads: seconds})."""
+    first timed once at 8, 16, 32 and 64 threads — the port oversubscribes on a many-core host (measured: 1.5 s per
+    BERT-base sample at 32 threads, 256 s at all 256) — then `n` times at the best count.  Returns (threads, [seconds], {threads: seconds})."""
     nproc = os.cpu_count() or 1
-    cands = sorted({min(t, nproc) for t in (8, 32, nproc)})
+    cands = sorted({min(t, nproc) for t in (8, 16, 32, 64)})  # (all 256 threads of a GPU host: minutes per sample)
     prev = torch.get_num_threads()
     sweep = {}
     try:
@@ -359,28 +359,65 @@ def alg_gemm_bytes(bmodel, cfgd, S, dtype):
     return round(sum(tot) / len(tot)) if tot else None
 
 
-def calibration_probes(device):
-    """Inside a rocprofv3 --pmc child pass (--calibrate-traffic): streaming reads whose byte count and home are known, ahead
-    of the workload, so that the SAME pass yields the counters' calibration: a 2 GiB buffer (eight times the 256 MiB
-    Infinity Cache: served by HBM) read once, then a 96 MiB buffer (three times the aggregate L2, well inside the Infinity
-    Cache) read three times — its third pass comes from the cache.  Kernel: bf_probe_read_kernel (bf_probe_stream_read)."""
-    from bayeformers_amd import _C
+GEMM_POSITIONS = ("qkv", "attn_out", "ffn_up_gelu", "ffn_down")  # order of the tiled launches inside a BERT layer
+
+
+def calibration_probes(device, shapes=None, S=10, M=4096, dtype=torch.bfloat16):
+    """Inside a rocprofv3 --pmc child pass (--calibrate-traffic), ahead of the workload: launches whose byte count and
+    data home are KNOWN, so that the same pass yields the counters' calibration.
+      * bf_probe_read_kernel over a 2 GiB buffer (eight times the 256 MiB Infinity Cache: every line from HBM), then
+        three passes over a 96 MiB buffer (inside the cache, three times the aggregate L2): checks the FETCH_SIZE unit;
+      * for each tiled-GEMM shape of the step (`shapes`: [(layers, N, K, act)]), the launch itself twice: once after the
+        2 GiB read has pushed everything out of the Infinity Cache (operands from HBM), once more straight after (operands
+        as cache-resident as that launch can have them).  The step's own launches of the same shape are then placed between
+        these two by their mean fabric read latency (measure_traffic)."""
+    from bayeformers_amd import _C, ops
 
     lib = _C.lib()
     big = torch.full((2 << 30,), 1, dtype=torch.uint8, device=device)
     small = torch.full((96 << 20,), 1, dtype=torch.uint8, device=device)
     sink = torch.zeros(1, dtype=torch.int32, device=device)
-    torch.cuda.synchronize()
     st = torch.cuda.current_stream().cuda_stream
-    _C.check(lib.bf_probe_stream_read(big.data_ptr(), big.numel(), sink.data_ptr(), st), "bf_probe_stream_read")
+
+    def read(buf):
+        _C.check(lib.bf_probe_stream_read(buf.data_ptr(), buf.numel(), sink.data_ptr(), st), "bf_probe_stream_read")
+
+    torch.cuda.synchronize()
+    read(big)
     for _ in range(3):
-        _C.check(lib.bf_probe_stream_read(small.data_ptr(), small.numel(), sink.data_ptr(), st), "bf_probe_stream_read")
+        read(small)
+    for L, N, K, act in shapes or ():
+        g = torch.Generator(device=device).manual_seed(N * 7 + K)
+        x = torch.randn(S, M, K, device=device, generator=g).to(dtype)
+        w = (torch.randn(L, S, N, K, device=device, generator=g) * 0.05).to(dtype)
+        bias = torch.randn(L, S, N, device=device, generator=g)
+
+        def launch():
+            if L > 1:
+                return ops.gemm_nt_layers(x, w, bias, L, S, M, N, K, M * K, dtype, act)
+            return ops.gemm_nt(x, w[0], bias[0], S, M, N, K, M * K, dtype, act)
+
+        y = launch()  # builds the tile schedule of the shape (a device allocation) outside the measured pair
+        del y
+        read(big)     # flush: nothing of x, w or y is left on chip
+        y = launch()  # cold
+        y2 = launch()  # hot
+        del y, y2
     torch.cuda.synchronize()
     del big, small
     torch.cuda.empty_cache()
 
 
-PROBE_BYTES = (2 << 30, 96 << 20, 96 << 20, 96 << 20)  # calibration_probes' four dispatches, in order
+PROBE_BYTES = (2 << 30, 96 << 20, 96 << 20, 96 << 20)  # calibration_probes' first four bf_probe_read_kernel dispatches
+
+
+def bert_gemm_shapes(workload):
+    """[(layers in the launch, N, K, activation)] of the step's tiled launches in layer order, M, dtype."""
+    if workload == "bert_base":
+        return [(3, 768, 768, 0), (1, 768, 768, 0), (1, 3072, 768, 1), (1, 768, 3072, 0)], 32 * 128, torch.bfloat16
+    if workload == "bert_large_qa":
+        return [(3, 1024, 1024, 0), (1, 1024, 1024, 0), (1, 4096, 1024, 1), (1, 1024, 4096, 0)], 16 * 384, torch.float16
+    return None, None, None
 
 
 def measure_traffic(args):
@@ -389,10 +426,13 @@ def measure_traffic(args):
     run of this same workload, values in KiB, FETCH_SIZE doubled (gfx950 reports half the bytes of wide 16 B/lane
     reads, which is what the LDS-DMA loads are; re-measured in the same pass on bf_probe_read_kernel's known byte
     counts and reported as `fetch_unit_check`), WRITE_SIZE as is for the 16-byte epilogue stores.
-    A third pass (TCC_EA0_RDREQ_sum, TCC_EA0_RDREQ_LEVEL_sum) gives the mean time an L2 read request spends on the fabric
-    (LEVEL / REQ, L2 clocks): rocprofv3 lists no memory-side (Infinity Cache / UMC) counter on gfx950, and FETCH_SIZE
-    counts cache hits and HBM reads alike, so the split is an ESTIMATE by interpolation between the two calibration
-    streams of that pass (2 GiB from HBM, 96 MiB from the Infinity Cache).  Returns None if the profiler is unavailable."""
+    FETCH_SIZE counts the L2's fabric-side reads: Infinity-Cache hits and HBM reads alike, and rocprofv3 lists no
+    memory-side (Infinity Cache / UMC) counter on gfx950 (profiles/r4a_rocprofv3_counter_blocks.txt).  A third pass
+    (TCC_EA0_RDREQ_sum, TCC_EA0_RDREQ_LEVEL_sum) therefore takes the mean time a read request of the L2 spends on the
+    fabric (LEVEL / REQ, L2 clocks) for every GEMM launch and places the step's launches, shape by shape, between the SAME
+    launch run with all operands in HBM (after a 2 GiB flush) and run again straight after (operands as cache-resident as
+    they can be): hit fraction ~ (t_cold - t_step) / (t_cold - t_hot), an ESTIMATE.  Returns None if the profiler is
+    unavailable."""
     import csv
     import glob
     import shutil
@@ -402,7 +442,9 @@ def measure_traffic(args):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None
-    out, probe = {}, {}
+    shapes, _, _ = bert_gemm_shapes(args.workload)
+    n_cal = 3 * len(shapes) if shapes else 0  # per shape: schedule-building launch, cold, hot
+    gemm, probe = {}, {}
     tmp = tempfile.mkdtemp(prefix="bf_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     is_gemm = lambda name: "gemm256_ring5" in name or "gemm256_sched" in name
     try:
@@ -410,9 +452,7 @@ def measure_traffic(args):
             d = os.path.join(tmp, counters[0])
             cmd = [rocprof, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "-o", "t", "--",
                    sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", "2", "--warmup", "1",
-                   "--no-cpu-baseline", "--no-traffic", "--graph", "off"]
-            if counters[0] != "WRITE_SIZE":
-                cmd.append("--calibrate-traffic")
+                   "--no-cpu-baseline", "--no-traffic", "--graph", "off", "--calibrate-traffic"]
             if args.samples:
                 cmd += ["--samples", str(args.samples)]
             if args.dtype:
@@ -427,39 +467,49 @@ def measure_traffic(args):
                     raise
                 continue  # the latency pass is optional
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            vals = {c: [] for c in counters}
-            pvals = {c: [] for c in counters}
+            gv = {c: [] for c in counters}
+            pv = {c: [] for c in counters}
             for f in files:
                 for r in csv.DictReader(open(f)):
                     c = r["Counter_Name"]
-                    if c not in vals:
+                    if c not in gv:
                         continue
+                    row = (int(r.get("Dispatch_Id", 0) or 0), float(r["Counter_Value"]))
                     if is_gemm(r["Kernel_Name"]):
-                        vals[c].append(float(r["Counter_Value"]))
+                        gv[c].append(row)
                     elif "bf_probe_read_kernel" in r["Kernel_Name"]:
-                        pvals[c].append((int(r.get("Dispatch_Id", 0) or 0), float(r["Counter_Value"])))
+                        pv[c].append(row)
             for c in counters:
-                if vals[c]:
-                    out[c] = sum(vals[c]) / len(vals[c])
-                probe[c] = [v for _, v in sorted(pvals[c])]
-        if "FETCH_SIZE" not in out or "WRITE_SIZE" not in out:
+                gemm[c] = [v for _, v in sorted(gv[c])]   # in dispatch order: calibration launches first, then the steps
+                probe[c] = [v for _, v in sorted(pv[c])]
+        step = lambda c: gemm.get(c, [])[n_cal:]
+        mean = lambda v: sum(v) / len(v)
+        if not step("FETCH_SIZE") or not step("WRITE_SIZE"):
             return None
-        res = {"bytes_per_launch": 2.0 * out["FETCH_SIZE"] * 1024.0 + out["WRITE_SIZE"] * 1024.0,
-               "fetch_bytes": 2.0 * out["FETCH_SIZE"] * 1024.0, "write_bytes": out["WRITE_SIZE"] * 1024.0}
+        fetch, write = 2.0 * 1024.0 * mean(step("FETCH_SIZE")), 1024.0 * mean(step("WRITE_SIZE"))
+        res = {"bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write}
         pf = probe.get("FETCH_SIZE") or []
-        if len(pf) == len(PROBE_BYTES):
+        if len(pf) >= len(PROBE_BYTES) and pf[0] > 0:
             # bytes of a known streaming read per byte FETCH_SIZE reports (the guide's gfx950 correction says 2)
             res["fetch_unit_check"] = round(PROBE_BYTES[0] / (pf[0] * 1024.0), 3)
-        req, lvl = probe.get("TCC_EA0_RDREQ_sum") or [], probe.get("TCC_EA0_RDREQ_LEVEL_sum") or []
-        if len(req) == len(PROBE_BYTES) and len(lvl) == len(PROBE_BYTES) and "TCC_EA0_RDREQ_sum" in out and min(req) > 0:
-            lat_hbm, lat_cache = lvl[0] / req[0], lvl[3] / req[3]
-            lat_gemm = out["TCC_EA0_RDREQ_LEVEL_sum"] / out["TCC_EA0_RDREQ_sum"]
-            res["ea_read_latency_clk"] = {"hbm_stream_2GiB": round(lat_hbm, 1), "infinity_cache_stream_96MiB": round(lat_cache, 1),
-                                          "gemm": round(lat_gemm, 1)}
-            if lat_hbm > lat_cache:
-                f = min(1.0, max(0.0, (lat_hbm - lat_gemm) / (lat_hbm - lat_cache)))
-                res["infinity_cache_hit_fraction_est"] = round(f, 3)
-                res["hbm_read_bytes_est"] = (1.0 - f) * res["fetch_bytes"]
+        req, lvl = gemm.get("TCC_EA0_RDREQ_sum", []), gemm.get("TCC_EA0_RDREQ_LEVEL_sum", [])
+        if shapes and len(req) > n_cal and len(req) == len(lvl) and len(gemm["FETCH_SIZE"]) == len(req):
+            P = len(shapes)
+            by_pos, hbm = {}, 0.0
+            for pos in range(P):
+                cold = lvl[3 * pos + 1] / req[3 * pos + 1]
+                hot = lvl[3 * pos + 2] / req[3 * pos + 2]
+                idx = [i for i in range(n_cal, len(req)) if (i - n_cal) % P == pos]
+                lat = sum(lvl[i] for i in idx) / sum(req[i] for i in idx)
+                fbytes = 2.0 * 1024.0 * mean([gemm["FETCH_SIZE"][i] for i in idx])
+                f = min(1.0, max(0.0, (cold - lat) / (cold - hot))) if cold > hot else None
+                by_pos[GEMM_POSITIONS[pos]] = {"fabric_fetch": round(fbytes), "ea_read_latency_clk": {
+                    "operands_in_hbm": round(cold, 1), "operands_cache_resident": round(hot, 1), "in_step": round(lat, 1)},
+                    "infinity_cache_hit_fraction": None if f is None else round(f, 3)}
+                hbm += fbytes * (1.0 - (f if f is not None else 0.0))
+            res["by_position"] = by_pos
+            res["hbm_read_bytes_est"] = hbm / P
+            res["infinity_cache_hit_fraction_est"] = round(1.0 - res["hbm_read_bytes_est"] / fetch, 3) if fetch > 0 else None
         return res
     except Exception:
         return None
@@ -606,7 +656,8 @@ def main():
     from bayeformers_amd import _C
 
     if args.calibrate_traffic:
-        calibration_probes(device)
+        cal_shapes, cal_m, cal_dt = bert_gemm_shapes(args.workload)
+        calibration_probes(device, cal_shapes, S=args.samples or 10, M=cal_m or 4096, dtype=cal_dt or torch.bfloat16)
     defaults = {"bert_base": (10, "bf16"), "bert_base_train": (10, "bf16"), "bert_large_qa": (10, "fp16"), "linear768": (10, "bf16"), "linear768_m32": (10, "bf16"), "mlp": (5, "bf16")}
     S = args.samples or defaults[args.workload][0]
     dtype = args.dtype or defaults[args.workload][1]
@@ -773,9 +824,11 @@ def main():
                     # read latency of the launches between an HBM stream and an Infinity-Cache stream (measure_traffic)
                     detail.update({"hbm_read": round(tr["hbm_read_bytes_est"]),
                                    "infinity_cache_hit_fraction": tr["infinity_cache_hit_fraction_est"],
-                                   "ea_read_latency_clk": tr["ea_read_latency_clk"],
-                                   "hbm_read_method": "estimate: interpolation of TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ between "
-                                                      "calibration streams in the same pass; no memory-side counter is exposed"})
+                                   "by_position": tr["by_position"],
+                                   "hbm_read_method": "estimate: each launch's mean fabric read latency (TCC_EA0_RDREQ_LEVEL / "
+                                                      "TCC_EA0_RDREQ) placed between the same launch with its operands in HBM "
+                                                      "(after a 2 GiB flush) and repeated at once (cache-resident), same PMC "
+                                                      "pass; rocprofv3 exposes no memory-side counter on gfx950"})
                 if "fetch_unit_check" in tr:
                     detail["fetch_unit_check"] = tr["fetch_unit_check"]
                 roofline["traffic_detail"] = detail

@@ -192,18 +192,10 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
                   uint64_t seed, uint32_t sample_base, double* d_logprob_out, void* d_workspace,
                   size_t workspace_bytes, void* stream);
 
-/* The same operation as bf_linear_fwd in ONE launch for LARGE M, weight-stationary: a workgroup owns (sample, strip
- * of 64 output features, a share of the rows), draws the strip's 64 x K sampled weights once into LDS — they never
- * exist in HBM — accumulates the log-probs exactly once (row share 0), and streams its rows of x against the resident
- * strip (csrc/bf_fused_ws.hip).  Needs 16-bit x / y of the compute dtype, N % 64 == 0, K % 64 == 0, K <= 768.
- * row_shares: workgroups per (sample, strip) along M (each regenerates the strip); 0 = enough to fill the chip.
- * This is the measured alternative to sampling launch + 256-wide GEMM: it is NOT what
- * bnn.Linear dispatches to, because it is slower — four times the LDS-DMA bytes per flop of the 256 x 256 tile. */
-size_t bf_linear_fwd_ws_workspace_bytes(int S, int N);
-int bf_linear_fwd_ws(const void* d_x, int x_dtype, int64_t x_sample_stride, const bf_tensor_t* weight,
-                     const bf_tensor_t* bias, void* d_y, int y_dtype, int compute_dtype, int S, int M, int N, int K,
-                     uint64_t seed, uint32_t sample_base, int row_shares, double* d_logprob_out, void* d_workspace,
-                     size_t workspace_bytes, void* stream);
+/* (The weight-stationary single-launch variant for LARGE M, bf_linear_fwd_ws, is a DEVELOPER-build entry point since
+ * round 4 — csrc/bf_dev_api.h, library libbayeformers_amd_dev.so: measured 2.1-3.3x slower than sampling launch + tiled
+ * GEMM at M = 4096 and slower than both alternatives at every M from 32 to 2048 (profiles/r4b_mid_m_crossover.txt), it
+ * is dispatched nowhere, so the product library does not carry it.) */
 
 /* Backward of bf_linear_fwd, reproducing the reference's autograd graph: gradients flow through
  * F.linear(input, mu + eps*softplus(rho), ...) (layers/linear.py:97,104, gaussian.py:100-101) with eps a constant and
@@ -314,12 +306,15 @@ int bf_profile_enable(int on);
 int bf_profile_reset(void);
 int bf_profile_read(int kind, uint64_t* launches, double* total_ms, double* total_work);
 
-/* Rows per sample (M) up to which bf_linear_fwd runs as its single fused kernel (sampling + log-probs + MFMA in one
- * launch, no sampled weights in memory) instead of sampling launch + tiled GEMM.  The built-in default is the measured
- * crossover; the setter (0 .. 128, 0 = never) is a tuning knob for tools/crossover_bench.py.  Python's bnn.Linear asks
- * the getter, so that layers it keeps out of the cross-layer sampling plan are exactly those the kernel will take. */
+/* Rows per sample (M) up to which bf_linear_fwd runs an N x K layer as its single fused kernel (sampling + log-probs +
+ * MFMA in one launch, no sampled weights in memory) instead of sampling launch + tiled GEMM: bf_fused_small_rows_for(N, K)
+ * is the measured crossover (64 rows; 128 for layers of at most 512 x 512 weights), capped by bf_fused_small_max_rows(),
+ * which the setter (0 .. 128, 0 = never) moves — a tuning knob for tools/crossover_bench.py.  Python's bnn.Linear asks
+ * bf_fused_small_rows_for, so that the layers it keeps out of the cross-layer sampling plan are exactly those the
+ * kernel will take. */
 int bf_fused_small_max_rows(void);
 int bf_set_fused_small_max_rows(int rows);
+int bf_fused_small_rows_for(int N, int K);
 
 /* Measurement utility, not part of the path: one streaming pass of 16-byte loads over `bytes` (a multiple of 16) of device
  * memory (kernel bf_probe_read_kernel).  bench.py runs it inside its rocprofv3 --pmc child passes to calibrate the L2's

@@ -266,7 +266,9 @@ def test_full_size_layer_768(golden_dir, kind, M):
     S, N, K = int(g["S"]), 768, 768
     base = int(g[f"{kind}/base"])
     layer = linear768_layer(kind)
-    assert module_checksum(layer) == float(g[f"{kind}/checksum"])
+    # (the MOPED rho = log(exp(delta |w|) - 1) is rebuilt with THIS host's libm: an ulp here and there against the build
+    # container's, 2e-8 of the checksum — far inside every tolerance below)
+    assert module_checksum(layer) == pytest.approx(float(g[f"{kind}/checksum"]), rel=1e-6)
     layer = layer.cuda()
     layer.layer_id = 0
     if kind == "moped":  # a frozen mean under its MOPED prior: the kernel reads 8 instead of 16 bytes per scalar
