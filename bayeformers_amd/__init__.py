@@ -14,6 +14,7 @@ import torch.nn
 
 from . import nn  # noqa: F401  (bayeformers_amd.nn)
 from .nn import TORCH2BAYE
+from . import random as bfr
 from .nn.model import Model
 from .nn.parameters.base import Parameter
 from .nn.parameters.gaussian import DEFAULT_SCALED_GAUSSIAN_MIXTURE
@@ -97,13 +98,15 @@ def _dense_residual_norm_forward(self, hidden_states, input_tensor):
 
     hidden_states = self.dense(hidden_states)
     ln = self.LayerNorm
-    if self.training and self.dropout.p > 0:
-        hidden_states = self.dropout(hidden_states)
+    dropping = self.training and self.dropout.p > 0
     if not ops.layernorm_supported(hidden_states, input_tensor, ln):
-        return ln(hidden_states + input_tensor)
+        return ln((self.dropout(hidden_states) if dropping else hidden_states) + input_tensor)
+    # training mode (/root/reference/examples/bert_glue.py:221): the hidden dropout runs INSIDE the kernel, its Philox mask
+    # regenerated in the backward pass — no mask tensor, no extra pass over the dense output
+    drop = ops.Dropout(self.dropout.p, bfr.STATE.seed, bfr.dropout_call(), bfr.dropout_site(self)) if dropping else None
     if torch.is_grad_enabled() and (hidden_states.requires_grad or input_tensor.requires_grad or ln.weight.requires_grad):
-        return ops.AddLayerNormFn.apply(hidden_states, input_tensor, ln.weight, ln.bias, ln.eps)
-    return ops.add_layernorm(hidden_states, input_tensor, ln.weight, ln.bias, ln.eps)
+        return ops.AddLayerNormFn.apply(hidden_states, input_tensor, ln.weight, ln.bias, ln.eps, drop)
+    return ops.add_layernorm(hidden_states, input_tensor, ln.weight, ln.bias, ln.eps, drop)
 
 
 def _layernorm_forward(self, input):
@@ -149,8 +152,9 @@ def _embeddings_forward(self, input_ids=None, token_type_ids=None, position_ids=
     from . import ops
 
     w, t, p, ln = self.word_embeddings, self.token_type_embeddings, self.position_embeddings, self.LayerNorm
+    dropping = self.training and self.dropout.p > 0
     plain = (input_ids is not None and inputs_embeds is None and input_ids.dim() == 2 and input_ids.is_cuda
-             and input_ids.dtype == torch.long and not (self.training and self.dropout.p > 0)
+             and input_ids.dtype == torch.long
              and not (torch.is_grad_enabled() and (w.weight.requires_grad or t.weight.requires_grad or
                                                    p.weight.requires_grad or ln.weight.requires_grad))
              and w.weight.dtype == t.weight.dtype == p.weight.dtype and w.weight.dtype in ops._TORCH2BF
@@ -167,7 +171,7 @@ def _embeddings_forward(self, input_ids=None, token_type_ids=None, position_ids=
         # are then scattered from B*T rows instead of S*B*T, after one sum over the copies
         rep = getattr(input_ids, "_bf_repeat", None) if input_ids is not None else None
         orig = rep[1]() if rep is not None else None  # (samples, weak reference to the tensor the ids repeat)
-        if orig is not None and inputs_embeds is None and not (self.training and self.dropout.p > 0):
+        if orig is not None and inputs_embeds is None:
             S = rep[0]
             B = orig.shape[0]
 
@@ -185,15 +189,25 @@ def _embeddings_forward(self, input_ids=None, token_type_ids=None, position_ids=
             tt, ok1 = one_copy(token_type_ids)
             pp, ok2 = one_copy(position_ids)
             if ok1 and ok2 and orig.dim() == 2 and orig.shape[0] * S == input_ids.shape[0]:
-                e = self._bf_plain_forward(input_ids=orig, token_type_ids=tt, position_ids=pp, inputs_embeds=None,
-                                           past_key_values_length=past_key_values_length)
-                return e.repeat(S, *([1] * (e.dim() - 1)))
+                # training mode: the block up to its LayerNorm is still the same for every copy — only the dropout that
+                # ends it draws a mask per copy, so it moves behind the repeat
+                saved = self.dropout
+                if dropping:
+                    self.dropout = torch.nn.Identity()
+                try:
+                    e = self._bf_plain_forward(input_ids=orig, token_type_ids=tt, position_ids=pp, inputs_embeds=None,
+                                               past_key_values_length=past_key_values_length)
+                finally:
+                    self.dropout = saved
+                e = e.repeat(S, *([1] * (e.dim() - 1)))
+                return torch.nn.functional.dropout(e, saved.p, training=True) if dropping else e
         return self._bf_plain_forward(input_ids=input_ids, token_type_ids=token_type_ids, position_ids=position_ids,
                                       inputs_embeds=inputs_embeds, past_key_values_length=past_key_values_length)
     if position_ids is None and past_key_values_length:
         position_ids = self.position_ids[:, past_key_values_length:input_ids.shape[1] + past_key_values_length]
-    return ops.embed_layernorm(input_ids, token_type_ids, position_ids, w.weight, t.weight, p.weight, ln.weight, ln.bias,
-                               ln.eps)
+    e = ops.embed_layernorm(input_ids, token_type_ids, position_ids, w.weight, t.weight, p.weight, ln.weight, ln.bias,
+                            ln.eps)
+    return torch.nn.functional.dropout(e, self.dropout.p, training=True) if dropping else e
 
 
 def fuse_embeddings(model: torch.nn.Module) -> int:
@@ -251,8 +265,10 @@ def _attention_interface(module, query, key, value, attention_mask, dropout: flo
 
     from . import ops
 
-    usable = (dropout == 0.0 and not kwargs.get("is_causal", False) and ops.attention_supported(query, key, value))
     need_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
+    # attention_probs_dropout (training mode) runs inside the kernels; its backward exists for one-tile sequences (T = 128)
+    usable = (not kwargs.get("is_causal", False) and ops.attention_supported(query, key, value)
+              and (dropout == 0.0 or not need_grad or query.shape[2] == 128))
     key_mask = mask_off = None
     ready = getattr(attention_mask, "_bf_key_mask", None) if attention_mask is not None else None
     if usable and ready is not None and ready.shape == (query.shape[0], query.shape[2]):
@@ -275,9 +291,10 @@ def _attention_interface(module, query, key, value, attention_mask, dropout: flo
             attention_mask = attention_mask.to(query.dtype)  # the framework's kernels want bool or the query's dtype
         return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
     scale = scaling if scaling is not None else query.shape[-1] ** -0.5
+    drop = ops.Dropout(dropout, bfr.STATE.seed, bfr.dropout_call(), bfr.dropout_site(module)) if dropout > 0.0 else None
     if need_grad:  # training: the same kernel, with bf_attention_bwd behind it
-        return ops.AttentionFn.apply(query, key, value, key_mask, mask_off, scale), None
-    return ops.attention_forward(query, key, value, key_mask, scale, mask_off), None
+        return ops.AttentionFn.apply(query, key, value, key_mask, mask_off, scale, drop), None
+    return ops.attention_forward(query, key, value, key_mask, scale, mask_off, drop=drop), None
 
 
 def _padding_mask_interface(batch_size, q_length=None, kv_length=None, q_offset=0, kv_offset=0, mask_function=None,

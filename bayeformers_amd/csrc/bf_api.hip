@@ -430,6 +430,71 @@ int bf_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const fl
                                    dtype, B, T, H, head_dim, token_stride, scaling, (hipStream_t)stream);
 }
 
+static bf_dropout_t make_dropout(float p_drop, uint64_t seed, uint32_t call, uint32_t site) {
+    bf_dropout_t d;
+    d.k0 = (uint32_t)seed;
+    d.k1 = (uint32_t)(seed >> 32);
+    d.call = call;
+    d.site = site;
+    d.thresh = bf_dropout_thresh(p_drop);
+    d.inv_keep = 1.0f / (1.0f - (float)d.thresh / 65536.0f);
+    return d;
+}
+
+int bf_dropout_keep_host(uint8_t* out, uint64_t first_group, uint64_t n_groups, float p_drop, uint64_t seed, uint32_t call,
+                         uint32_t site) {
+    if (!out && n_groups) BF_FAIL("bf_dropout_keep_host: out is NULL");
+    if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_dropout_keep_host: p must be in [0, 1) (got %g)", p_drop);
+    const uint32_t thresh = bf_dropout_thresh(p_drop);
+    for (uint64_t i = 0; i < n_groups; ++i) {
+        const uint64_t g = first_group + i;
+        const uint32_t keep = bf_dropout_keep8((uint32_t)g, (uint32_t)(g >> 32), call, site, (uint32_t)seed, (uint32_t)(seed >> 32), thresh);
+        for (int j = 0; j < 8; ++j) out[8 * i + j] = (uint8_t)((keep >> j) & 1u);
+    }
+    return 0;
+}
+
+int bf_attention_fwd_dropout(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
+                             void* d_out, float* d_lse, int dtype, int B, int T, int H, int head_dim, int64_t token_stride,
+                             float scaling, float p_drop, uint64_t seed, uint32_t call, uint32_t site, uint32_t* d_keep_bits,
+                             void* stream) {
+    if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_attention_fwd_dropout: p must be in [0, 1) (got %g)", p_drop);
+    const bf_dropout_t d = make_dropout(p_drop, seed, call, site);
+    return bf_launch_attention_fwd(d_q, d_k, d_v, d_mask, d_mask_off, d_out, d_lse, dtype, B, T, H, head_dim, token_stride,
+                                   scaling, (hipStream_t)stream, &d, d_keep_bits);
+}
+
+int bf_attention_bwd_dropout(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
+                             const void* d_out, const void* d_dout, const float* d_lse, float* d_delta, void* d_dq, void* d_dk,
+                             void* d_dv, int dtype, int B, int T, int H, int head_dim, int64_t token_stride, float scaling,
+                             float p_drop, const uint32_t* d_keep_bits, void* stream) {
+    if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_attention_bwd_dropout: p must be in [0, 1) (got %g)", p_drop);
+    const bf_dropout_t d = make_dropout(p_drop, 0, 0, 0);
+    if (d.thresh && !d_keep_bits) BF_FAIL("bf_attention_bwd_dropout: the forward's keep bits are needed");
+    return bf_launch_attention_bwd(d_q, d_k, d_v, d_mask, d_mask_off, d_out, d_dout, d_lse, d_delta, d_dq, d_dk, d_dv, dtype,
+                                   B, T, H, head_dim, token_stride, scaling, (hipStream_t)stream,
+                                   d.thresh ? d_keep_bits : nullptr, d.inv_keep);
+}
+
+int bf_add_layernorm_dropout(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, int param_dtype,
+                             void* d_out, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed, uint32_t call,
+                             uint32_t site, void* stream) {
+    if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_add_layernorm_dropout: p must be in [0, 1) (got %g)", p_drop);
+    const bf_dropout_t d = make_dropout(p_drop, seed, call, site);
+    return bf_launch_add_layernorm(d_x, d_residual, d_gamma, d_beta, param_dtype, d_out, dtype, rows, N, eps,
+                                   (hipStream_t)stream, &d);
+}
+
+int bf_add_layernorm_dropout_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
+                                 const void* d_dy, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
+                                 size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
+                                 uint32_t call, uint32_t site, void* stream) {
+    if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_add_layernorm_dropout_bwd: p must be in [0, 1) (got %g)", p_drop);
+    const bf_dropout_t d = make_dropout(p_drop, seed, call, site);
+    return bf_launch_add_layernorm_bwd(d_x, d_residual, d_gamma, param_dtype, d_dy, d_dz, d_dgamma, d_dbeta, d_workspace,
+                                       workspace_bytes, dtype, rows, N, eps, (hipStream_t)stream, &d, d_dx);
+}
+
 size_t bf_add_layernorm_bwd_workspace_bytes(int64_t rows, int N) { return bf_add_layernorm_bwd_ws_bytes(rows, N); }
 
 int bf_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "bf_common.h"
+#include "bf_philox.h"
 
 namespace {
 
@@ -64,9 +65,18 @@ struct AttnParams {
     int B, T, H;
     float scale_log2e;  // scaling * log2(e)
     int ablate;         // developer ablation bits (BF_ATTN_ABLATE): 1 = no output stores, 2 = K/V staged once from tile 0
+    // DROP instantiation (training, HF attention_probs_dropout): the probabilities are dropped AFTER the softmax
+    // normalisation (the row sums keep every term) with the Philox keep-mask of bf_philox.h.  A dropout group is the 8
+    // probabilities of one P^T fragment: query q, keys tile * 128 + (2c + e) * 16 + 4 lg + j (e = 0, 1; j = 0..3) ->
+    //   group index g = (((b * H + h) * T + q) * (T / 32) + tile * 4 + c) * 4 + lg,   field = e * 4 + j.
+    // keep_bits (nullable): the decisions as one 32-bit word per (b, h, q, tile, lg), bit c * 8 + e * 4 + j — 1 bit per
+    // probability, 3 % of the layer's q/k/v/o traffic — for the backward kernel, whose lanes own 4 QUERIES of one key and
+    // would have to evaluate eight Philox blocks per group of eight to regenerate them.
+    bf_dropout_t drop;
+    uint32_t* keep_bits;  // [B][H][T][T / 32]
 };
 
-template <typename T>
+template <typename T, bool DROP = false>
 __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams p) {
     using frag = typename Mfma<T>::frag;
     using half4 = typename Mfma<T>::half4;
@@ -163,6 +173,25 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams 
             sum += __shfl_xor(sum, 32);
             run_sum[qi] = run_sum[qi] * corr + sum;
             run_max[qi] = new_max;
+            if constexpr (DROP) {
+                // drop probabilities (the sum above saw all of them); the 1 / (1 - p) factor joins the final normalisation
+                const unsigned long long qrow = ((unsigned long long)b * p.H + h) * p.T + (q0 + qi * 16 + li);
+                const unsigned long long g0 = (qrow * (unsigned)(p.T >> 5) + (unsigned)(key0 >> 7) * 4u) * 4u + lg;
+                uint32_t word = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned long long g = g0 + 4ull * c;
+                    const uint32_t keep = bf_dropout_keep8((uint32_t)g, (uint32_t)(g >> 32), p.drop.call, p.drop.site,
+                                                           p.drop.k0, p.drop.k1, p.drop.thresh);
+                    word |= keep << (8 * c);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (!((keep >> (e * 4 + j)) & 1u)) s[2 * c + e][j] = 0.f;
+                }
+                if (p.keep_bits) p.keep_bits[(qrow * (unsigned)(p.T >> 7) + (unsigned)(key0 >> 7)) * 4u + lg] = word;
+            }
 #pragma unroll
             for (int db = 0; db < 4; ++db) o[qi][db] *= corr;
             // O^T[d][query] += V^T[d][k] P^T[k][query], k walking 32 keys at a time in the order
@@ -193,7 +222,7 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams 
 #endif
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
-        const float inv = run_sum[qi] > 0.f ? 1.0f / run_sum[qi] : 0.f;
+        const float inv = run_sum[qi] > 0.f ? (DROP ? p.drop.inv_keep : 1.0f) / run_sum[qi] : 0.f;
         // a fully masked query has no probabilities: +inf makes exp2(score - lse) = 0 in the backward kernels
         if (p.lse && lg == 0)
             p.lse[((long long)b * p.H + h) * p.T + q0 + qi * 16 + li] =
@@ -211,7 +240,8 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams 
 
 int bf_launch_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask,
                             const unsigned char* d_mask_off, void* d_out, float* d_lse, int dtype, int B, int T, int H,
-                            int head_dim, long long token_stride, float scaling, hipStream_t stream) {
+                            int head_dim, long long token_stride, float scaling, hipStream_t stream,
+                            const bf_dropout_t* drop, uint32_t* d_keep_bits) {
     if (!d_q || !d_k || !d_v || !d_out) BF_FAIL("bf_attention_fwd: NULL argument");
     if (dtype != BF_DT_BF16 && dtype != BF_DT_F16) BF_FAIL("bf_attention_fwd: dtype must be bf16 or fp16");
     if (head_dim != HD) BF_FAIL("bf_attention_fwd: head size %d (only %d)", head_dim, HD);
@@ -241,6 +271,17 @@ int bf_launch_attention_fwd(const void* d_q, const void* d_k, const void* d_v, c
     p.ablate = 0;
 #endif
     const dim3 grid(T / TQ, H, B);
+    p.keep_bits = nullptr;
+    p.drop = bf_dropout_t{0, 0, 0, 0, 0, 1.0f};
+    if (drop && drop->thresh) {
+        if (d_keep_bits && ((uintptr_t)d_keep_bits & 3)) BF_FAIL("bf_attention_fwd: keep bits must be 4-byte aligned");
+        p.drop = *drop;
+        p.keep_bits = d_keep_bits;
+        if (dtype == BF_DT_BF16) hipLaunchKernelGGL((attention_fwd_kernel<__bf16, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((attention_fwd_kernel<_Float16, true>), grid, dim3(256), 0, stream, p);
+        BF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (dtype == BF_DT_BF16) hipLaunchKernelGGL(attention_fwd_kernel<__bf16>, grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(attention_fwd_kernel<_Float16>, grid, dim3(256), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());

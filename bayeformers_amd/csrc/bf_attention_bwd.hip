@@ -66,6 +66,11 @@ struct BwdParams {
     long long tok_stride;           // elements between consecutive tokens of q / k / v
     int B, T, H;
     float scale, scale_log2e;
+    // attention_probs_dropout (the forward's DROP instantiation): the keep decisions the forward stored, one bit per
+    // probability — word (b, h, q, tile, lg), bit c * 8 + e * 4 + j <-> key tile * 128 + (2c + e) * 16 + 4 lg + j — and the
+    // 1 / (1 - p) factor.  NULL: no dropout.  With P~ = P o keep / (1 - p):  dV = P~^T dO,  dS = P o (keep / (1 - p) o dP~ - delta).
+    const uint32_t* keep_bits;
+    float inv_keep;
 };
 
 // stage a [128][64] tile (rows `row0`.. of a [tokens][stride] tensor) into the swizzled and / or the padded image
@@ -310,17 +315,18 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
 // atomics, a fixed summation order.  HBM: 5 reads (Q, K, V, O, dO) + 3 writes, against 9 + 3 of the two-kernel path.
 constexpr int DS_ROW = TT * 2 + 32;  // 288 B: a row of dS^T (128 queries) + the transpose read's padding
 
-template <typename T>
+template <typename T, bool DROP = false>
 __global__ __launch_bounds__(512, 4) void attention_bwd_tile_kernel(const BwdParams p) {
     using frag = typename Mfma<T>::frag;
     using half4 = typename Mfma<T>::half4;
-    __shared__ __attribute__((aligned(16))) char smem[2 * S_BYTES + 2 * P_BYTES + 2 * TT * 4];
+    __shared__ __attribute__((aligned(16))) char smem[2 * S_BYTES + 2 * P_BYTES + 2 * TT * 4 + (DROP ? TT * 16 : 0)];
     char* const qs = smem;                               // Q, swizzled: row operand of S
     char* const dos = smem + S_BYTES;                    // dO, swizzled: row operand of dP
     char* const qp = smem + 2 * S_BYTES;                 // Q, padded: Q^T through the transpose read
     char* const dop = smem + 2 * S_BYTES + P_BYTES;      // dO, padded: dO^T through the transpose read
     float* const lse_s = reinterpret_cast<float*>(smem + 2 * S_BYTES + 2 * P_BYTES);
     float* const del_s = lse_s + TT;
+    uint32_t* const keep_s = reinterpret_cast<uint32_t*>(del_s + TT);  // DROP: [128 queries][4 lg] keep words of this (b, h)
     char* const kp = smem;                               // K, padded, over qs | dos once S and dP are done (K is still in registers)
     char* const dst = smem + 2 * S_BYTES;                // dS^T [128 keys][DS_ROW] over qp | dop once dK and dV are done
     static_assert(P_BYTES <= 2 * S_BYTES && TT * DS_ROW <= 2 * P_BYTES, "the K and dS^T images alias dead tiles only");
@@ -352,6 +358,7 @@ __global__ __launch_bounds__(512, 4) void attention_bwd_tile_kernel(const BwdPar
     stage_tile<T, 512>(dob, ostride, 0, dos, dop, tid);
     if (tid < TT / 4)
         *reinterpret_cast<f32x4_t*>(lse_s + tid * 4) = *reinterpret_cast<const f32x4_t*>(lse_g + tid * 4);
+    if constexpr (DROP) keep_s[tid] = p.keep_bits[(((long long)b * p.H + h) * p.T) * 4 + tid];  // 512 words = 128 x 4
     __syncthreads();
     {   // delta of query `row` = <dO, O>: the dO row comes out of the staged tile (a row fragment of block wid is the
         // lane's 8 features of that row); it is first read behind the barrier that follows the S / dP products
@@ -387,6 +394,9 @@ __global__ __launch_bounds__(512, 4) void attention_bwd_tile_kernel(const BwdPar
     // P and dS leave the fp32 accumulators as 16-bit column operands right away (half the registers through the dV /
     // dK products: no spills at 128 VGPRs); pf[c] / dsf[c] = query blocks 2c, 2c + 1
     frag pf[4], dsf[4];
+    // DROP: this lane's key sits in word (query, lg_f) at one fixed bit
+    const int key_i = (int)row;
+    const int keep_word = (key_i >> 2) & 3, keep_bit = ((key_i >> 5) << 3) | (((key_i >> 4) & 1) << 2) | (key_i & 3);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -397,8 +407,15 @@ __global__ __launch_bounds__(512, 4) void attention_bwd_tile_kernel(const BwdPar
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float pr = __builtin_amdgcn_exp2f(fmaf(s[qbk][j], p.scale_log2e, mk) - l4[j]);
-                s[qbk][j] = pr;                          // P
-                dp[qbk][j] = pr * (dp[qbk][j] - d4[j]);  // dS
+                if constexpr (DROP) {
+                    const uint32_t wrd = keep_s[(qbk * 16 + lg * 4 + j) * 4 + keep_word];
+                    const float m = ((wrd >> keep_bit) & 1u) ? p.inv_keep : 0.f;
+                    s[qbk][j] = pr * m;                          // P~ = P o keep / (1 - p)
+                    dp[qbk][j] = pr * (dp[qbk][j] * m - d4[j]);  // dS
+                } else {
+                    s[qbk][j] = pr;                          // P
+                    dp[qbk][j] = pr * (dp[qbk][j] - d4[j]);  // dS
+                }
             }
         }
         pf[c] = pack2<T>(s[2 * c], s[2 * c + 1]);
@@ -452,7 +469,8 @@ __global__ __launch_bounds__(512, 4) void attention_bwd_tile_kernel(const BwdPar
 int bf_launch_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask,
                             const unsigned char* d_mask_off, const void* d_out, const void* d_dout, const float* d_lse,
                             float* d_delta, void* d_dq, void* d_dk, void* d_dv, int dtype, int B, int T, int H,
-                            int head_dim, long long token_stride, float scaling, hipStream_t stream) {
+                            int head_dim, long long token_stride, float scaling, hipStream_t stream,
+                            const uint32_t* d_keep_bits, float inv_keep) {
     if (!d_q || !d_k || !d_v || !d_out || !d_dout || !d_lse || !d_delta || !d_dq || !d_dk || !d_dv)
         BF_FAIL("bf_attention_bwd: NULL argument");
     if (dtype != BF_DT_BF16 && dtype != BF_DT_F16) BF_FAIL("bf_attention_bwd: dtype must be bf16 or fp16");
@@ -483,7 +501,17 @@ int bf_launch_attention_bwd(const void* d_q, const void* d_k, const void* d_v, c
     p.H = H;
     p.scale = scaling;
     p.scale_log2e = scaling * 1.4426950408889634f;
+    p.keep_bits = d_keep_bits;
+    p.inv_keep = inv_keep;
     const dim3 grid(T / TT, H, B);
+    if (d_keep_bits) {
+        if (T != TT) BF_FAIL("bf_attention_bwd: dropout is supported for one-tile sequences only (T = %d, got %d)", TT, T);
+        if ((uintptr_t)d_keep_bits & 3) BF_FAIL("bf_attention_bwd: keep bits must be 4-byte aligned");
+        if (dtype == BF_DT_BF16) hipLaunchKernelGGL((attention_bwd_tile_kernel<__bf16, true>), grid, dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((attention_bwd_tile_kernel<_Float16, true>), grid, dim3(512), 0, stream, p);
+        BF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (T == TT) {  // one tile: dQ, dK, dV in one launch
         if (dtype == BF_DT_BF16) hipLaunchKernelGGL(attention_bwd_tile_kernel<__bf16>, grid, dim3(512), 0, stream, p);
         else hipLaunchKernelGGL(attention_bwd_tile_kernel<_Float16>, grid, dim3(512), 0, stream, p);

@@ -167,9 +167,10 @@ int bf_launch_embedding_fwd(const long long* d_ids, const float* d_mu, const flo
 int bf_launch_embedding_bwd(const long long* d_ids, const void* d_grad, int grad_dtype, const float* d_rho, float* d_dmu,
                             float* d_drho, long long n_tokens, long long tokens_per_sample, long long V, int D,
                             uint64_t seed, uint32_t sample_base, uint32_t stream_id, hipStream_t stream);
+struct bf_dropout_t;  // bf_philox.h
 int bf_launch_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta,
                             int param_dtype, void* d_out, int dtype, long long rows, int N, float eps,
-                            hipStream_t stream);
+                            hipStream_t stream, const bf_dropout_t* drop = nullptr);
 int bf_launch_embed_layernorm(const long long* d_ids, const long long* d_type_ids, const long long* d_pos_ids,
                               const void* d_word, const void* d_type, const void* d_pos, const void* d_gamma,
                               const void* d_beta, int param_dtype, void* d_out, int dtype, long long rows, int N,
@@ -177,12 +178,15 @@ int bf_launch_embed_layernorm(const long long* d_ids, const long long* d_type_id
                               long long pos_table_rows, float eps, hipStream_t stream);
 int bf_launch_attention_fwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask,
                             const unsigned char* d_mask_off, void* d_out, float* d_lse, int dtype, int B, int T, int H,
-                            int head_dim, long long token_stride, float scaling, hipStream_t stream);
+                            int head_dim, long long token_stride, float scaling, hipStream_t stream,
+                            const bf_dropout_t* drop = nullptr, uint32_t* d_keep_bits = nullptr);
 int bf_launch_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const float* d_mask,
                             const unsigned char* d_mask_off, const void* d_out, const void* d_dout, const float* d_lse,
                             float* d_delta, void* d_dq, void* d_dk, void* d_dv, int dtype, int B, int T, int H,
-                            int head_dim, long long token_stride, float scaling, hipStream_t stream);
+                            int head_dim, long long token_stride, float scaling, hipStream_t stream,
+                            const uint32_t* d_keep_bits = nullptr, float inv_keep = 1.0f);
 size_t bf_add_layernorm_bwd_ws_bytes(long long rows, int N);
 int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
                                 const void* d_dy, void* d_dz, float* d_dgamma, float* d_dbeta, void* d_workspace,
-                                size_t workspace_bytes, int dtype, long long rows, int N, float eps, hipStream_t stream);
+                                size_t workspace_bytes, int dtype, long long rows, int N, float eps, hipStream_t stream,
+                                const bf_dropout_t* drop = nullptr, void* d_dx = nullptr);

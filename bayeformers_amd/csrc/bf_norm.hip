@@ -8,6 +8,7 @@
 // reductions on the DPP network.  Algorithmic bytes per row: N * (2 reads + 1 write) * sizeof(T).
 #include "bf_common.h"
 #include "bf_device.h"
+#include "bf_philox.h"
 
 namespace {
 
@@ -59,11 +60,20 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
 
 constexpr int kRowsPerBlock = 4;  // one wave per row
 
+// hidden dropout of the dense output (HF BertSelfOutput / BertOutput: LayerNorm(dropout(dense(h)) + input), training mode):
+// the 8-element vector `vec` (= 8 consecutive features) of row `row` is dropout group row * (N / 8) + vec of bf_philox.h
+__device__ __forceinline__ void drop8(const bf_dropout_t& d, long long row, int nvec, int vec, float (&v)[8]) {
+    const unsigned long long g = (unsigned long long)row * (unsigned)nvec + (unsigned)vec;
+    const uint32_t keep = bf_dropout_keep8((uint32_t)g, (uint32_t)(g >> 32), d.call, d.site, d.k0, d.k1, d.thresh);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = ((keep >> i) & 1u) ? v[i] * d.inv_keep : 0.f;
+}
+
 // VPL = 8-element vectors per lane: a row has N/8 <= 64*VPL of them
-template <typename T, typename GT, int VPL>
+template <typename T, typename GT, int VPL, bool DROP = false>
 __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_kernel(
     const T* __restrict__ x, const T* __restrict__ res, const GT* __restrict__ gamma, const GT* __restrict__ beta,
-    T* __restrict__ out, long long rows, int N, float eps) {
+    T* __restrict__ out, long long rows, int N, float eps, const bf_dropout_t drop) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -77,6 +87,7 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_kernel(
         const int vi = lane + 64 * c;
         if (vi < nvec) {
             load8(xr + vi * 8, v[c]);
+            if constexpr (DROP) drop8(drop, row, nvec, vi, v[c]);
             if (rr) {
                 float r[8];
                 load8(rr + vi * 8, r);
@@ -119,10 +130,10 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_kernel(
 // Rows of 32 V vectors (N = 256 V: 768, 1024): HALF a wave per row, V vectors per lane, so every lane of every load,
 // store and arithmetic instruction is busy (one wave per row leaves a quarter of the lanes of N = 768 idle), two rows
 // per wave.
-template <typename T, typename GT, int V>
+template <typename T, typename GT, int V, bool DROP = false>
 __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_half_kernel(
     const T* __restrict__ x, const T* __restrict__ res, const GT* __restrict__ gamma, const GT* __restrict__ beta,
-    T* __restrict__ out, long long rows, int N, float eps) {
+    T* __restrict__ out, long long rows, int N, float eps, const bf_dropout_t drop) {
     const int lane = threadIdx.x & 63, hl = lane & 31;
     const long long row_raw = ((long long)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6)) * 2 + (lane >> 5);
     if (row_raw - (lane >> 5) >= rows) return;           // the whole wave is past the end
@@ -136,6 +147,7 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_half_kernel(
     for (int c = 0; c < V; ++c) {
         const int vi = hl + 32 * c;
         load8(xr + vi * 8, v[c]);
+        if constexpr (DROP) drop8(drop, row, N >> 3, vi, v[c]);
         if (rr) {
             float r[8];
             load8(rr + vi * 8, r);
@@ -177,10 +189,13 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_half_kernel(
 // One wave per row, a workgroup walks rows blockIdx, blockIdx + gridDim, ...; every lane keeps the dgamma / dbeta
 // partial sums of its own columns in registers, the 4 waves of a workgroup are combined through LDS and leave one
 // [2][N] fp32 row per workgroup, reduced in a fixed order by layernorm_param_grad_kernel (deterministic).
-template <typename T, typename GT, int VPL>
+// DROP: z = dropout(x) + residual with the forward's keep-mask regenerated (bf_philox.h); dz is the gradient of the
+// residual, and dx = dz o keep / (1 - p) goes to its own tensor.
+template <typename T, typename GT, int VPL, bool DROP = false>
 __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_bwd_kernel(
     const T* __restrict__ x, const T* __restrict__ res, const GT* __restrict__ gamma, const T* __restrict__ dy,
-    T* __restrict__ dz, float* __restrict__ partial, long long rows, int N, float eps) {
+    T* __restrict__ dz, float* __restrict__ partial, long long rows, int N, float eps, const bf_dropout_t drop,
+    T* __restrict__ dx) {
     extern __shared__ float sh[];  // [kRowsPerBlock][2][N]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = N >> 3;
@@ -201,6 +216,7 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_bwd_kernel(
             const int vi = lane + 64 * c;
             if (vi < nvec) {
                 load8(x + row * N + vi * 8, v[c]);
+                if constexpr (DROP) drop8(drop, row, nvec, vi, v[c]);
                 if (res) {
                     float r[8];
                     load8(res + row * N + vi * 8, r);
@@ -246,6 +262,10 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_bwd_kernel(
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = rstd * (g[c][i] - s1 - v[c][i] * s2);
                 store8(dz + row * N + vi * 8, o);
+                if constexpr (DROP) {
+                    drop8(drop, row, nvec, vi, o);  // the same groups, the same decisions: dx = dz o keep / (1 - p)
+                    store8(dx + row * N + vi * 8, o);
+                }
             }
         }
     }
@@ -296,13 +316,20 @@ constexpr int kBwdBlocks = BF_LN_BWD_BLOCKS;  // workgroups (each leaves one [2]
 
 template <typename T, typename GT>
 int launch_bwd_vpl(const void* x, const void* res, const void* gamma, const void* dy, void* dz, float* partial,
-                   int nblocks, long long rows, int N, float eps, hipStream_t stream) {
+                   int nblocks, long long rows, int N, float eps, hipStream_t stream, const bf_dropout_t* drop, void* dx) {
     const int nvec = N >> 3;
     const size_t lds = (size_t)kRowsPerBlock * 2 * N * sizeof(float);
     const dim3 grid((unsigned)nblocks), block(64 * kRowsPerBlock);
-#define BF_LNB_LAUNCH(VPL)                                                                                            \
-    hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, GT, VPL>), grid, block, lds, stream, (const T*)x, (const T*)res,   \
-                       (const GT*)gamma, (const T*)dy, (T*)dz, partial, rows, N, eps)
+    const bf_dropout_t d = drop ? *drop : bf_dropout_t{0, 0, 0, 0, 0, 1.0f};
+#define BF_LNB_LAUNCH(VPL)                                                                                                  \
+    do {                                                                                                                    \
+        if (d.thresh)                                                                                                       \
+            hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, GT, VPL, true>), grid, block, lds, stream, (const T*)x,         \
+                               (const T*)res, (const GT*)gamma, (const T*)dy, (T*)dz, partial, rows, N, eps, d, (T*)dx);    \
+        else                                                                                                                \
+            hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, GT, VPL, false>), grid, block, lds, stream, (const T*)x,        \
+                               (const T*)res, (const GT*)gamma, (const T*)dy, (T*)dz, partial, rows, N, eps, d, (T*)dx);    \
+    } while (0)
     if (nvec <= 64) BF_LNB_LAUNCH(1);
     else if (nvec <= 128) BF_LNB_LAUNCH(2);
     else if (nvec <= 256) BF_LNB_LAUNCH(4);
@@ -314,13 +341,20 @@ int launch_bwd_vpl(const void* x, const void* res, const void* gamma, const void
 
 template <typename T, typename GT>
 int launch_vpl(const void* x, const void* res, const void* gamma, const void* beta, void* out, long long rows, int N,
-               float eps, hipStream_t stream) {
+               float eps, hipStream_t stream, const bf_dropout_t* drop) {
     const int nvec = N >> 3;
+    const bf_dropout_t d = drop ? *drop : bf_dropout_t{0, 0, 0, 0, 0, 1.0f};
     if (nvec % 32 == 0 && nvec <= 128) {  // N = 256, 512, 768, 1024: half a wave per row
         const dim3 hgrid((unsigned)((rows + 2 * kRowsPerBlock - 1) / (2 * kRowsPerBlock))), hblock(64 * kRowsPerBlock);
-#define BF_LNH_LAUNCH(V)                                                                                          \
-    hipLaunchKernelGGL((add_layernorm_half_kernel<T, GT, V>), hgrid, hblock, 0, stream, (const T*)x, (const T*)res, \
-                       (const GT*)gamma, (const GT*)beta, (T*)out, rows, N, eps)
+#define BF_LNH_LAUNCH(V)                                                                                                \
+    do {                                                                                                                \
+        if (d.thresh)                                                                                                   \
+            hipLaunchKernelGGL((add_layernorm_half_kernel<T, GT, V, true>), hgrid, hblock, 0, stream, (const T*)x,      \
+                               (const T*)res, (const GT*)gamma, (const GT*)beta, (T*)out, rows, N, eps, d);             \
+        else                                                                                                            \
+            hipLaunchKernelGGL((add_layernorm_half_kernel<T, GT, V, false>), hgrid, hblock, 0, stream, (const T*)x,     \
+                               (const T*)res, (const GT*)gamma, (const GT*)beta, (T*)out, rows, N, eps, d);             \
+    } while (0)
         switch (nvec / 32) {
             case 1: BF_LNH_LAUNCH(1); break;
             case 2: BF_LNH_LAUNCH(2); break;
@@ -332,9 +366,15 @@ int launch_vpl(const void* x, const void* res, const void* gamma, const void* be
         return 0;
     }
     const dim3 grid((unsigned)((rows + kRowsPerBlock - 1) / kRowsPerBlock)), block(64 * kRowsPerBlock);
-#define BF_LN_LAUNCH(VPL)                                                                                        \
-    hipLaunchKernelGGL((add_layernorm_kernel<T, GT, VPL>), grid, block, 0, stream, (const T*)x, (const T*)res,    \
-                       (const GT*)gamma, (const GT*)beta, (T*)out, rows, N, eps)
+#define BF_LN_LAUNCH(VPL)                                                                                              \
+    do {                                                                                                               \
+        if (d.thresh)                                                                                                  \
+            hipLaunchKernelGGL((add_layernorm_kernel<T, GT, VPL, true>), grid, block, 0, stream, (const T*)x,          \
+                               (const T*)res, (const GT*)gamma, (const GT*)beta, (T*)out, rows, N, eps, d);            \
+        else                                                                                                           \
+            hipLaunchKernelGGL((add_layernorm_kernel<T, GT, VPL, false>), grid, block, 0, stream, (const T*)x,         \
+                               (const T*)res, (const GT*)gamma, (const GT*)beta, (T*)out, rows, N, eps, d);            \
+    } while (0)
     if (nvec <= 64) BF_LN_LAUNCH(1);
     else if (nvec <= 128) BF_LN_LAUNCH(2);
     else if (nvec <= 256) BF_LN_LAUNCH(4);
@@ -347,9 +387,9 @@ int launch_vpl(const void* x, const void* res, const void* gamma, const void* be
 
 template <typename T>
 int launch_gt(const void* x, const void* res, const void* gamma, const void* beta, int param_dtype, int dtype,
-              void* out, long long rows, int N, float eps, hipStream_t stream) {
-    if (param_dtype == BF_DT_F32) return launch_vpl<T, float>(x, res, gamma, beta, out, rows, N, eps, stream);
-    if (param_dtype == dtype) return launch_vpl<T, T>(x, res, gamma, beta, out, rows, N, eps, stream);
+              void* out, long long rows, int N, float eps, hipStream_t stream, const bf_dropout_t* drop) {
+    if (param_dtype == BF_DT_F32) return launch_vpl<T, float>(x, res, gamma, beta, out, rows, N, eps, stream, drop);
+    if (param_dtype == dtype) return launch_vpl<T, T>(x, res, gamma, beta, out, rows, N, eps, stream, drop);
     BF_FAIL("bf_add_layernorm: gamma/beta must be fp32 or have the activation dtype");
 }
 
@@ -448,7 +488,7 @@ int launch_embed(const long long* ids, const long long* type_ids, const long lon
 
 int bf_launch_add_layernorm(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta,
                             int param_dtype, void* d_out, int dtype, long long rows, int N, float eps,
-                            hipStream_t stream) {
+                            hipStream_t stream, const bf_dropout_t* drop) {
     if (rows < 0 || N <= 0) BF_FAIL("bf_add_layernorm: bad shape rows=%lld N=%d", rows, N);
     if (rows == 0) return 0;
     if (!d_x || !d_gamma || !d_beta || !d_out) BF_FAIL("bf_add_layernorm: null pointer");
@@ -457,9 +497,9 @@ int bf_launch_add_layernorm(const void* d_x, const void* d_residual, const void*
     const uintptr_t al = (uintptr_t)d_x | (uintptr_t)d_residual | (uintptr_t)d_gamma | (uintptr_t)d_beta | (uintptr_t)d_out;
     if (al & 15) BF_FAIL("bf_add_layernorm: pointers must be 16-byte aligned");
     switch (dtype) {
-        case BF_DT_BF16: return launch_gt<__bf16>(d_x, d_residual, d_gamma, d_beta, param_dtype, dtype, d_out, rows, N, eps, stream);
-        case BF_DT_F16: return launch_gt<_Float16>(d_x, d_residual, d_gamma, d_beta, param_dtype, dtype, d_out, rows, N, eps, stream);
-        case BF_DT_F32: return launch_gt<float>(d_x, d_residual, d_gamma, d_beta, param_dtype, dtype, d_out, rows, N, eps, stream);
+        case BF_DT_BF16: return launch_gt<__bf16>(d_x, d_residual, d_gamma, d_beta, param_dtype, dtype, d_out, rows, N, eps, stream, drop);
+        case BF_DT_F16: return launch_gt<_Float16>(d_x, d_residual, d_gamma, d_beta, param_dtype, dtype, d_out, rows, N, eps, stream, drop);
+        case BF_DT_F32: return launch_gt<float>(d_x, d_residual, d_gamma, d_beta, param_dtype, dtype, d_out, rows, N, eps, stream, drop);
     }
     BF_FAIL("bf_add_layernorm: unknown dtype %d", dtype);
 }
@@ -510,7 +550,10 @@ size_t bf_add_layernorm_bwd_ws_bytes(long long rows, int N) {
 
 int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
                                 const void* d_dy, void* d_dz, float* d_dgamma, float* d_dbeta, void* d_workspace,
-                                size_t workspace_bytes, int dtype, long long rows, int N, float eps, hipStream_t stream) {
+                                size_t workspace_bytes, int dtype, long long rows, int N, float eps, hipStream_t stream,
+                                const bf_dropout_t* drop, void* d_dx) {
+    if (drop && drop->thresh && (!d_dx || ((uintptr_t)d_dx & 15)))
+        BF_FAIL("bf_add_layernorm_bwd: dropout needs a 16-byte aligned d_dx (the gradient of the dropped input)");
     if (rows < 0 || N <= 0) BF_FAIL("bf_add_layernorm_bwd: bad shape rows=%lld N=%d", rows, N);
     if (N % 8 || N > 4096) BF_FAIL("bf_add_layernorm_bwd: N=%d must be a multiple of 8 and at most 4096", N);
     if (!d_dgamma || !d_dbeta) BF_FAIL("bf_add_layernorm_bwd: null parameter gradient");
@@ -528,8 +571,8 @@ int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const v
     float* partial = reinterpret_cast<float*>(d_workspace);
     int rc = 1;
 #define BF_LNB_DISPATCH(T)                                                                                              \
-    rc = param_dtype == BF_DT_F32 ? launch_bwd_vpl<T, float>(d_x, d_residual, d_gamma, d_dy, d_dz, partial, nb, rows, N, eps, stream) \
-         : param_dtype == dtype   ? launch_bwd_vpl<T, T>(d_x, d_residual, d_gamma, d_dy, d_dz, partial, nb, rows, N, eps, stream)     \
+    rc = param_dtype == BF_DT_F32 ? launch_bwd_vpl<T, float>(d_x, d_residual, d_gamma, d_dy, d_dz, partial, nb, rows, N, eps, stream, drop, d_dx) \
+         : param_dtype == dtype   ? launch_bwd_vpl<T, T>(d_x, d_residual, d_gamma, d_dy, d_dz, partial, nb, rows, N, eps, stream, drop, d_dx)     \
                                   : (bf_set_error("bf_add_layernorm_bwd: gamma must be fp32 or have the activation dtype"), 1)
     switch (dtype) {
         case BF_DT_BF16: BF_LNB_DISPATCH(__bf16); break;

@@ -78,6 +78,45 @@ static inline void bf_normal4_host(uint64_t group, uint32_t sample, uint32_t str
     bf_box_muller_host(x.z, x.w, &z[2], &z[3]);
 }
 
+// ---- dropout contract -----------------------------------------------------------------------------------------------
+// The reference trains with the wrapped model in .train() (/root/reference/examples/bert_glue.py:221): HuggingFace's
+// dropout (p = 0.1) is a second, non-Philox noise source there.  Inside the fused kernels a keep / drop decision is a pure
+// function of (seed, call, site, element), so a backward pass — or the recomputation of a checkpointed block — finds the
+// forward's mask again without storing it:
+//   group g = 8 elements (which 8 is the kernel's choice and part of its contract: 8 consecutive hidden features of a row
+//             for the residual + LayerNorm path, the 8 probabilities of one P^T fragment for the attention path)
+//   (x0..x3) = Philox4x32-7(counter = {lo32(g), call, 0x80000000 | site, hi32(g)}, key = {lo32(seed), hi32(seed)})
+//   field i (0..7) = the 16-bit halves of x0, x1, x2, x3 in that order, low half first
+//   element i is KEPT iff field_i >= thresh,  thresh = round(p * 65536)   (p exact to 1.5e-5), kept values scale by 1/(1-p')
+//   with p' = thresh / 65536.
+// Streams with the top bit set cannot collide with the weight streams 2 * layer_id + {0, 1}.  `call` identifies the
+// forward (one number per bnn.Model forward), `site` the module the dropout belongs to.
+#define BF_DROPOUT_STREAM 0x80000000u
+BF_HD uint32_t bf_dropout_thresh(float p) {
+    const float t = p * 65536.0f + 0.5f;
+    return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (uint32_t)t);
+}
+BF_HD uint32_t bf_dropout_keep8(uint32_t g_lo, uint32_t g_hi, uint32_t call, uint32_t site, uint32_t k0, uint32_t k1,
+                                uint32_t thresh) {
+    const bf_u32x4 x = bf_philox4x32(g_lo, call, BF_DROPOUT_STREAM | site, g_hi, k0, k1);
+    const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+    uint32_t keep = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        keep |= ((w[i] & 0xFFFFu) >= thresh ? 1u : 0u) << (2 * i);
+        keep |= ((w[i] >> 16) >= thresh ? 1u : 0u) << (2 * i + 1);
+    }
+    return keep;
+}
+
+// what a kernel needs to know about a dropout it applies (thresh == 0: none)
+struct bf_dropout_t {
+    uint32_t k0, k1;     // seed
+    uint32_t call, site;
+    uint32_t thresh;     // bf_dropout_thresh(p)
+    float inv_keep;      // 1 / (1 - thresh / 65536)
+};
+
 #if defined(__HIPCC__) || defined(__HIP__)
 // Device Box-Muller on the hardware transcendental units.
 //   v_log_f32 is log2; v_sin_f32 / v_cos_f32 take their argument in revolutions (valid for |x| <= 256).

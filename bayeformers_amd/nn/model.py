@@ -47,6 +47,7 @@ class _ForwardContext:
         self.shared_out = {}  # id(first layer of a stacked run) -> (input identity, [L, S, M, N] outputs)
         self.counter = bfr.counter_snapshot()  # device-counter mode: the counter value this forward's kernels added
         self.graph_tasks = set()  # ids of the backward passes that reached this forward's outputs (bfr.remember_context)
+        self.drop_call = bfr.reserve_dropout_call()  # the `call` of every dropout applied inside this forward
 
     @contextlib.contextmanager
     def replay(self):

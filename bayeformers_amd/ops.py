@@ -451,8 +451,33 @@ def embedding_backward(ids: Tensor, grad: Tensor, mu: Tensor, rho: Tensor, S: in
     return dmu, drho
 
 
-def add_layernorm(x: Tensor, residual: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float) -> Tensor:
-    """LayerNorm(x + residual) over the last axis in one pass (bf_add_layernorm); residual may be None."""
+class Dropout:
+    """One dropout of the training-mode forward, as the kernels take it (the dropout contract of csrc/bf_philox.h):
+    rate p, the Philox seed, `call` = the number of the forward it belongs to (reserved with the forward's sample indices, so
+    a backward pass and the recomputation of a checkpointed block find the same mask) and `site` = the module."""
+    __slots__ = ("p", "seed", "call", "site")
+
+    def __init__(self, p: float, seed: int, call: int, site: int):
+        self.p, self.seed, self.call, self.site = float(p), int(seed), int(call) & 0xFFFFFFFF, int(site) & 0x7FFFFFFF
+
+    @property
+    def keep_scale(self) -> float:
+        thresh = min(65535, int(self.p * 65536.0 + 0.5))
+        return 1.0 / (1.0 - thresh / 65536.0)
+
+
+def dropout_keep_host(first_group: int, n_groups: int, d: "Dropout") -> Tensor:
+    """Host twin of the kernels' keep decisions (bf_dropout_keep_host): uint8 [n_groups, 8], 1 = kept."""
+    out = torch.empty((int(n_groups), 8), dtype=torch.uint8)
+    _C.check(_C.lib().bf_dropout_keep_host(out.data_ptr(), int(first_group), int(n_groups), d.p, d.seed, d.call, d.site),
+             "bf_dropout_keep_host")
+    return out
+
+
+def add_layernorm(x: Tensor, residual: Optional[Tensor], gamma: Tensor, beta: Tensor, eps: float,
+                  drop: Optional[Dropout] = None) -> Tensor:
+    """LayerNorm(x + residual) over the last axis in one pass (bf_add_layernorm); residual may be None.
+    drop: LayerNorm(dropout(x) + residual) (bf_add_layernorm_dropout)."""
     _require_device(x, "add_layernorm input")
     N = x.shape[-1]
     x2 = x.reshape(-1, N)
@@ -466,6 +491,12 @@ def add_layernorm(x: Tensor, residual: Optional[Tensor], gamma: Tensor, beta: Te
     if gamma.dtype != beta.dtype or gamma.dtype not in (torch.float32, x.dtype):
         raise _C.BayeFormersAMDError("add_layernorm: gamma/beta must be float32 or have the input's dtype")
     out = torch.empty_like(x2)
+    if drop is not None and drop.p > 0.0:
+        _C.check(_C.lib().bf_add_layernorm_dropout(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
+                                                   beta.data_ptr(), _TORCH2BF[gamma.dtype], out.data_ptr(),
+                                                   _TORCH2BF[x.dtype], x2.shape[0], N, float(eps), drop.p, drop.seed,
+                                                   drop.call, drop.site, _stream_ptr()), "bf_add_layernorm_dropout")
+        return out.view(x.shape)
     _C.check(_C.lib().bf_add_layernorm(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
                                        beta.data_ptr(), _TORCH2BF[gamma.dtype], out.data_ptr(), _TORCH2BF[x.dtype],
                                        x2.shape[0], N, float(eps), _stream_ptr()), "bf_add_layernorm")
@@ -511,7 +542,8 @@ def attention_supported(q: Tensor, k: Tensor, v: Tensor) -> bool:
 
 
 def attention_forward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tensor], scaling: float,
-                      mask_off: Optional[Tensor] = None, want_lse: bool = False):
+                      mask_off: Optional[Tensor] = None, want_lse: bool = False, drop: Optional[Dropout] = None,
+                      want_keep: bool = False):
     """softmax(q k^T * scaling + key_mask) v (bf_attention_fwd).  q, k, v: [B, H, T, 64] views as described by
     attention_supported; key_mask: additive fp32 [B, T] or None; mask_off: optional 1-element bool/uint8 device tensor,
     true = the mask is all zeros (the kernel then skips it).  Returns [B, T, H, 64] contiguous — and, with want_lse, the
@@ -519,6 +551,19 @@ def attention_forward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tensor
     B, H, T, D = q.shape
     out = torch.empty((B, T, H, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, T), dtype=torch.float32, device=q.device) if want_lse else None
+    if drop is not None and drop.p > 0.0:
+        # attention_probs_dropout in the kernel (bf_attention_fwd_dropout); with want_keep the decisions come back as one
+        # bit per probability ([B, H, T, T/32] int32) for bf_attention_bwd_dropout
+        keep = torch.empty((B, H, T, T // 32), dtype=torch.int32, device=q.device) if want_keep else None
+        _C.check(_C.lib().bf_attention_fwd_dropout(q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                                   key_mask.data_ptr() if key_mask is not None else None,
+                                                   mask_off.data_ptr() if mask_off is not None else None, out.data_ptr(),
+                                                   lse.data_ptr() if lse is not None else None, _TORCH2BF[q.dtype], B, T, H,
+                                                   D, H * D, float(scaling), drop.p, drop.seed, drop.call, drop.site,
+                                                   keep.data_ptr() if keep is not None else None, _stream_ptr()),
+                 "bf_attention_fwd_dropout")
+        res = (out,) + ((lse,) if want_lse else ()) + ((keep,) if want_keep else ())
+        return res if len(res) > 1 else out
     _C.check(_C.lib().bf_attention_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                        key_mask.data_ptr() if key_mask is not None else None,
                                        mask_off.data_ptr() if mask_off is not None else None, out.data_ptr(),
@@ -529,7 +574,8 @@ def attention_forward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tensor
 
 
 def attention_backward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tensor], mask_off: Optional[Tensor],
-                       out: Tensor, grad_out: Tensor, lse: Tensor, scaling: float):
+                       out: Tensor, grad_out: Tensor, lse: Tensor, scaling: float, drop_p: float = 0.0,
+                       keep: Optional[Tensor] = None):
     """Gradients of attention_forward (bf_attention_bwd).  Returns (dq, dk, dv), each [B, T, H, 64] contiguous."""
     B, H, T, D = q.shape
     go = grad_out if (grad_out.dtype == q.dtype and grad_out.is_contiguous()) else grad_out.to(q.dtype).contiguous()
@@ -537,6 +583,15 @@ def attention_backward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tenso
     dqkv = torch.empty((3, B, T, H, D), dtype=q.dtype, device=q.device)
     dq, dk, dv = dqkv[0], dqkv[1], dqkv[2]
     delta = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+    if drop_p > 0.0:
+        _C.check(_C.lib().bf_attention_bwd_dropout(q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                                   key_mask.data_ptr() if key_mask is not None else None,
+                                                   mask_off.data_ptr() if mask_off is not None else None, out.data_ptr(),
+                                                   go.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(),
+                                                   dk.data_ptr(), dv.data_ptr(), _TORCH2BF[q.dtype], B, T, H, D, H * D,
+                                                   float(scaling), float(drop_p), keep.data_ptr(), _stream_ptr()),
+                 "bf_attention_bwd_dropout")
+        return dq, dk, dv
     _C.check(_C.lib().bf_attention_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                        key_mask.data_ptr() if key_mask is not None else None,
                                        mask_off.data_ptr() if mask_off is not None else None, out.data_ptr(),
@@ -551,23 +606,31 @@ class AttentionFn(torch.autograd.Function):
     statistic per query is kept; the probabilities are recomputed in the backward kernels."""
 
     @staticmethod
-    def forward(ctx, q, k, v, key_mask, mask_off, scaling):
-        out, lse = attention_forward(q, k, v, key_mask, scaling, mask_off, want_lse=True)
-        ctx.save_for_backward(q, k, v, out, lse)
+    def forward(ctx, q, k, v, key_mask, mask_off, scaling, drop=None):
+        ctx.drop_p = drop.p if drop is not None else 0.0
+        if ctx.drop_p > 0.0:  # training mode: probabilities dropped in the kernel, one keep bit each kept for the backward
+            out, lse, keep = attention_forward(q, k, v, key_mask, scaling, mask_off, want_lse=True, drop=drop, want_keep=True)
+            ctx.save_for_backward(q, k, v, out, lse, keep)
+        else:
+            out, lse = attention_forward(q, k, v, key_mask, scaling, mask_off, want_lse=True)
+            ctx.save_for_backward(q, k, v, out, lse)
         ctx.key_mask, ctx.mask_off, ctx.scaling = key_mask, mask_off, scaling
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        q, k, v, out, lse = ctx.saved_tensors
-        dq, dk, dv = attention_backward(q, k, v, ctx.key_mask, ctx.mask_off, out, grad_out, lse, ctx.scaling)
+        q, k, v, out, lse = ctx.saved_tensors[:5]
+        keep = ctx.saved_tensors[5] if ctx.drop_p > 0.0 else None
+        dq, dk, dv = attention_backward(q, k, v, ctx.key_mask, ctx.mask_off, out, grad_out, lse, ctx.scaling, ctx.drop_p, keep)
         # q, k, v came in as [B, H, T, 64] views of [B, T, H*64] projections: hand the gradients back in that view
-        return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2), None, None, None
+        return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2), None, None, None, None
 
 
-def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor, grad_out: Tensor, eps: float):
+def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor, grad_out: Tensor, eps: float,
+                           drop: Optional[Dropout] = None):
     """Gradients of add_layernorm (bf_add_layernorm_bwd): returns (dz, dgamma, dbeta); dz is the gradient of both x
-    and residual, dgamma / dbeta are fp32."""
+    and residual, dgamma / dbeta are fp32.  With `drop` (bf_add_layernorm_dropout_bwd) returns (dz, dgamma, dbeta, dx):
+    dz is the residual's gradient, dx = dz o keep / (1 - p) the dropped input's."""
     N = x.shape[-1]
     x2 = x.reshape(-1, N)
     x2 = x2 if x2.is_contiguous() else x2.contiguous()
@@ -583,6 +646,14 @@ def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor,
     lib = _C.lib()
     need = lib.bf_add_layernorm_bwd_workspace_bytes(x2.shape[0], N)
     ws = workspace(x.device, need)
+    if drop is not None and drop.p > 0.0:
+        dx = torch.empty_like(x2)
+        _C.check(lib.bf_add_layernorm_dropout_bwd(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
+                                                  _TORCH2BF[gamma.dtype], g2.data_ptr(), dz.data_ptr(), dx.data_ptr(),
+                                                  dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  _TORCH2BF[x.dtype], x2.shape[0], N, float(eps), drop.p, drop.seed, drop.call,
+                                                  drop.site, _stream_ptr()), "bf_add_layernorm_dropout_bwd")
+        return dz.view(x.shape), dgamma, dbeta, dx.view(x.shape)
     _C.check(lib.bf_add_layernorm_bwd(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
                                       _TORCH2BF[gamma.dtype], g2.data_ptr(), dz.data_ptr(), dgamma.data_ptr(),
                                       dbeta.data_ptr(), ws.data_ptr(), ws.numel(), _TORCH2BF[x.dtype], x2.shape[0], N,
@@ -594,22 +665,27 @@ class AddLayerNormFn(torch.autograd.Function):
     """LayerNorm(x + residual) * gamma + beta with both directions in the HIP kernels; nothing but the inputs is saved."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps):
+    def forward(ctx, x, residual, gamma, beta, eps, drop=None):
         ctx.eps, ctx.has_res = eps, residual is not None
+        ctx.drop = drop if (drop is not None and drop.p > 0.0) else None
         ctx.save_for_backward(x, residual if residual is not None else x, gamma)
-        return add_layernorm(x, residual, gamma, beta, eps)
+        return add_layernorm(x, residual, gamma, beta, eps, ctx.drop)
 
     @staticmethod
     def backward(ctx, grad_out):
         x, residual, gamma = ctx.saved_tensors
-        dz, dgamma, dbeta = add_layernorm_backward(x, residual if ctx.has_res else None, gamma, grad_out, ctx.eps)
+        dx = None
+        if ctx.drop is not None:  # the mask is regenerated from (seed, call, site): nothing was stored
+            dz, dgamma, dbeta, dx = add_layernorm_backward(x, residual if ctx.has_res else None, gamma, grad_out, ctx.eps, ctx.drop)
+        else:
+            dz, dgamma, dbeta = add_layernorm_backward(x, residual if ctx.has_res else None, gamma, grad_out, ctx.eps)
         need = ctx.needs_input_grad
         if gamma.dtype != torch.float32 and (need[2] or need[3]):
             # dgamma and dbeta are the two rows of one fp32 buffer: cast them with one launch
             both = dgamma._base.to(gamma.dtype) if dgamma._base is not None else torch.stack((dgamma, dbeta)).to(gamma.dtype)
             dgamma, dbeta = both[0], both[1]
-        return (dz if need[0] else None, dz if (ctx.has_res and need[1]) else None,
-                dgamma if need[2] else None, dbeta if need[3] else None, None)
+        return ((dx if dx is not None else dz) if need[0] else None, dz if (ctx.has_res and need[1]) else None,
+                dgamma if need[2] else None, dbeta if need[3] else None, None, None)
 
 
 def layernorm_supported(x: Tensor, residual: Optional[Tensor], ln) -> bool:

@@ -32,6 +32,8 @@ class _State:
         self.next_layer_id = 0
         self.device_counter = None  # 1-element int32 device tensor when the sample counter lives on the GPU
         self.kl_gradient = False    # opt-in Bayes-by-Backprop gradient of the KL terms (the reference has none)
+        self.next_dropout_call = 0  # dropout contract (csrc/bf_philox.h): one `call` number per forward
+        self.next_dropout_site = 1  # ... and one `site` number per module that applies a dropout
 
 
 STATE = _State()
@@ -41,6 +43,7 @@ def manual_seed(seed: int, next_sample: int = 0) -> None:
     """Seed the Philox key and rewind the Monte-Carlo sample counter."""
     STATE.seed = int(seed) & (2 ** 64 - 1)
     STATE.next_sample = int(next_sample) & 0xFFFFFFFF
+    STATE.next_dropout_call = 0
     if STATE.device_counter is not None:
         v = STATE.next_sample if STATE.next_sample < 2 ** 31 else STATE.next_sample - 2 ** 32
         STATE.device_counter.fill_(v)
@@ -158,6 +161,30 @@ def recompute_context():
         "bayeformers_amd: a Bayesian layer is being recomputed during backward (a checkpointed block) and "
         f"{len(hit) or len(STATE.live_ctxs)} finished bnn.Model forwards could own it; run backward() after each "
         "grad-enabled forward of a checkpointed model (evaluation passes belong under torch.no_grad())")
+
+
+def reserve_dropout_call() -> int:
+    """A fresh `call` number of the dropout contract (csrc/bf_philox.h): every bnn.Model forward takes one, so that all the
+    dropouts of that forward — and their regeneration in backward or in a recomputed checkpointed block — share it."""
+    c = STATE.next_dropout_call
+    STATE.next_dropout_call = (c + 1) & 0xFFFFFFFF
+    return c
+
+
+def dropout_call() -> int:
+    """The `call` number for a dropout applied now: the running bnn.Model forward's, the original forward's when a
+    checkpointed block is being recomputed during backward, a fresh one outside any forward."""
+    ctx = STATE.ctx if STATE.ctx is not None else recompute_context()
+    return ctx.drop_call if ctx is not None else reserve_dropout_call()
+
+
+def dropout_site(module) -> int:
+    """The `site` number of a module (assigned at its first dropout, in execution order: stable for a given model)."""
+    site = getattr(module, "_bf_drop_site", None)
+    if site is None:
+        site = module._bf_drop_site = STATE.next_dropout_site
+        STATE.next_dropout_site += 1
+    return site
 
 
 def new_layer_id() -> int:

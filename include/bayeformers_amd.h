@@ -293,6 +293,41 @@ int bf_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const fl
                      void* d_dv, int dtype, int B, int T, int H, int head_dim, int64_t token_stride, float scaling,
                      void* stream);
 
+/* ---- training mode: HuggingFace dropout inside the fused kernels ------------------------------------------------------
+ * The reference trains with the wrapped model in .train() (/root/reference/examples/bert_glue.py:221,227-241): HF's
+ * dropout (p = 0.1) acts on the attention probabilities and on every dense output in front of a residual + LayerNorm.
+ * Here a keep / drop decision is a pure function of (seed, call, site, element) — the dropout contract of
+ * csrc/bf_philox.h: groups of 8 elements, one Philox4x32-7 block per group under stream 0x80000000 | site, 16-bit fields
+ * compared with round(p * 65536) — so nothing but a bit per attention probability is kept for the backward pass.
+ *   call = one number per forward (the Python side reserves it with the forward's sample indices, so the recomputation
+ *          of a checkpointed block finds the same masks), site = the module the dropout belongs to.
+ * bf_dropout_keep_host: the host twin — keep flags (0 / 1), 8 per group, of groups first_group .. first_group + n_groups.
+ *
+ * bf_attention_fwd_dropout: bf_attention_fwd with the probabilities dropped after the softmax normalisation.  Group of
+ *   probability (b, h, q, key): g = (((b*H + h)*T + q) * (T/32) + (key/128)*4 + c) * 4 + lg, field e*4 + j, where
+ *   key % 128 = (2c + e)*16 + 4 lg + j.  d_keep_bits (nullable; needed by the backward): [B][H][T][T/32] words, word
+ *   (b, h, q, key/128, lg), bit c*8 + e*4 + j.
+ * bf_attention_bwd_dropout: bf_attention_bwd for that forward; sequences of ONE tile (T = 128) only.
+ * bf_add_layernorm_dropout: LayerNorm(dropout(x) + residual); group of element (row, n): row * (N/8) + n/8, field n % 8.
+ * bf_add_layernorm_dropout_bwd: its backward; d_dz = gradient of the residual, d_dx = d_dz o keep / (1 - p). */
+int bf_dropout_keep_host(uint8_t* out, uint64_t first_group, uint64_t n_groups, float p_drop, uint64_t seed, uint32_t call,
+                         uint32_t site);
+int bf_attention_fwd_dropout(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
+                             void* d_out, float* d_lse, int dtype, int B, int T, int H, int head_dim, int64_t token_stride,
+                             float scaling, float p_drop, uint64_t seed, uint32_t call, uint32_t site, uint32_t* d_keep_bits,
+                             void* stream);
+int bf_attention_bwd_dropout(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
+                             const void* d_out, const void* d_dout, const float* d_lse, float* d_delta, void* d_dq, void* d_dk,
+                             void* d_dv, int dtype, int B, int T, int H, int head_dim, int64_t token_stride, float scaling,
+                             float p_drop, const uint32_t* d_keep_bits, void* stream);
+int bf_add_layernorm_dropout(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, int param_dtype,
+                             void* d_out, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed, uint32_t call,
+                             uint32_t site, void* stream);
+int bf_add_layernorm_dropout_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
+                                 const void* d_dy, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
+                                 size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
+                                 uint32_t call, uint32_t site, void* stream);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * While enabled, every sampling launch (kind BF_PROF_SAMPLE) and every GEMM launch (BF_PROF_GEMM) made through
  * this library is bracketed by two events; bf_profile_read() synchronises them and returns, per kind, the number

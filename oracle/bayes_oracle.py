@@ -75,6 +75,44 @@ def philox4x32_numpy(ctr, key, rounds=PHILOX_ROUNDS):
     return c.astype(np.uint32)
 
 
+def dropout_keep(first_group, n_groups, p, seed, call, site):
+    """Keep flags (uint8 [n_groups, 8], 1 = kept) of dropout groups first_group .. — an independent restatement of the
+    dropout contract of bayeformers_amd/csrc/bf_philox.h: Philox4x32-7 with counter {lo32(g), call, 0x80000000 | site,
+    hi32(g)}, the eight 16-bit halves of its four words (low half first) compared with round(p * 65536).
+
+    Stands in for torch.nn.Dropout in the wrapped HuggingFace modules the reference trains in .train() mode
+    (/root/reference/examples/bert_glue.py:221): like epsilon, the mask is the build's own contract — a test applies THIS
+    mask with plain torch ops and compares with the kernels."""
+    g = np.uint64(first_group) + np.arange(int(n_groups), dtype=np.uint64)
+    ctr = np.stack([g & np.uint64(0xFFFFFFFF), np.full_like(g, np.uint64(call & 0xFFFFFFFF)),
+                    np.full_like(g, np.uint64(0x80000000 | (site & 0x7FFFFFFF))), g >> np.uint64(32)], axis=-1)
+    x = philox4x32_numpy(ctr, [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF]).astype(np.uint32)
+    fields = np.stack([f for i in range(4) for f in (x[:, i] & np.uint32(0xFFFF), x[:, i] >> np.uint32(16))], axis=-1)
+    t = np.float32(p) * np.float32(65536.0) + np.float32(0.5)
+    thresh = 0 if t <= 0 else (65535 if t >= 65535 else int(t))
+    return (fields >= np.uint32(thresh)).astype(np.uint8)
+
+
+def dropout_keep_scale(p):
+    t = np.float32(p) * np.float32(65536.0) + np.float32(0.5)
+    thresh = 0 if t <= 0 else (65535 if t >= 65535 else int(t))
+    return 1.0 / (1.0 - thresh / 65536.0)
+
+
+def attention_keep_mask(B, H, T, p, seed, call, site):
+    """[B, H, T(query), T(key)] keep mask of bf_attention_fwd_dropout: the group of probability (b, h, q, key) is
+    (((b*H + h)*T + q) * (T/32) + (key // 128)*4 + c) * 4 + lg with key % 128 = (2c + e)*16 + 4 lg + j, field e*4 + j."""
+    keep = dropout_keep(0, B * H * T * (T // 8), p, seed, call, site).reshape(B, H, T, T // 128, 4, 4, 8)  # [.., tile, c, lg, field]
+    out = np.empty((B, H, T, T), dtype=np.uint8)
+    for tile in range(T // 128):
+        for c in range(4):
+            for lg in range(4):
+                for e in range(2):
+                    k0 = tile * 128 + (2 * c + e) * 16 + 4 * lg
+                    out[..., k0:k0 + 4] = keep[:, :, :, tile, c, lg, e * 4:e * 4 + 4]
+    return out
+
+
 def normals(n, seed, sample, stream, offset=0):
     """eps for elements [offset, offset+n) of Philox stream `stream`, MC sample `sample` (fp32 numpy array).
 

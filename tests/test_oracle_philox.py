@@ -1,5 +1,6 @@
 """The oracle's epsilon generator: Random123 known-answer vectors, C vs numpy, committed KAT, host twin."""
 import numpy as np
+import pytest
 
 from oracle import bayes_oracle as bo
 
@@ -60,3 +61,24 @@ def test_product_host_twin_matches_oracle():
     for n, seed, sample, stream, off in [(4099, 0x5EED, 0, 0, 0), (257, 77, 12, 147, 6)]:
         a = ops.philox_normal_host(n, seed, sample, stream, off).numpy()
         assert np.array_equal(a, bo.normals(n, seed, sample, stream, off))
+
+
+def test_dropout_host_twin_matches_the_oracle_restatement():
+    """bf_dropout_keep_host (the library's host twin of the kernels' keep decisions) against the oracle's independent
+    numpy restatement of the dropout contract, incl. groups past 2^32 and the rate the 16-bit threshold realises."""
+    import torch
+
+    from bayeformers_amd import ops
+    from oracle import bayes_oracle as bo
+
+    for p, seed, call, site, first in [(0.1, 0x5EED, 0, 1, 0), (0.1, 0x5EED, 7, 3, 2 ** 32 - 5), (0.5, 12345678901234, 9, 250, 17),
+                                       (0.0, 1, 2, 3, 0)]:
+        d = ops.Dropout(p, seed, call, site)
+        host = ops.dropout_keep_host(first, 4096, d).numpy()
+        ref = bo.dropout_keep(first, 4096, p, seed, call, site)
+        assert np.array_equal(host, ref)
+        assert abs(host.mean() - (1.0 - p)) < 0.01
+        assert d.keep_scale == pytest.approx(bo.dropout_keep_scale(p), rel=1e-12)
+    # different call / site / seed -> different masks
+    a = bo.dropout_keep(0, 512, 0.1, 1, 0, 1)
+    assert not np.array_equal(a, bo.dropout_keep(0, 512, 0.1, 1, 1, 1)) and not np.array_equal(a, bo.dropout_keep(0, 512, 0.1, 1, 0, 2))
