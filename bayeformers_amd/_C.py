@@ -50,8 +50,8 @@ SYMBOLS = {
     "bf_sample_logprob_workspace_bytes": (_sz, [_tp, _i, _i]),
     "bf_sample_logprob": (_i, [_tp, _i, _i, _u64, _u32, _vp, _vp, _sz, _vp]),
     "bf_sample_table_bytes": (_sz, [_tp, _i, ctypes.POINTER(ctypes.c_uint32)]),
-    "bf_sample_table_build": (_i, [_tp, _i, _vp, _sz, _vp]),
-    "bf_sample_logprob_table": (_i, [_vp, _i, _u32, _u32, _i, _u64, _u32, _vp, _vp]),
+    "bf_sample_table_build": (_i, [_tp, _i, _vp, _sz, _vp, _vp]),
+    "bf_sample_logprob_table": (_i, [_vp, _i, _u32, _u32, _i, _u64, _u32, _vp, _i, _vp]),
     "bf_reduce_logprob": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "bf_gemm_nt": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "bf_gemm_nt_act": (_i, [_vp, _i, _i64, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -98,7 +98,7 @@ SYMBOLS = {
 BF_PROF_SAMPLE, BF_PROF_GEMM, BF_PROF_FUSED_SMALL, BF_PROF_FUSED_WS = 0, 1, 2, 3
 BF_ACT_NONE, BF_ACT_GELU = 0, 1
 
-ABI_VERSION = 2  # bf_version() of the library these bindings describe (include/bayeformers_amd.h: BF_VERSION_*)
+ABI_VERSION = 3  # bf_version() of the library these bindings describe (include/bayeformers_amd.h: BF_VERSION_*)
 
 # developer-build entry points (csrc/bf_dev_api.h): bound when the loaded library has them (BF_LIB_PATH=..._dev.so)
 DEV_SYMBOLS = {

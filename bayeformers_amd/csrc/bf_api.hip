@@ -215,16 +215,16 @@ size_t bf_sample_table_bytes(const bf_tensor_t* tensors, int n_tensors, uint32_t
 }
 
 int bf_sample_table_build(const bf_tensor_t* tensors, int n_tensors, void* h_blob, size_t blob_bytes,
-                          uint32_t* h_block_begin) {
+                          uint32_t* h_block_begin, int32_t* h_kinds) {
     if (!tensors || n_tensors < 1) BF_FAIL("bf_sample_table_build: no tensors");
-    return bf_table_build(tensors, n_tensors, h_blob, blob_bytes, h_block_begin);
+    return bf_table_build(tensors, n_tensors, h_blob, blob_bytes, h_block_begin, h_kinds);
 }
 
 int bf_sample_logprob_table(const void* d_blob, int n_tensors, uint32_t block_begin, uint32_t block_end, int S,
-                            uint64_t seed, uint32_t sample_base, double* d_partials, void* stream) {
+                            uint64_t seed, uint32_t sample_base, double* d_partials, int prior_kinds, void* stream) {
     ProfScope prof(BF_PROF_SAMPLE, 0.0, (hipStream_t)stream);
     return bf_launch_sample_table(d_blob, n_tensors, block_begin, block_end, S, seed, sample_base, d_partials,
-                                  (hipStream_t)stream);
+                                  (hipStream_t)stream, prior_kinds);
 }
 
 int bf_reduce_logprob(const double* d_partials, const uint32_t* d_rows, int n_groups, int S, double* d_out,

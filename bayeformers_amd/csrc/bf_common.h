@@ -43,9 +43,9 @@ size_t bf_sample_partials_bytes(const bf_tensor_t* tensors, int n_tensors, int S
 int bf_launch_sample_logprob(const bf_tensor_t* tensors, int n_tensors, int S, uint64_t seed, uint32_t sample_base,
                              double* d_logprob_out, void* d_workspace, size_t workspace_bytes, hipStream_t stream);
 size_t bf_table_blob_bytes(const bf_tensor_t* tensors, int n_tensors, uint32_t* total_blocks);
-int bf_table_build(const bf_tensor_t* tensors, int n_tensors, void* h_blob, size_t blob_bytes, uint32_t* h_block_begin);
+int bf_table_build(const bf_tensor_t* tensors, int n_tensors, void* h_blob, size_t blob_bytes, uint32_t* h_block_begin, int32_t* h_kinds = nullptr);
 int bf_launch_sample_table(const void* d_blob, int n_tensors, uint32_t block_begin, uint32_t block_end, int S,
-                           uint64_t seed, uint32_t sample_base, double* d_partials, hipStream_t stream);
+                           uint64_t seed, uint32_t sample_base, double* d_partials, hipStream_t stream, int prior_kinds = 0);
 int bf_launch_reduce_groups(const double* d_partials, const uint32_t* d_rows, int G, int S, double* d_out,
                             hipStream_t stream);
 int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, const void* d_w, int w_dtype,

@@ -351,7 +351,17 @@ struct TableEntry {
     int vec_in, vec_out;
 };
 
-__global__ __launch_bounds__(kThreads) void bf_sample_table_kernel(const TableEntry* __restrict__ table,
+// ONLY >= 0: every tensor of the launch has that (effective) prior kind — the caller says so (bf_sample_logprob_table's
+// prior_kinds) — and the kernel is compiled for it alone: a launch of MOPED-aliased tensors (BERT with delta and
+// freeze=True: all of them) then needs 62-65 VGPRs = 8 waves per SIMD instead of the 80 / 6 of the kernel that must be able
+// to take every kind.
+#ifndef BF_SAMPLE_ONLY_WAVES
+#define BF_SAMPLE_ONLY_WAVES 8  // minimum waves per SIMD asked of the single-kind instantiations: 64 VGPRs (3 dwords of scratch)
+// measured in the BERT-base step, one box, three interleaved runs each (profiles/r4e_sampling_kernel_occupancy_ab.txt):
+// kernel for every prior kind (80 VGPRs, 6 waves) 0.529-0.542 ms, single-kind at 68 VGPRs / 7 waves 0.520-0.527, at 64 / 8 waves 0.514-0.522
+#endif
+template <int ONLY>
+__global__ __launch_bounds__(kThreads, ONLY >= 0 ? BF_SAMPLE_ONLY_WAVES : 1) void bf_sample_table_kernel(const TableEntry* __restrict__ table,
                                                                    const uint32_t* __restrict__ entry_of_block,
                                                                    uint32_t block0, int S, int ny, uint32_t k0,
                                                                    uint32_t k1, uint32_t sample_base,
@@ -369,6 +379,10 @@ __global__ __launch_bounds__(kThreads) void bf_sample_table_kernel(const TableEn
     a.S = S; a.ny = ny; a.k0 = k0; a.k1 = k1;
     a.sample_base = sample_base + (counter ? *counter : 0u);
     a.partial_row = partials + (size_t)gb * S * 2;
+    if constexpr (ONLY >= 0) {
+        sample_body<ONLY, OUT_RUNTIME>(a, red, cst);
+        return;
+    }
     const int pk = __builtin_amdgcn_readfirstlane(e.prior_kind);
     if (pk == PRIOR_GAUSS_ALIAS) sample_body<PRIOR_GAUSS_ALIAS, OUT_RUNTIME>(a, red, cst);
     else if (pk == BF_PRIOR_GAUSSIAN) sample_body<BF_PRIOR_GAUSSIAN, OUT_RUNTIME>(a, red, cst);
@@ -571,7 +585,8 @@ size_t bf_table_blob_bytes(const bf_tensor_t* tensors, int n_tensors, uint32_t* 
     return bf_align_up((size_t)n_tensors * sizeof(TableEntry), 256) + bf_align_up((size_t)blk * sizeof(uint32_t), 256);
 }
 
-int bf_table_build(const bf_tensor_t* tensors, int n_tensors, void* h_blob, size_t blob_bytes, uint32_t* h_block_begin) {
+int bf_table_build(const bf_tensor_t* tensors, int n_tensors, void* h_blob, size_t blob_bytes, uint32_t* h_block_begin,
+                   int32_t* h_kinds) {
     uint32_t total = 0;
     const size_t need = bf_table_blob_bytes(tensors, n_tensors, &total);
     if (!h_blob || blob_bytes < need) BF_FAIL("bf_sample_table_build: blob too small (%zu < %zu bytes)", blob_bytes, need);
@@ -587,6 +602,7 @@ int bf_table_build(const bf_tensor_t* tensors, int n_tensors, void* h_blob, size
         e.mu = T.d_mu; e.rho = T.d_rho; e.mu_p = T.prior.d_mu; e.rho_p = T.prior.d_rho;
         e.out = T.d_sample_out; e.n = T.n; e.stream = T.stream_id; e.block_begin = blk;
         e.prior_kind = effective_prior(T.prior); e.out_dt = T.out_dtype;
+        if (h_kinds) h_kinds[t] = e.prior_kind;
         uintptr_t align_bits = (uintptr_t)T.d_mu | (uintptr_t)T.d_rho;
         if (T.prior.kind == BF_PRIOR_GAUSSIAN) align_bits |= (uintptr_t)T.prior.d_mu | (uintptr_t)T.prior.d_rho;
         e.vec_in = (align_bits & 15) == 0;
@@ -614,7 +630,7 @@ int bf_table_build(const bf_tensor_t* tensors, int n_tensors, void* h_blob, size
 }
 
 int bf_launch_sample_table(const void* d_blob, int n_tensors, uint32_t block_begin, uint32_t block_end, int S,
-                           uint64_t seed, uint32_t sample_base, double* d_partials, hipStream_t stream) {
+                           uint64_t seed, uint32_t sample_base, double* d_partials, hipStream_t stream, int prior_kinds) {
     if (!d_blob || !d_partials) BF_FAIL("bf_sample_logprob_table: NULL blob or partials");
     if (S < 1 || block_end <= block_begin) BF_FAIL("bf_sample_logprob_table: empty launch (S=%d)", S);
     const TableEntry* ent = reinterpret_cast<const TableEntry*>(d_blob);
@@ -622,8 +638,13 @@ int bf_launch_sample_table(const void* d_blob, int n_tensors, uint32_t block_beg
                                                             bf_align_up((size_t)n_tensors * sizeof(TableEntry), 256));
     const uint32_t blk = block_end - block_begin;
     const int ny = pick_ny(blk, S);
-    hipLaunchKernelGGL(bf_sample_table_kernel, dim3(blk, (uint32_t)ny), dim3(kThreads), 0, stream, ent, map,
-                       block_begin, S, ny, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, bf_sample_counter(), d_partials);
+#define BF_TABLE_LAUNCH(ONLY)                                                                                          \
+    hipLaunchKernelGGL(bf_sample_table_kernel<ONLY>, dim3(blk, (uint32_t)ny), dim3(kThreads), 0, stream, ent, map,      \
+                       block_begin, S, ny, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, bf_sample_counter(), d_partials)
+    if (prior_kinds == (1 << PRIOR_GAUSS_ALIAS)) BF_TABLE_LAUNCH(PRIOR_GAUSS_ALIAS);
+    else if (prior_kinds == (1 << BF_PRIOR_MIXTURE)) BF_TABLE_LAUNCH(BF_PRIOR_MIXTURE);
+    else BF_TABLE_LAUNCH(-1);
+#undef BF_TABLE_LAUNCH
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }

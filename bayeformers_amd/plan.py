@@ -116,6 +116,7 @@ class SamplePlan:
         self.arena_owner = [None] * len(self.arenas)
 
         self.pending = set()  # groups sampled in the running forward whose block partials are not reduced yet
+        self._kinds_of = {}   # (first group, last group) -> set of prior kinds of a launch over those groups
 
         # table: entries in layer order (weight, then bias)
         n_entries = sum(1 + (self.slices[id(l)][2] is not None) for l in layers)
@@ -157,8 +158,11 @@ class SamplePlan:
         nbytes = lib.bf_sample_table_bytes(arr, n_entries, ctypes.byref(total))
         blob = torch.empty(nbytes, dtype=torch.uint8, pin_memory=False)
         begin = torch.empty(n_entries + 1, dtype=torch.int32)
-        _C.check(lib.bf_sample_table_build(arr, n_entries, blob.data_ptr(), nbytes, begin.data_ptr()),
+        kinds = torch.empty(n_entries, dtype=torch.int32)  # the tensors' effective prior kinds
+        _C.check(lib.bf_sample_table_build(arr, n_entries, blob.data_ptr(), nbytes, begin.data_ptr(), kinds.data_ptr()),
                  "bf_sample_table_build")
+        self.entry_kinds = kinds.tolist()
+        self.first_entry_of_layer = first_entry_of_layer + [n_entries]
         self.n_entries, self.total_blocks = n_entries, total.value
         self.blob = blob.to(device)
         begin_l = begin.tolist()
@@ -220,8 +224,19 @@ class SamplePlan:
     def _sample_groups(self, first: int, last: int, token, seed: int, sample_base: int):
         """ONE launch over the (contiguous) blocks of groups first..last; they must map to distinct arenas."""
         b0, b1 = self.group_span[first][2], self.group_span[last][3]
+        # the set of prior kinds among the launched tensors: a uniform launch runs the kernel compiled for its kind alone
+        mask = self._kinds_of.get((first, last))
+        if mask is None:
+            l0 = self.group_span[first][0]
+            l1 = self.group_span[last][0] + self.group_span[last][1]
+            mask = 0
+            for k in self.entry_kinds[self.first_entry_of_layer[l0]:self.first_entry_of_layer[l1]]:
+                mask |= 1 << k
+            if os.environ.get("BF_NO_UNIFORM_TABLE") is not None:
+                mask = 0  # developer A/B: always the kernel that takes every prior kind
+            self._kinds_of[(first, last)] = mask
         _C.check(_C.lib().bf_sample_logprob_table(self.blob.data_ptr(), self.n_entries, b0, b1, self.S, seed,
-                                                  sample_base & 0xFFFFFFFF, self.partials.data_ptr(),
+                                                  sample_base & 0xFFFFFFFF, self.partials.data_ptr(), mask,
                                                   ops._stream_ptr()), "bf_sample_logprob_table")
         for gi in range(first, last + 1):
             self.pending.add(gi)

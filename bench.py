@@ -53,8 +53,11 @@ def parse():
                          "the default is weak scaling, --samples per GPU, which is what the driver's scaling run measures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-mode", action="store_true",
-                    help="bert_base_train only: put the model in .train() like examples/bert_glue.py:221 (HF dropout p = 0.1 "
-                         "active: attention and embeddings take the framework's paths); default: dropout off")
+                    help="(default since round 4, accepted for old command lines) bert_base_train runs with the model in "
+                         ".train() like examples/bert_glue.py:221: HF dropout p = 0.1 active, inside the fused kernels")
+    ap.add_argument("--no-dropout", action="store_true",
+                    help="bert_base_train only: keep the wrapped model's modules in eval mode (dropout off), the step rounds "
+                         "1-3 timed")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--calibrate-traffic", action="store_true",
                     help="(set by the PMC child passes) run the known-size streaming reads that calibrate the counters first")
@@ -205,7 +208,8 @@ def make_bert(device, S, dtype, train=False, train_mode=False):
         return cpu_line(1, times, best, sweep, "serial MC samples (fwd + log-probs) of the same BERT-base B=32 L=128 batch")
 
     cfgd = {"workload": "to_bayesian(BERT-base seq-cls, delta=0.05, freeze=True) " +
-                        (("training step: fwd+ELBO+backward+clip+AdamW, " + ("model.train(): dropout 0.1" if train_mode else "dropout off"))
+                        (("training step: fwd+ELBO+backward+clip+AdamW, " +
+                          ("model.train(): HF dropout 0.1 inside the fused kernels" if train_mode else "dropout off (--no-dropout)"))
                          if train else "fwd+ELBO"), "samples_per_gpu": S,
             "batch": B, "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "bayesian_scalars": 85609730}
     cfgd.update(info)
@@ -666,7 +670,7 @@ def main():
     if args.workload == "bert_base":
         step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype)
     elif args.workload == "bert_base_train":
-        step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype, train=True, train_mode=args.train_mode)
+        step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype, train=True, train_mode=not args.no_dropout)
     elif args.workload == "bert_large_qa":
         step, cpu_baseline, cfgd, bmodel = make_bert_large_qa(device, S, dtype)
     elif args.workload == "linear768":

@@ -25,7 +25,8 @@ extern "C" {
 #endif
 
 #define BF_VERSION_MAJOR 0
-#define BF_VERSION_MINOR 2  /* 2: bf_embed_layernorm takes the table row counts */
+#define BF_VERSION_MINOR 3  /* 2: bf_embed_layernorm takes the table row counts; 3: bf_sample_table_build reports the
+                               tensors' effective prior kinds, bf_sample_logprob_table takes the launch's set of them */
 
 /* element types of activations / sampled weights */
 enum { BF_DT_F32 = 0, BF_DT_BF16 = 1, BF_DT_F16 = 2 };
@@ -106,12 +107,17 @@ int bf_sample_logprob(const bf_tensor_t* tensors, int n_tensors, int S, uint64_t
  *                          h_block_begin[n_tensors+1], the first block of each tensor;
  *   bf_sample_logprob_table  samples + log-probs of blocks [block_begin, block_end) (whole tensors) and writes one
  *                          [S][2] row of fp64 partial sums per block into d_partials[block] (total_blocks rows);
+ *                          h_kinds (nullable, [n_tensors]): each tensor's EFFECTIVE prior kind — BF_PRIOR_*, or 3 for a
+ *                          Gaussian prior the caller asserted to be the alias of the posterior's mean (bf_prior_t.pi == 1).
+ *                          prior_kinds: bit k set = kind k occurs among the launched tensors, 0 = not known.  A launch
+ *                          whose tensors all share one kind runs a kernel compiled for that kind alone (fewer registers,
+ *                          more waves per SIMD); any other value selects the kernel that takes every kind;
  *   bf_reduce_logprob      d_out[g][s][{log_prior, log_q}] = fixed-order sum of partial rows [d_rows[g], d_rows[g+1]). */
 size_t bf_sample_table_bytes(const bf_tensor_t* tensors, int n_tensors, uint32_t* total_blocks);
 int bf_sample_table_build(const bf_tensor_t* tensors, int n_tensors, void* h_blob, size_t blob_bytes,
-                          uint32_t* h_block_begin);
+                          uint32_t* h_block_begin, int32_t* h_kinds);
 int bf_sample_logprob_table(const void* d_blob, int n_tensors, uint32_t block_begin, uint32_t block_end, int S,
-                            uint64_t seed, uint32_t sample_base, double* d_partials, void* stream);
+                            uint64_t seed, uint32_t sample_base, double* d_partials, int prior_kinds, void* stream);
 int bf_reduce_logprob(const double* d_partials, const uint32_t* d_rows, int n_groups, int S, double* d_out,
                       void* stream);
 
