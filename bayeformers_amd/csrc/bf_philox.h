@@ -38,7 +38,9 @@ struct bf_u32x4 {
 // certify as Crush-resistant (BigCrush passes from 7 rounds on; 10 is their default with extra margin).  The integer
 // multiplies of the round function are the largest single cost of the VALU-bound sampling kernel: 7 instead of 10
 // rounds takes 6 of 19 64-bit multiply-adds out of every block of 4 normals.  Round r uses key + r*W.
-#define BF_PHILOX_ROUNDS 7
+#ifndef BF_PHILOX_ROUNDS
+#define BF_PHILOX_ROUNDS 7  // -DBF_PHILOX_ROUNDS=10 builds the Random123 default (tests/test_oracle_philox.py keeps that build pinned)
+#endif
 BF_HD bf_u32x4 bf_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < BF_PHILOX_ROUNDS; ++r) {

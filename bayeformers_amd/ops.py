@@ -382,10 +382,25 @@ def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_
     if has_bias:
         fill_tensor(b, layer.bias, NoneParameter(), 2 * layer.layer_id + 1)
     dx = torch.empty((S * M, K), dtype=cdt, device=dev) if need_x else None
-    dmu_w = torch.empty((N, K), dtype=torch.float32, device=dev) if need_mu_w else None
-    drho_w = torch.empty((N, K), dtype=torch.float32, device=dev)
-    dmu_b = torch.empty((N,), dtype=torch.float32, device=dev) if (has_bias and need_mu_b) else None
-    drho_b = torch.empty((N,), dtype=torch.float32, device=dev) if has_bias else None
+    # A parameter whose gradient has a standing destination — its slot in a flat all-reduce bucket
+    # (training.GradientBuckets, between zero() and finish()) — gets the kernel's result written there: no copy into the
+    # bucket afterwards, and autograd is handed None for it (the slot IS the accumulated gradient).
+    sunk = []
+
+    def dest(param, shape, needed=True):
+        if not needed:
+            return None
+        sink = getattr(param, "_bf_grad_sink", None)
+        slot = sink.slot(param) if sink is not None else None
+        if slot is not None and slot.dtype == torch.float32 and slot.shape == shape and slot.device == dev:
+            sunk.append((sink, param))
+            return slot
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+
+    dmu_w = dest(layer.weight.mu, (N, K), need_mu_w)
+    drho_w = dest(layer.weight.rho, (N, K))
+    dmu_b = dest(layer.bias.mu, (N,), has_bias and need_mu_b) if has_bias else None
+    drho_b = dest(layer.bias.rho, (N,)) if has_bias else None
     lib = _C.lib()
     if act:
         if act_pre is None or act_pre.dtype != cdt or act_pre.numel() != S * M * N:
@@ -401,6 +416,15 @@ def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_
                                ws.data_ptr(), ws.numel(), _stream_ptr()), "bf_linear_bwd")
     if dx is not None and dx.dtype != x.dtype:
         dx = dx.to(x.dtype)
+    if sunk:
+        gone = {id(p) for _, p in sunk}
+        for sink, param in sunk:
+            sink.arrived(param)
+        if has_bias:
+            dmu_b = None if (dmu_b is not None and id(layer.bias.mu) in gone) else dmu_b
+            drho_b = None if id(layer.bias.rho) in gone else drho_b
+        dmu_w = None if (dmu_w is not None and id(layer.weight.mu) in gone) else dmu_w
+        drho_w = None if id(layer.weight.rho) in gone else drho_w
     return dx, dmu_w, drho_w, dmu_b, drho_b
 
 

@@ -65,10 +65,16 @@ class GradientBuckets:
             if cur:
                 self._close(cur)
         self._works = []
-        # tensor hooks (they see the gradient BEFORE it is accumulated): autograd keeps adopting the produced tensors as
-        # .grad; a post-accumulate hook made the training step 2 ms slower on its own
+        # Two ways a gradient reaches its slot.  The Bayesian layers' own backward kernels (ops.linear_backward: all of the
+        # fp32 mu / rho gradients, 342 MB of a BERT-base step) find the slot through `param._bf_grad_sink` and WRITE THERE:
+        # no copy, autograd sees None.  Every other parameter (LayerNorms, embeddings) comes through a tensor hook (which
+        # sees the gradient before it is accumulated) and is copied into its slot when its bucket closes.
         self._hooks = [p.register_hook(self._make_hook(p)) for p in self.params]
         self._got = {}
+        self._direct = set()   # parameters whose gradient was written straight into the slot this step
+        self.active = False    # between zero() and finish(): the slots are live destinations
+        for p in self.params:
+            p._bf_grad_sink = self
 
     def _close(self, ps):
         # parameters whose size keeps the next one 256-byte aligned first, the odd-sized ones (a 2-element classifier bias)
@@ -83,11 +89,28 @@ class GradientBuckets:
             off += p.numel()
         self.buckets.append([flat, ps, len(ps), False])
 
+    def slot(self, p):
+        """The standing destination of p's gradient while a step is open (None otherwise): ops.linear_backward writes it."""
+        return self._views.get(p) if self.active else None
+
+    def arrived(self, p) -> None:
+        """p's gradient has been written into its slot by the kernel that produced it."""
+        i = self._bucket_of[p]
+        if self.buckets[i][3] or p in self._got or p in self._direct:
+            raise RuntimeError("GradientBuckets: a parameter received a second gradient in one backward() (a module "
+                               "used twice?) — every trainable parameter must be used once per step")
+        self._direct.add(p)
+        self.buckets[i][2] -= 1
+        if self.buckets[i][2] == 0:
+            self._launch(i)
+
     def zero(self) -> None:
         """Start a step: gradients are None (autograd adopts the tensors backward produces, no accumulation kernels);
-        a bucket is filled by ONE torch.cat when its last gradient has arrived."""
+        a bucket goes on the wire when its last gradient has arrived."""
         self._works = []
         self._got = {}
+        self._direct = set()
+        self.active = True
         for b in self.buckets:
             b[2], b[3] = len(b[1]), False
         for p in self.params:
@@ -99,18 +122,25 @@ class GradientBuckets:
             return
         b[3] = True
         have = [p for p in b[1] if p in self._got]
-        if len(have) == len(b[1]) and all(self._got[p].dtype == b[0].dtype for p in have):
-            # the usual case: one batched copy of the bucket's gradients into its flat buffer
+        direct = [p for p in b[1] if p in self._direct]
+        if len(direct) == len(b[1]):
+            pass  # every gradient of the bucket was written in place by its kernel: nothing to copy
+        elif len(have) == len(b[1]) and all(self._got[p].dtype == b[0].dtype for p in have):
+            # one batched copy of the bucket's gradients into its flat buffer
             torch.cat([self._got[p].reshape(-1) for p in b[1]], out=b[0])
         else:
-            b[0].zero_()  # some parameter of the bucket got no gradient this step: its slot must read zero
-            for p in have:
-                self._views[p].copy_(self._got[p])
+            missing = [p for p in b[1] if p not in self._got and p not in self._direct]
+            for p in missing:  # no gradient this step: the slot must read zero
+                self._views[p].zero_()
+            if have:
+                torch._foreach_copy_([self._views[p] for p in have], [self._got[p] for p in have])
         if self.distributed:
             self._works.append(dist.all_reduce(b[0], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _make_hook(self, p):
         def hook(grad):
+            if grad is None or p in self._direct:
+                return None  # written in place by its kernel (ops.linear_backward): autograd was handed no gradient
             i = self._bucket_of[p]
             if self.buckets[i][3] or p in self._got:
                 raise RuntimeError("GradientBuckets: a parameter received a second gradient in one backward() (a module "
@@ -130,6 +160,8 @@ class GradientBuckets:
             w.wait()
         self._works = []
         self._got = {}
+        self._direct = set()
+        self.active = False
         for p in self.params:  # the optimizer (and the clipping) read the reduced gradients from the flat buffers
             p.grad = self._views[p]
 
@@ -140,6 +172,10 @@ class GradientBuckets:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        self.active = False
+        for p in self.params:
+            if getattr(p, "_bf_grad_sink", None) is self:
+                del p._bf_grad_sink
 
 
 def grad_norm(tensors: List[Tensor]) -> Tensor:

@@ -5,6 +5,7 @@ all-reduced means, the all-gathered per-sample outputs, and — for the training
 and the updated parameters must equal the single-process run's."""
 import os
 import socket
+import time
 
 import numpy as np
 import pytest
@@ -79,7 +80,16 @@ def test_two_ranks_on_one_gpu_match_single_process():
     procs = [ctx.Process(target=_worker, args=(r, world, port, S, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=500) for _ in procs], key=lambda r: r[0])
+    res = []
+    deadline = time.monotonic() + 500
+    while len(res) < len(procs):  # a rank that died must fail the test at once, not after the timeout
+        try:
+            res.append(q.get(timeout=2))
+        except Exception:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"a rank exited with {dead}"
+            assert time.monotonic() < deadline, "timed out"
+    res = sorted(res, key=lambda r: r[0])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0

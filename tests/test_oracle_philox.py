@@ -82,3 +82,48 @@ def test_dropout_host_twin_matches_the_oracle_restatement():
     # different call / site / seed -> different masks
     a = bo.dropout_keep(0, 512, 0.1, 1, 0, 1)
     assert not np.array_equal(a, bo.dropout_keep(0, 512, 0.1, 1, 1, 1)) and not np.array_equal(a, bo.dropout_keep(0, 512, 0.1, 1, 0, 2))
+
+
+@pytest.mark.parametrize("rounds", [7, 10])
+def test_contract_header_builds_with_either_round_count(tmp_path, rounds):
+    """csrc/bf_philox.h is the epsilon contract shared by host and device code.  Its round count is a build option
+    (-DBF_PHILOX_ROUNDS): the shipped 7 and Random123's default 10 both reproduce the Random123 known-answer vectors from
+    the header's own block function, and the host normal generator agrees with the oracle at that round count."""
+    import os
+    import shutil
+    import subprocess
+
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "kat.cpp"
+    src.write_text("""
+#include <stdio.h>
+#include <stdlib.h>
+#include "bf_philox.h"
+int main(int argc, char** argv) {
+    uint32_t v[6];
+    for (int i = 0; i < 6; ++i) v[i] = (uint32_t)strtoul(argv[1 + i], 0, 16);
+    const bf_u32x4 o = bf_philox4x32(v[0], v[1], v[2], v[3], v[4], v[5]);
+    printf("%08x %08x %08x %08x\\n", o.x, o.y, o.z, o.w);
+    float z[4];
+    bf_normal4_host(5, 3, 2, 0x5EEDull, z);
+    printf("%.9g %.9g %.9g %.9g\\n", z[0], z[1], z[2], z[3]);
+    return 0;
+}
+""")
+    exe = tmp_path / "kat"
+    subprocess.run([gxx, "-O1", f"-DBF_PHILOX_ROUNDS={rounds}", "-I", os.path.join(root, "bayeformers_amd", "csrc"), str(src),
+                    "-o", str(exe), "-lm"], check=True)
+    for ctr, key, want in KAT[rounds]:
+        out = subprocess.run([str(exe)] + [f"{w:x}" for w in list(ctr) + list(key)], check=True, capture_output=True, text=True)
+        lines = out.stdout.splitlines()
+        assert [int(w, 16) for w in lines[0].split()] == want
+    # the header's host normals (group 5, sample 3, stream 2) vs the oracle's block function at the same round count
+    x = bo.philox4x32([5, 3, 2, 0], [0x5EED, 0], rounds=rounds).astype(np.uint64)
+    u = (x.astype(np.float32) * np.float32(2.0 ** -32) + np.float32(2.0 ** -33)).astype(np.float64)
+    r0, r1 = np.sqrt(-2 * np.log(u[0])), np.sqrt(-2 * np.log(u[2]))
+    want_z = [r0 * np.cos(2 * np.pi * u[1]), r0 * np.sin(2 * np.pi * u[1]), r1 * np.cos(2 * np.pi * u[3]), r1 * np.sin(2 * np.pi * u[3])]
+    got_z = [float(v) for v in lines[1].split()]
+    np.testing.assert_allclose(got_z, want_z, rtol=2e-6, atol=2e-7)

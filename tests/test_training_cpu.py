@@ -193,3 +193,46 @@ def test_clipping_factor_does_not_outlive_its_step():
     opt.step()
     for a, p in zip(after, model.parameters()):
         np.testing.assert_allclose(a.numpy(), p.detach().numpy(), rtol=1e-6, atol=1e-8)
+
+
+def test_gradient_written_in_place_by_its_producer_needs_no_copy():
+    """The Bayesian layers' backward kernels write their parameter gradients straight into the bucket slot
+    (ops.linear_backward: `param._bf_grad_sink`) and hand autograd None.  Same protocol here with a stand-in autograd
+    function: the slot holds the gradient, the bucket closes when the in-place and the hooked gradients have all arrived,
+    the hook that autograd may still fire with None is ignored, and nothing is written outside a step."""
+    class InPlace(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            ctx.w = w
+            return x @ w
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            sink = getattr(ctx.w, "_bf_grad_sink", None)
+            slot = sink.slot(ctx.w) if sink is not None else None
+            if slot is not None:
+                torch.matmul(x.t(), g, out=slot)
+                sink.arrived(ctx.w)
+                return g @ w.t(), None
+            return g @ w.t(), x.t() @ g
+
+    torch.manual_seed(5)
+    w = torch.nn.Parameter(torch.randn(4, 3))
+    b = torch.nn.Parameter(torch.randn(3))
+    x = torch.randn(6, 4)
+    buckets = GradientBuckets([w, b], bucket_bytes=1 << 20)  # one bucket holding both
+    assert buckets.slot(w) is None  # no step open: the producer must take the ordinary path
+    (InPlace.apply(x, w) + b).sum().backward()
+    ref_w, ref_b = w.grad.clone(), b.grad.clone()
+    for _ in range(2):  # two steps: the state of the first must not leak into the second
+        buckets.zero()
+        assert buckets.slot(w) is buckets._views[w]
+        (InPlace.apply(x, w) + b).sum().backward()
+        buckets.finish()
+        assert w.grad.data_ptr() == buckets._views[w].data_ptr() and b.grad.data_ptr() == buckets._views[b].data_ptr()
+        np.testing.assert_allclose(w.grad.numpy(), ref_w.numpy(), rtol=1e-6)
+        np.testing.assert_allclose(b.grad.numpy(), ref_b.numpy(), rtol=1e-6)
+    buckets.remove()
+    assert not hasattr(w, "_bf_grad_sink")
