@@ -30,21 +30,47 @@ _BUCKETS_OF: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()  # optimi
 
 
 class GradientBuckets:
-    """Flat gradient buffers over the trainable parameters of a model, summed over the ranks of `group` while backward
-    runs.  `zero()` before the forward, `finish()` after `backward()`; the parameters' `.grad` are views of the buffers
-    (the optimizer updates from them directly).  Buckets hold one dtype each (the fp32 mu / rho masters apart from a
-    16-bit model's embeddings and LayerNorms); the slots are packed, odd-sized parameters last, so that all but those
-    start on a 256-byte boundary and the multi-tensor optimizer kernels keep their vectorised path.  What it costs: one
-    torch.cat per bucket (the gradients backward produced -> their slots), i.e. one extra read and write of the gradients per
-    step — use it where there is something to all-reduce (world > 1)."""
+    """Flat gradient buffers over the parameters of a model THAT RECEIVE A GRADIENT, summed over the ranks of `group` while
+    backward runs.  `zero()` before the forward, `finish()` after `backward()`; afterwards the parameters' `.grad` are
+    views of the buffers (the optimizer updates from them directly).
+
+    Which parameters: `requires_grad` says too much — the Gaussian priors of a converted model are nn.Parameters like the
+    reference's (/root/reference/bayeformers/nn/parameters/gaussian.py:51-52), and no gradient ever reaches them (the
+    log-probs are detached, layers/linear.py:99-102); the reference's optimizer skips them because their .grad stays None.
+    So the buckets are laid out after the FIRST step, over what that step's backward actually produced (the first step
+    itself runs on buckets over everything; the rest keep .grad = None, exactly as without buckets).  Measured on BERT-base:
+    with the priors inside, every step zero-filled 370 slots, all-reduced 1 GB instead of 0.39 GB and ran the fused AdamW
+    over three times the elements — the whole +2.4 ms the bucket path used to cost (profiles/r4g_*).
+
+    How a gradient reaches its slot: the Bayesian layers' own backward kernels (ops.linear_backward: all fp32 mu / rho
+    gradients, 342 MB of a BERT-base step) find it through `param._bf_grad_sink` and WRITE THERE — no copy, autograd is
+    handed None.  Any other parameter (LayerNorms, embeddings) comes through a tensor hook that copies it into the slot at
+    once (autograd keeps adopting the produced tensor as .grad until finish() points .grad at the slot).  A bucket goes on
+    the wire, asynchronously, when its last gradient has arrived, i.e. under the remaining backward GEMMs.  Buckets hold one
+    dtype each; slots are packed, odd-sized parameters last, so that all but those start on a 256-byte boundary."""
 
     ALIGN = 256  # bytes
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional["dist.ProcessGroup"] = None,
                  bucket_bytes: int = 128 << 20):
         self.group = group
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        self.bucket_bytes = bucket_bytes
+        self.candidates: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self._works = []
+        self._arrived = set()   # parameters whose gradient is in its slot this step
+        self.active = False     # between zero() and finish(): the slots are live destinations
+        self._settled = False   # True once the layout covers exactly the parameters that receive gradients
+        self._relayout = None   # parameter list to lay out at the next zero()
+        self._hooks = {p: p.register_hook(self._make_hook(p)) for p in self.candidates}
+        self._layout(self.candidates)
+
+    # ------------------------------------------------------------------------------------------------ layout
+    def _layout(self, params) -> None:
+        for p in getattr(self, "params", []):
+            if getattr(p, "_bf_grad_sink", None) is self:
+                del p._bf_grad_sink
+        self.params = list(params)
         self.buckets = []   # [flat tensor, [params], pending count, launched]
         self._bucket_of = {}
         self._views = {}
@@ -57,28 +83,19 @@ class GradientBuckets:
             cur, cur_bytes = [], 0
             for p in ps:
                 nb = p.numel() * p.element_size()
-                if cur and cur_bytes + nb > bucket_bytes:
+                if cur and cur_bytes + nb > self.bucket_bytes:
                     self._close(cur)
                     cur, cur_bytes = [], 0
                 cur.append(p)
                 cur_bytes += nb
             if cur:
                 self._close(cur)
-        self._works = []
-        # Two ways a gradient reaches its slot.  The Bayesian layers' own backward kernels (ops.linear_backward: all of the
-        # fp32 mu / rho gradients, 342 MB of a BERT-base step) find the slot through `param._bf_grad_sink` and WRITE THERE:
-        # no copy, autograd sees None.  Every other parameter (LayerNorms, embeddings) comes through a tensor hook (which
-        # sees the gradient before it is accumulated) and is copied into its slot when its bucket closes.
-        self._hooks = [p.register_hook(self._make_hook(p)) for p in self.params]
-        self._got = {}
-        self._direct = set()   # parameters whose gradient was written straight into the slot this step
-        self.active = False    # between zero() and finish(): the slots are live destinations
         for p in self.params:
             p._bf_grad_sink = self
 
     def _close(self, ps):
         # parameters whose size keeps the next one 256-byte aligned first, the odd-sized ones (a 2-element classifier bias)
-        # last: the slots are packed without padding, so that ONE torch.cat fills a bucket
+        # last: the slots are packed without padding
         q = self.ALIGN // ps[0].element_size()
         ps = [p for p in ps if p.numel() % q == 0] + [p for p in ps if p.numel() % q != 0]
         flat = torch.zeros(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
@@ -89,89 +106,87 @@ class GradientBuckets:
             off += p.numel()
         self.buckets.append([flat, ps, len(ps), False])
 
+    # ------------------------------------------------------------------------------------------------ one step
+    def zero(self) -> None:
+        """Start a step: gradients are None (autograd adopts the tensors backward produces, no accumulation kernels)."""
+        if self._relayout is not None:
+            self._layout(self._relayout)
+            self._relayout, self._settled = None, True
+        self._works = []
+        self._arrived = set()
+        self.active = True
+        for b in self.buckets:
+            b[2], b[3] = len(b[1]), False
+        for p in self.candidates:
+            p.grad = None
+
     def slot(self, p):
         """The standing destination of p's gradient while a step is open (None otherwise): ops.linear_backward writes it."""
         return self._views.get(p) if self.active else None
 
     def arrived(self, p) -> None:
-        """p's gradient has been written into its slot by the kernel that produced it."""
+        """p's gradient is in its slot (written there by the kernel that produced it, or copied by the hook)."""
         i = self._bucket_of[p]
-        if self.buckets[i][3] or p in self._got or p in self._direct:
+        if self.buckets[i][3] or p in self._arrived:
             raise RuntimeError("GradientBuckets: a parameter received a second gradient in one backward() (a module "
                                "used twice?) — every trainable parameter must be used once per step")
-        self._direct.add(p)
+        self._arrived.add(p)
         self.buckets[i][2] -= 1
         if self.buckets[i][2] == 0:
             self._launch(i)
 
-    def zero(self) -> None:
-        """Start a step: gradients are None (autograd adopts the tensors backward produces, no accumulation kernels);
-        a bucket goes on the wire when its last gradient has arrived."""
-        self._works = []
-        self._got = {}
-        self._direct = set()
-        self.active = True
-        for b in self.buckets:
-            b[2], b[3] = len(b[1]), False
-        for p in self.params:
-            p.grad = None
+    def _make_hook(self, p):
+        def hook(grad):
+            if grad is None or not self.active or p in self._arrived:
+                return None  # (a gradient its kernel wrote in place reaches autograd as None)
+            view = self._views.get(p)
+            if view is None:
+                raise RuntimeError("GradientBuckets: a parameter that had no gradient in the first step received one now; "
+                                   "build new GradientBuckets for the changed model")
+            view.copy_(grad)  # straight into the slot: no reference kept, autograd still adopts `grad` without a clone
+            self.arrived(p)
+            return None
+        return hook
 
     def _launch(self, i: int) -> None:
         b = self.buckets[i]
         if b[3]:
             return
         b[3] = True
-        have = [p for p in b[1] if p in self._got]
-        direct = [p for p in b[1] if p in self._direct]
-        if len(direct) == len(b[1]):
-            pass  # every gradient of the bucket was written in place by its kernel: nothing to copy
-        elif len(have) == len(b[1]) and all(self._got[p].dtype == b[0].dtype for p in have):
-            # one batched copy of the bucket's gradients into its flat buffer
-            torch.cat([self._got[p].reshape(-1) for p in b[1]], out=b[0])
-        else:
-            missing = [p for p in b[1] if p not in self._got and p not in self._direct]
-            for p in missing:  # no gradient this step: the slot must read zero
+        for p in b[1]:
+            if p not in self._arrived:  # no gradient this step: the slot must read zero on the wire
                 self._views[p].zero_()
-            if have:
-                torch._foreach_copy_([self._views[p] for p in have], [self._got[p] for p in have])
         if self.distributed:
             self._works.append(dist.all_reduce(b[0], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def _make_hook(self, p):
-        def hook(grad):
-            if grad is None or p in self._direct:
-                return None  # written in place by its kernel (ops.linear_backward): autograd was handed no gradient
-            i = self._bucket_of[p]
-            if self.buckets[i][3] or p in self._got:
-                raise RuntimeError("GradientBuckets: a parameter received a second gradient in one backward() (a module "
-                                   "used twice?) — every trainable parameter must be used once per step")
-            self._got[p] = grad
-            self.buckets[i][2] -= 1
-            if self.buckets[i][2] == 0:
-                self._launch(i)
-            return None
-        return hook
-
     def finish(self) -> None:
-        """After backward(): send what has not been sent (parameters without a gradient this step) and wait."""
+        """After backward(): send what has not been sent (buckets holding a parameter without a gradient this step), wait,
+        and point .grad at the slots.  After the first step the layout shrinks to the parameters that got a gradient."""
         for i in range(len(self.buckets)):
             self._launch(i)
         for w in self._works:
             w.wait()
         self._works = []
-        self._got = {}
-        self._direct = set()
         self.active = False
-        for p in self.params:  # the optimizer (and the clipping) read the reduced gradients from the flat buffers
-            p.grad = self._views[p]
+        got = self._arrived
+        for p in self.params:
+            # the reduced gradient; a parameter no gradient reached keeps .grad = None (the optimizer skips it, as it
+            # does without buckets) until the layout drops it
+            p.grad = self._views[p] if (self._settled or p in got) else None
+        if not self._settled:
+            if len(got) < len(self.params):
+                self._relayout = [p for p in self.params if p in got]
+            else:
+                self._settled = True
+        self._arrived = set()
 
     def flats(self) -> List[Tensor]:
         return [b[0] for b in self.buckets]
 
     def remove(self) -> None:
-        for h in self._hooks:
+        for h in self._hooks.values():
             h.remove()
-        self._hooks = []
+        self._hooks = {}
         self.active = False
         for p in self.params:
             if getattr(p, "_bf_grad_sink", None) is self:

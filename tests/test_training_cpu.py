@@ -236,3 +236,28 @@ def test_gradient_written_in_place_by_its_producer_needs_no_copy():
         np.testing.assert_allclose(b.grad.numpy(), ref_b.numpy(), rtol=1e-6)
     buckets.remove()
     assert not hasattr(w, "_bf_grad_sink")
+
+
+def test_buckets_settle_on_the_parameters_that_receive_gradients():
+    """requires_grad says too much: the Gaussian priors of a converted model are Parameters no gradient ever reaches (the
+    reference's optimizer skips them because .grad stays None).  After the first step the buckets cover only what backward
+    produced; the others keep .grad = None and are neither zero-filled, nor sent, nor stepped."""
+    torch.manual_seed(3)
+    w = torch.nn.Parameter(torch.randn(8, 4))
+    prior = torch.nn.Parameter(torch.randn(8, 4))     # never in the graph
+    b = torch.nn.Parameter(torch.randn(4))
+    buckets = GradientBuckets([w, prior, b], bucket_bytes=1 << 20)
+    assert buckets.flats()[0].numel() == 32 + 32 + 4
+    for step in range(3):
+        buckets.zero()
+        (torch.ones(2, 8) @ w + b).sum().backward()
+        buckets.finish()
+        assert prior.grad is None
+        assert w.grad.data_ptr() == buckets._views[w].data_ptr() and float(w.grad.sum()) == 2.0 * 32
+        if step >= 1:
+            assert {id(p) for p in buckets.params} == {id(w), id(b)}
+            assert sum(f.numel() for f in buckets.flats()) == 32 + 4
+    # a parameter that joins the graph later is reported, not silently left out of the reduction
+    buckets.zero()
+    with pytest.raises(RuntimeError, match="had no gradient in the first step"):
+        (torch.ones(2, 8) @ (w + prior) + b).sum().backward()
