@@ -866,7 +866,7 @@ int bf_launch_gemm256(const GemmParams& p0, int w_dtype, int y_dtype, hipStream_
     const char* fe = getenv("BF_GEMM_NT_FORM");
     if (fe) form = atoi(fe);
 #endif
-    if (form && bf_gemm256_r5_supported(p, w_dtype, y_dtype)) return bf_launch_gemm256_r5(p, w_dtype, stream, sc.grid);
+    if (form && bf_gemm256_r5_supported(p, w_dtype, y_dtype)) return bf_launch_gemm256_r5(p, w_dtype, stream, sc.grid, form != 2);  // developer builds: form 2 = the LDS-staged epilogue
     if (w_dtype == BF_DT_BF16) return launch256<__bf16>(p, y_dtype, stream, sc.grid);
     return launch256<_Float16>(p, y_dtype, stream, sc.grid);
 }

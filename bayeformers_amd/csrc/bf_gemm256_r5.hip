@@ -37,8 +37,18 @@ constexpr int NSLOT = 5;
 // (on the DMA source address) and whose fragments come out through ds_read_b64_tr_b16, exactly as in bf_gemm256.hip.
 // SEG: the contraction runs over p.segs segments of K (x: [segs][S][M][K], w: [segs][S][K][N]) — the one input gradient
 // of the stacked query / key / value layers.
-template <typename T, typename YT, bool TRW = false, bool SEG = false>
+// DPPE (forward form, 16-bit outputs, N % 8 == 0; DEVELOPER builds only — a measured dead end, see below): W fragment
+// rows permuted so that the epilogue runs in registers (epilogue_dpp in bf_gemm256_dev.h) instead of through LDS.
+// Bit-identical outputs, no LDS traffic in the epilogue — and 7 % (K = 4096) to 18 % (K = 768) slower per launch: a store
+// instruction still writes 8 full 128-byte lines, but a QUAD of consecutive lanes now holds 2 rows x 32 B instead of 64
+// contiguous bytes, and the vector memory pipe coalesces per quad — +6-8 us per tile.  Getting 64 contiguous bytes into a
+// quad needs the chunk index in lane bits 1:0, i.e. two more exchange stages (v_permlane16_swap + DPP + selects, ~28 VALU
+// per block) — about what the LDS round trip costs.  Not pursued.  The W units then use their own 16-byte-chunk swizzle,
+// chunk ^= ((row >> 1) & 1) | (((row >> 4) & 3) << 1): a fragment read touches rows {16 a + b + 4 i} (a, b = 0..3), whose
+// swizzle under the x units' (row >> 1) & 7 would take two values only.
+template <typename T, typename YT, bool TRW = false, bool SEG = false, bool DPPE = false>
 __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams p) {
+    static_assert(!DPPE || (!TRW && sizeof(YT) == 2), "the register epilogue belongs to the forward form");
     using frag = typename Mfma16<T>::frag;
 
     __shared__ __attribute__((aligned(1024))) char smem[NSLOT * SLOT_BYTES];
@@ -84,6 +94,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         } else {
             int prow, kc8;
             piece_lane(prow, kc8);
+            if constexpr (DPPE) {  // W units: chunk ^= ((row >> 1) & 1) | (((row >> 4) & 3) << 1), row = 64 i + 8 wid + prow
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                kc8 = ((ln & 7) ^ (((ln >> 4) & 1) | ((wid >> 1) << 1))) * 8;
+            }
             wo = ((unsigned)(n0 + wid * 8 + prow) * (unsigned)K + kc8) * 2u;
             w_bytes = (unsigned)N * (unsigned)K * 2u;
         }
@@ -148,7 +163,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     const unsigned foff0 = (lane & 15) * ROW_BYTES + ((((lane >> 4)) ^ fsw) << 4);
     const unsigned foff1 = (lane & 15) * ROW_BYTES + (((4 + (lane >> 4)) ^ fsw) << 4);
     const unsigned xrow0 = lds0 + wm * 16 * ROW_BYTES;  // + j * 32 rows: wave group wm owns blocks wm, wm + 2, ...
-    const unsigned wrow0 = lds0 + wn * 64 * ROW_BYTES;  // + i * 16 rows
+    const unsigned wrow0 = lds0 + wn * 64 * ROW_BYTES;  // + i * 16 rows (DPPE: + i * 4 rows, permuted fragment rows)
+    // DPPE: fragment row li of block i is W row 16 (li >> 2) + 4 i + (li & 3) of the wave's 64; its swizzle depends on li only
+    const int wsw = ((lane >> 1) & 1) | (((lane >> 2) & 3) << 1);
+    const unsigned wperm = (16 * ((lane & 15) >> 2) + (lane & 3)) * ROW_BYTES;
+    const unsigned wfoff0 = DPPE ? wperm + ((((lane >> 4)) ^ wsw) << 4) : foff0;
+    const unsigned wfoff1 = DPPE ? wperm + (((4 + (lane >> 4)) ^ wsw) << 4) : foff1;
     auto lds_read = [&](unsigned a, auto off) -> frag {
         frag v;
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(decltype(off)::value));
@@ -220,9 +240,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) wf[i] = tr_read(aw, i, half);
                 } else {
-                    const unsigned aw = wrow0 + slot_w * SLOT_BYTES + (HF ? foff1 : foff0);
+                    const unsigned aw = wrow0 + slot_w * SLOT_BYTES + (HF ? wfoff1 : wfoff0);
                     static_for<0, 4>([&](auto ic) {
-                        wf[decltype(ic)::value] = lds_read(aw, std::integral_constant<int, decltype(ic)::value * 16 * ROW_BYTES>{});
+                        wf[decltype(ic)::value] = lds_read(aw, std::integral_constant<int, decltype(ic)::value * (DPPE ? 4 : 16) * ROW_BYTES>{});
                     });
                 }
                 static_for<0, H>([&](auto jc) {
@@ -300,6 +320,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
             };
 
             if (wm == 1) __builtin_amdgcn_s_barrier();  // G1 runs one slot behind G0
+            if constexpr (DPPE) init_acc_perm<H>(acc, p.bias ? p.bias + (long long)s * N : nullptr, n0, N, wn, lane);
+            else
 #ifdef BF_DEV
             init_acc<H>(acc, (p.bias && !(p.flags & 2)) ? p.bias + (long long)s * N : nullptr, n0, N, wn, lane);
 #else
@@ -328,7 +350,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
             if (p.flags & 16) m_end = 0;  // ablation: no global stores
             if (p.flags & 8) return;      // ablation: no epilogue
 #endif
-            epilogue_wave<YT, H>(scratch, acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act);
+            if constexpr (DPPE) epilogue_dpp<YT, H>(acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act);
+            else epilogue_wave<YT, H>(scratch, acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act);
         };
         switch (h) {
             case 8: body(std::integral_constant<int, 8>{}); break;
@@ -348,9 +371,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     }
 }
 
-template <typename T, typename YT, bool TRW, bool SEG>
+template <typename T, typename YT, bool TRW, bool SEG, bool DPPE = false>
 int launch_r5(const GemmParams& p, hipStream_t stream, int grid) {
-    hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, TRW, SEG>), dim3(grid), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, TRW, SEG, DPPE>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -366,8 +389,19 @@ bool bf_gemm256_r5_supported(const GemmParams& p, int w_dtype, int y_dtype) {
     return true;
 }
 
-int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, int grid) {
+int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, int grid, bool reg_epilogue) {
     if (p.segs > 1) BF_FAIL("bf_gemm256_r5: the forward form has no segments");
+#ifdef BF_DEV
+    // developer builds (BF_GEMM_NT_FORM=3): the register epilogue — measured 7-18 % SLOWER than the LDS-staged one
+    // (profiles/r4i_register_epilogue_ab.txt), so the product library does not instantiate it.  It stores whole 16-byte
+    // chunks: N a multiple of 8, 16-byte aligned outputs and fp32 bias rows.
+    if (reg_epilogue && p.N % 8 == 0 && (((uintptr_t)p.y | (uintptr_t)p.y2 | (uintptr_t)p.bias) & 15) == 0) {
+        if (w_dtype == BF_DT_BF16) return launch_r5<__bf16, __bf16, false, false, true>(p, stream, grid);
+        return launch_r5<_Float16, _Float16, false, false, true>(p, stream, grid);
+    }
+#else
+    (void)reg_epilogue;
+#endif
     if (w_dtype == BF_DT_BF16) return launch_r5<__bf16, __bf16, false, false>(p, stream, grid);
     return launch_r5<_Float16, _Float16, false, false>(p, stream, grid);
 }
