@@ -223,9 +223,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
         }
         auto go = [&](auto tr, long long ld) {
             if constexpr (decltype(tr)::value) {
-                const T* rowp = b + (long long)(kt * TK + half * 32) * ld;
+                // contraction-major unit: pieces through a buffer descriptor over the sample's operand — 32-bit per-lane byte
+                // offset + a scalar row offset, no 64-bit vector address arithmetic per piece (what the forward ring kernel
+                // gained 3-5 % from at K = 768, bf_gemm256_r5.hip).  A sample's operand is < 2^31 bytes (host check).
+                const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(b), 0, 0x7FFFFFFF, 0x00020000);
+                const int row0 = kt * TK + half * 32;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) glds16(rowp + (long long)(i * 8) * ld + t.xo[i], dst + i * 4096);
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(dst + i * 4096), 16, (int)(t.xo[i] * 2u),
+                                                             (int)((row0 + i * 8) * ld) * 2, 0, 0);
             } else {
                 const T* colp = b + kt * TK + half * 32;
 #pragma unroll
@@ -878,7 +884,8 @@ bool bf_gemm256_tn_supported(int dtype, int batch, int Mc, int Nl, int Kl, const
     if (dtype != BF_DT_BF16 && dtype != BF_DT_F16) return false;
     if (batch < 1 || batch > 65535 || Mc < TK || Mc % TK || Nl < 8 || Nl % 8 || Kl < 8 || Kl % 8) return false;
     if (((uintptr_t)d_a | (uintptr_t)d_b | (uintptr_t)d_out) & 15) return false;
-    if ((long long)Mc * Nl >= (1ll << 32) || (long long)Mc * Kl >= (1ll << 32) || (long long)Nl * Kl >= (1ll << 31)) return false;
+    // (a sample's operand is addressed by 32-bit byte offsets through a buffer descriptor: < 2^30 elements)
+    if ((long long)Mc * Nl >= (1ll << 30) || (long long)Mc * Kl >= (1ll << 30) || (long long)Nl * Kl >= (1ll << 31)) return false;
     if (Nl >= (1 << 24) || (Kl + TN - 1) / TN >= (1 << 24)) return false;
     return true;
 }
