@@ -131,7 +131,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     };
     // this wave's pieces of unit X(kt) / W(kt) into ring slot `slot`; only the 4 h pieces of the tile's rows of x are
     // fetched (h4 = 4 h: an integral_constant inside a tile's k-loop, so a full-height tile issues without branches)
-    auto issue_x = [&](int kt, int slot, auto h4) {
+#ifndef BF_R5_SPLIT
+#define BF_R5_SPLIT 0  // experiment: pieces 2, 3 of a unit are issued at the END of the MFMA slot that follows its L slot
+// (behind the wave's last MFMA, where it would otherwise park at the barrier).  Measured in the BERT-base step, one box, three
+// interleaved runs each (profiles/r4l_split_dma_issue_ab.txt): roofline.frac 0.421-0.425 -> 0.399-0.404, i.e. 5 % SLOWER —
+// a piece costs the issuing wave as much behind its MFMAs as beside its fragment reads, and it lands a slot later.
+#endif
+    auto issue_x = [&](int kt, int slot, auto h4, int lo = 0, int hi = 4) {
 #ifdef BF_DEV
         if (p.flags & 64) kt = 0;  // ablation: every k-step re-reads k-step 0 (operands L2-hot)
 #endif
@@ -140,9 +146,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         const T* xs = SEG ? xb + (long long)seg * p.x_seg_stride : xb;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i * 8 + 7 < h4 || i * 8 + wid < h4) piece(xs, x_bytes, xo + i * rowblk, kt * (TK * 2), base + i * 8192);
+            if (i >= lo && i < hi && (i * 8 + 7 < h4 || i * 8 + wid < h4)) piece(xs, x_bytes, xo + i * rowblk, kt * (TK * 2), base + i * 8192);
     };
-    auto issue_w = [&](int kt, int slot) {
+    auto issue_w = [&](int kt, int slot, int lo = 0, int hi = 4) {
 #ifdef BF_DEV
         if (p.flags & 64) kt = 0;
 #endif
@@ -151,6 +157,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         const T* ws = SEG ? wb + (long long)seg * p.w_seg_stride : wb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (i < lo || i >= hi) continue;
             if constexpr (TRW) piece(ws, w_bytes, wo, (kt * TK + i * 16) * N * 2, base + i * 8192);
             else piece(ws, w_bytes, wo + i * rowblk, kt * (TK * 2), base + i * 8192);
         }
@@ -273,20 +280,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                 if (ax >= NSLOT) ax -= NSLOT;
                 if (a3 >= NSLOT) a3 -= NSLOT;
                 if (a4 >= NSLOT) a4 -= NSLOT;
-                auto dma0 = [&] {
+                auto dma0 = [&](int lo = 0, int hi = 4) {
                     if constexpr (MODE == 2) {
-                        if (has_next) issue_x(0, a3, 4 * h2);
+                        if (has_next) issue_x(0, a3, 4 * h2, lo, hi);
                     } else {
-                        issue_x(kt + 1, a3, std::integral_constant<int, 4 * H>{});
+                        issue_x(kt + 1, a3, std::integral_constant<int, 4 * H>{}, lo, hi);
                     }
+                };
+                auto dma1 = [&](int lo = 0, int hi = 4) {
+                    if constexpr (MODE == 0) issue_w(kt + 2, a4, lo, hi);
+                    else if (has_next) issue_w(MODE == 1 ? 0 : 1, a4, lo, hi);
                 };
                 auto wait_all_but_newest = [&] {
 #ifdef BF_DEV
                     // ablation (WRONG results): the first two k-steps of a tile do not wait for the previous tile's stores
                     if ((p.flags & 32) && MODE == 0 && kt < 2) { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); return; }
 #endif
-                    if (MODE == 0 || has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (MODE == 0 || has_next) {
+                        // (split issue: group 1 waits in its L1 with only the first two pieces of the newest unit out)
+                        if (BF_R5_SPLIT && wm == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 };
 #ifdef BF_DEV
                 // experiment (flags bit 12): one barrier per k-step from the tile's second k-step on — the one that carries
@@ -296,20 +310,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
 #else
                 constexpr bool relaxed = false, lock = true;
 #endif
-                dma0();
+                dma0(0, BF_R5_SPLIT ? 2 : 4);
                 read_frags(a, ax, std::integral_constant<int, 0>{});
                 __builtin_amdgcn_sched_barrier(0);
                 if (lock) __builtin_amdgcn_s_barrier();
                 mfmas();
+                if (BF_R5_SPLIT) dma0(2, 4);
                 __builtin_amdgcn_sched_barrier(0);
                 if (lock) __builtin_amdgcn_s_barrier();
-                if constexpr (MODE == 0) issue_w(kt + 2, a4);
-                else if (has_next) issue_w(MODE == 1 ? 0 : 1, a4);
+                dma1(0, BF_R5_SPLIT ? 2 : 4);
                 read_frags(a, ax, std::integral_constant<int, 1>{});
                 if (wm == 1) wait_all_but_newest();
                 __builtin_amdgcn_sched_barrier(0);
                 if (lock || wm == 1) __builtin_amdgcn_s_barrier();
                 mfmas();
+                if (BF_R5_SPLIT) dma1(2, 4);
                 if (wm == 0) wait_all_but_newest();
                 __builtin_amdgcn_sched_barrier(0);
                 // (group 1 does not meet group 0 again before the tile-end barrier: its last slot ends without one, which

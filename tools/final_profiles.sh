@@ -12,6 +12,8 @@ python bench.py > $OUT/bench_bert_base_default.json 2> $OUT/bench_bert_base_defa
 for w in bert_large_qa bert_base_train linear768 linear768_m32 mlp; do
     python bench.py --workload $w --no-traffic > $OUT/bench_$w.json 2> /dev/null
 done
+python bench.py --workload bert_base_train --no-dropout --no-traffic > $OUT/bench_bert_base_train_no_dropout.json 2> /dev/null
+python bench.py --dtype fp32 --steps 5 --warmup 2 --no-traffic --no-cpu-baseline > $OUT/bench_bert_base_fp32.json 2> /dev/null
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bert -- python3 bench.py --steps 10 --warmup 3 --no-traffic --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> /dev/null
 python tools/rocprof_positions.py $OUT/prof/bert_kernel_trace.csv "Sources at commit $HASH (binaries built from it by python -m bayeformers_amd.build); command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-traffic --no-cpu-baseline; the bench line of this profiled run: bench_under_rocprof.json (profiled runs clock 2-3 % lower than unprofiled ones)." > $OUT/bert_base_final.md
