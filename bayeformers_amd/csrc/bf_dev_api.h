@@ -2,7 +2,7 @@
  * libbayeformers_amd_dev.so, -DBF_DEV): measured alternatives that nothing dispatches to.  Same conventions as
  * include/bayeformers_amd.h. */
 #pragma once
-#include "bayeformers_amd.h"
+#include "../../include/bayeformers_amd.h"
 
 #ifdef __cplusplus
 extern "C" {

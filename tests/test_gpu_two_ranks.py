@@ -59,25 +59,39 @@ def _run(S, steps):
     return fwd, float(loss), grads, after
 
 
-def _worker(rank, world, port, S, steps, q):
+def _worker(rank, world, port, S, steps, q, rccl=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    if rccl:  # one rank per GPU, the process group bench.py builds
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         q.put((rank,) + _run(S, steps))
     finally:
         dist.destroy_process_group()
 
 
+def _gpus_visible() -> int:
+    # (device_count does not initialise the HIP runtime in the parent; the ranks are spawned processes)
+    return torch.cuda.device_count()
+
+
 @pytest.mark.timeout(600)
-def test_two_ranks_on_one_gpu_match_single_process():
+@pytest.mark.parametrize("rccl", [False, pytest.param(True, marks=pytest.mark.skipif(
+    _gpus_visible() < 2, reason="RCCL wants one GPU per rank: needs at least two visible GPUs"))])
+def test_two_ranks_on_one_gpu_match_single_process(rccl):
+    """rccl=False: both ranks share GPU 0 over gloo (runs on the one-GPU test box).  rccl=True: one rank per GPU over RCCL —
+    the transport `bench.py --gpus N` and a real N-GPU training job use; skipped where fewer than two GPUs are visible."""
     S, steps, world = 5, 2, 2  # uneven shards: 3 + 2 samples
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, S, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, S, steps, q, rccl)) for r in range(world)]
     for p in procs:
         p.start()
     res = []

@@ -151,6 +151,13 @@ def test_header_is_plain_c_and_every_entry_links_from_c(tmp_path):
                     "-L", libdir, "-lbayeformers_amd", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert out[-1] == str(len(names)) and int(out[0]) == _C.lib().bf_version()
+    # the developer build's header (csrc/bf_dev_api.h) is C too, finds the public header by itself, and declares
+    # exactly the developer symbols the binding knows
+    dev = os.path.join(root, "bayeformers_amd", "csrc", "bf_dev_api.h")
+    tu = tmp_path / "dev_check.c"
+    tu.write_text(f'#include "{dev}"\nint main(void) {{ return 0; }}\n')
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", str(tu)], check=True)
+    assert set(re.findall(r"\b(bf_[a-z0-9_]+)\s*\(", open(dev).read())) == set(_C.DEV_SYMBOLS)
 
 
 def test_recompute_context_is_bound_to_the_graph_that_runs_backward():
