@@ -100,6 +100,72 @@ def shard_span(samples: int, rank: int, world: int) -> Tuple[int, int]:
     return rank * q + min(rank, r), q + (1 if rank < r else 0)
 
 
+def _shard_group(group):
+    """(distributed?, rank, world) of the S-shard group."""
+    distributed = dist.is_available() and dist.is_initialized() and (group is not None or dist.get_world_size() > 1)
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    return distributed, rank, world
+
+
+def _local_step(model: Model, inputs, samples: int, select: Optional[Callable], rank: int, world: int, repeated: bool = False):
+    """This rank's part of a step: the batched forward of its slice of the samples and the sums over them.  Returns
+    (raw, sizes, local) — local is what the ranks add up: ONE packed fp64 buffer [sums of the outputs | sum log_prior |
+    sum lvp] when the outputs are small, else (fp32 output sums, fp64 log-prob sums).  repeated: `inputs` are already
+    the S_local-fold repeat."""
+    if samples < 1:
+        raise ValueError(f"samples={samples}: at least one Monte-Carlo sample")
+    start, count = shard_span(samples, rank, world)
+    idle = count == 0
+    if idle:
+        start, count = 0, 1
+    s_local = count
+    select = select or _default_select
+
+    rep = inputs if repeated else repeat_inputs(inputs, s_local)
+    with model.monte_carlo(s_local, span=(start, samples)):
+        if isinstance(rep, dict):
+            out = model(**rep)
+        elif isinstance(rep, Tensor):
+            out = model(rep)
+        else:
+            out = model(*rep)
+    outs = select(out)
+    raw = tuple(o.reshape(s_local, o.shape[0] // s_local, *o.shape[1:]) for o in outs)
+    lp = model.log_prob_samples()  # [S_local, 2] float64
+
+    # sums over this rank's samples: outputs in fp32 (fused convert-on-load, they can be large), the two log-prob
+    # scalars in fp64; small outputs ride in the same fp64 buffer so that a distributed step is ONE collective
+    sizes = [r[0].numel() for r in raw]
+    one_buffer = sum(sizes) <= 65536
+    acc_dt = torch.float64 if one_buffer else torch.float32
+    sums = [r.sum(0, dtype=acc_dt).reshape(-1) for r in raw]
+    if idle:  # this rank's forward only provided the shapes
+        sums, lp, raw = [t * 0 for t in sums], lp * 0, tuple(r[:0] for r in raw)
+    if one_buffer:
+        local = (torch.cat(sums + [lp.sum(0)]),)
+    else:
+        local = (torch.cat(sums) if len(sums) > 1 else sums[0], lp.sum(0))
+    return raw, sizes, local
+
+
+def _finish_step(raw, sizes, local, samples: int, group, distributed: bool):
+    """The step's collective(s) and the means over ALL samples: (means, log_prior, lvp)."""
+    n_out = sum(sizes)
+    if distributed:
+        local = tuple(_all_reduce_sum(t, group) for t in local)
+    if len(local) == 1:
+        packed = local[0] / samples
+        out_part, lp_part = packed[:n_out], packed[n_out:]
+    else:
+        out_part, lp_part = local[0] / samples, local[1] / samples
+    means, off = [], 0
+    for r, n in zip(raw, sizes):
+        means.append(out_part[off:off + n].reshape(r.shape[1:]).to(r.dtype))
+        off += n
+    return means, lp_part[0], lp_part[1]
+
+
 def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callable] = None,
                     group: Optional["dist.ProcessGroup"] = None, gather_raw: bool = False
                     ) -> Tuple[Tuple[Tensor, ...], Tuple[Tensor, ...], Tensor, Tensor]:
@@ -119,56 +185,9 @@ def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callabl
         mean  tuple of [B, ...] means over ALL S samples,
         log_prior, log_variational_posterior: 0-d float64 means over ALL S samples.
     """
-    distributed = dist.is_available() and dist.is_initialized() and (group is not None or dist.get_world_size() > 1)
-    world = dist.get_world_size(group) if distributed else 1
-    rank = dist.get_rank(group) if distributed else 0
-    if samples < 1:
-        raise ValueError(f"samples={samples}: at least one Monte-Carlo sample")
-    start, count = shard_span(samples, rank, world)
-    idle = count == 0
-    if idle:
-        start, count = 0, 1
-    s_local = count
-    select = select or _default_select
-
-    rep = repeat_inputs(inputs, s_local)
-    with model.monte_carlo(s_local, span=(start, samples)):
-        if isinstance(rep, dict):
-            out = model(**rep)
-        elif isinstance(rep, Tensor):
-            out = model(rep)
-        else:
-            out = model(*rep)
-    outs = select(out)
-    raw = tuple(o.reshape(s_local, o.shape[0] // s_local, *o.shape[1:]) for o in outs)
-    lp = model.log_prob_samples()  # [S_local, 2] float64
-
-    # sums over this rank's samples: outputs in fp32 (fused convert-on-load, they can be large), the two log-prob
-    # scalars in fp64; small outputs ride in the same fp64 buffer so that a distributed step is ONE collective
-    sizes = [r[0].numel() for r in raw]
-    n_out = sum(sizes)
-    one_buffer = n_out <= 65536
-    acc_dt = torch.float64 if one_buffer else torch.float32
-    sums = [r.sum(0, dtype=acc_dt).reshape(-1) for r in raw]
-    if idle:  # this rank's forward only provided the shapes
-        sums, lp, raw = [t * 0 for t in sums], lp * 0, tuple(r[:0] for r in raw)
-    if one_buffer:
-        packed = torch.cat(sums + [lp.sum(0)])
-        if distributed:
-            packed = _all_reduce_sum(packed, group)
-        packed = packed / samples
-        out_part, lp_part = packed[:n_out], packed[n_out:]
-    else:
-        out_part, lp_part = torch.cat(sums) if len(sums) > 1 else sums[0], lp.sum(0)
-        if distributed:
-            out_part = _all_reduce_sum(out_part, group)
-            lp_part = _all_reduce_sum(lp_part, group)
-        out_part, lp_part = out_part / samples, lp_part / samples
-    means, off = [], 0
-    for r, n in zip(raw, sizes):
-        means.append(out_part[off:off + n].reshape(r.shape[1:]).to(r.dtype))
-        off += n
-    log_prior, lvp = lp_part[0], lp_part[1]
+    distributed, rank, world = _shard_group(group)
+    raw, sizes, local = _local_step(model, inputs, samples, select, rank, world)
+    means, log_prior, lvp = _finish_step(raw, sizes, local, samples, group, distributed)
     if distributed and gather_raw:
         # shards may differ by one sample: every rank sends ceil(S / world) slabs, the receiver keeps each rank's own
         s_max = -(-samples // world)
@@ -188,3 +207,111 @@ def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callabl
 def elbo(log_prior: Tensor, log_variational_posterior: Tensor, nll: Tensor, n_batches: int) -> Tensor:
     """loss = (lvp - log_prior) / n_batches + nll  (bert_glue.py:235, mlp_mnist.py:107, README.md:72)."""
     return torch.add(nll, log_variational_posterior - log_prior, alpha=1.0 / n_batches)
+
+
+class GraphedSampler:
+    """`sample_bayesian` for ONE batch signature, replayed from a HIP graph (inference / evaluation).
+
+    A small step is bound by the host, not by the GPU: the forward of a BERT-base shard of 1-3 samples is ~2-3 ms of
+    kernels behind 4-7 ms of Python and launch calls (what a strong-scaling shard of S = 10 over 8 GPUs runs, or a
+    latency-bound evaluation with few samples).  This class runs the rank's part of the step — input repeat, the batched
+    forward, the sampling plan's launches, the sums over the rank's samples, and on a single process the means too — once
+    under `torch.cuda.graph` and replays it; the Monte-Carlo sample counter lives in device memory while it exists
+    (`use_device_counter`), so replay k draws the epsilon the k-th eager step would have drawn.  With an S-shard group the
+    step's one collective runs eagerly after the replay (RCCL on the compute stream), exactly as in `sample_bayesian`.
+
+        sampler = GraphedSampler(bmodel, inputs, samples=10)
+        raw, mean, log_prior, lvp = sampler()            # same batch, fresh epsilon
+        raw, mean, log_prior, lvp = sampler(next_inputs)  # same shapes / dtypes: copied into the captured buffers
+
+    The returned tensors are the graph's own buffers (`mean`, the log-probs: fresh tensors when a group reduces them): the
+    next call overwrites them — clone what must outlive it.  Gradients are not recorded (training steps are not
+    replayable: their dropout masks and autograd graphs are per step) and the model must be in eval mode."""
+
+    def __init__(self, model: Model, inputs, samples: int, select: Optional[Callable] = None,
+                 group: Optional["dist.ProcessGroup"] = None, warmup: int = 2) -> None:
+        from . import random as bfr
+
+        if model.training:
+            raise RuntimeError("GraphedSampler: the model is in training mode (dropout masks are per step); call model.eval()")
+        self.model, self.samples, self.select, self.group = model, int(samples), select, group
+        self.distributed, self.rank, self.world = _shard_group(group)
+        tensors = [v for v in self._leaves(inputs) if isinstance(v, Tensor)]
+        if not tensors or not all(t.is_cuda for t in tensors):
+            raise RuntimeError("GraphedSampler: the inputs must be tensors on the GPU the model runs on")
+        self.device = tensors[0].device
+        self._s_local = max(1, shard_span(self.samples, self.rank, self.world)[1])
+        # the S_local-fold repeat of the batch is made ONCE, here: a new batch is copied into it (broadcast over the
+        # sample axis) and the captured step starts at the model's forward
+        self._signature = self._sig(inputs)
+        self._rep = self._map(inputs, lambda v: v.repeat(self._s_local, *([1] * (v.dim() - 1))) if v.dim() > 0 else v.clone())
+        self._owns_counter = bfr.STATE.device_counter is None
+        bfr.use_device_counter(True, device=self.device)
+        self.graph = None
+        with torch.no_grad(), torch.cuda.device(self.device):
+            for _ in range(max(1, int(warmup))):  # plans, workspaces and tile schedules are built outside the capture
+                self._step()
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._static = self._step()
+            self.graph = graph
+
+    # ------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _leaves(inputs):
+        if isinstance(inputs, Tensor):
+            return [inputs]
+        return list(inputs.values()) if isinstance(inputs, dict) else list(inputs)
+
+    @staticmethod
+    def _map(inputs, fn):
+        f = lambda v: fn(v) if isinstance(v, Tensor) else v
+        if isinstance(inputs, Tensor):
+            return f(inputs)
+        if isinstance(inputs, dict):
+            return {k: f(v) for k, v in inputs.items()}
+        return type(inputs)(f(v) for v in inputs)
+
+    @classmethod
+    def _sig(cls, inputs):
+        keys = list(inputs.keys()) if isinstance(inputs, dict) else None
+        return keys, [(tuple(v.shape), v.dtype, v.device) if isinstance(v, Tensor) else v for v in cls._leaves(inputs)]
+
+    def _step(self):
+        raw, sizes, local = _local_step(self.model, self._rep, self.samples, self.select, self.rank, self.world, repeated=True)
+        if self.distributed:
+            return raw, sizes, local, None
+        return raw, sizes, local, _finish_step(raw, sizes, local, self.samples, None, False)
+
+    def load(self, inputs) -> None:
+        """Copy a new batch (same structure, shapes, dtypes, device) into the captured input buffers."""
+        if self._sig(inputs) != self._signature:
+            raise ValueError("GraphedSampler: the batch differs from the captured one in structure, shape, dtype or device; "
+                             "build another GraphedSampler for it")
+        S = self._s_local
+        for dst, src in zip(self._leaves(self._rep), self._leaves(inputs)):
+            if isinstance(src, Tensor):
+                (dst.view(S, *src.shape) if src.dim() > 0 else dst).copy_(src)
+
+    def __call__(self, inputs=None):
+        if self.graph is None:
+            raise RuntimeError("GraphedSampler: closed")
+        if inputs is not None:
+            self.load(inputs)
+        self.graph.replay()
+        raw, sizes, local, done = self._static
+        if done is None:  # the S-shard group's collective, on clones: the graph's buffers stay what the replay wrote
+            with torch.no_grad():
+                done = _finish_step(raw, sizes, tuple(t.clone() for t in local), self.samples, self.group, True)
+        means, log_prior, lvp = done
+        return raw, tuple(means), log_prior, lvp
+
+    def close(self) -> None:
+        """Drop the graph and, if this object moved the sample counter to the device, move it back to the host."""
+        from . import random as bfr
+
+        self.graph = self._static = None
+        if self._owns_counter:
+            bfr.use_device_counter(False)
+            self._owns_counter = False

@@ -1,0 +1,76 @@
+"""GraphedSampler: the harness step replayed from a HIP graph must be the eager step — replay k draws the epsilon of
+the k-th eager `sample_bayesian` call (device-resident sample counter), new batches are copied into the captured buffers,
+and closing it hands the counter back to the host."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+SEED = 0xBEEF
+
+
+def _build():
+    import bayeformers_amd as bf
+    from transformers import BertConfig, BertForSequenceClassification
+
+    cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, vocab_size=1000,
+                     max_position_embeddings=64)
+    torch.manual_seed(0)
+    model = BertForSequenceClassification(cfg).eval()
+    bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().cuda().to(torch.bfloat16)
+    bf.fuse_activations(bmodel), bf.fuse_residual_layernorm(bmodel), bf.fuse_shared_inputs(bmodel)
+    bf.fuse_attention(bmodel), bf.fuse_embeddings(bmodel)
+    g = torch.Generator().manual_seed(7)
+    batches = []
+    for _ in range(2):
+        ids = torch.randint(0, cfg.vocab_size, (4, 32), generator=g).cuda()
+        batches.append({"input_ids": ids, "attention_mask": torch.ones(4, 32, dtype=torch.long, device="cuda")})
+    return bmodel, batches
+
+
+def _host(res):
+    raw, mean, lp, lq = res
+    return raw[0].float().cpu().numpy().copy(), mean[0].float().cpu().numpy().copy(), float(lp), float(lq)
+
+
+@pytest.mark.parametrize("S", [1, 3])
+def test_replays_are_the_eager_steps(S):
+    import bayeformers_amd as bf
+    from bayeformers_amd import random as bfr
+    from bayeformers_amd.sampling import GraphedSampler, sample_bayesian
+
+    bmodel, batches = _build()
+    bf.set_compute_dtype("bf16")
+    order = [0, 0, 1, 0]  # the batch fed at each step
+    bf.manual_seed(SEED)
+    with torch.no_grad():
+        eager = [_host(sample_bayesian(bmodel, batches[b], S)) for b in order]
+    assert bfr.STATE.device_counter is None and bfr.get_state()[1] == len(order) * S
+
+    sampler = GraphedSampler(bmodel, batches[0], S)
+    assert bfr.STATE.device_counter is not None
+    bf.manual_seed(SEED)  # rewinds the device-resident counter too
+    for step, b in enumerate(order):
+        got = _host(sampler(batches[b]) if step else sampler())
+        want = eager[step]
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), step
+        assert got[2] == want[2] and got[3] == want[3], step
+    # a batch of another shape is refused, not silently truncated
+    with pytest.raises(ValueError, match="differs from the captured one"):
+        sampler({k: v[:2] for k, v in batches[0].items()})
+    sampler.close()
+    assert bfr.STATE.device_counter is None and bfr.get_state()[1] == len(order) * S  # the counter came back, advanced
+    with torch.no_grad():
+        nxt = _host(sample_bayesian(bmodel, batches[0], S))
+    assert not np.array_equal(nxt[0], eager[0][0])  # fresh sample indices, not a rewind
+    with pytest.raises(RuntimeError, match="closed"):
+        sampler()
+
+
+def test_training_mode_is_refused():
+    from bayeformers_amd.sampling import GraphedSampler
+
+    bmodel, batches = _build()
+    bmodel.train()
+    with pytest.raises(RuntimeError, match="training mode"):
+        GraphedSampler(bmodel, batches[0], 2)

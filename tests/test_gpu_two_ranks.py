@@ -59,6 +59,23 @@ def _run(S, steps):
     return fwd, float(loss), grads, after
 
 
+def _run_graphed(S, replays):
+    """The forward harness through GraphedSampler: `replays` steps of S samples, fresh epsilon each."""
+    import bayeformers_amd as bf
+    from bayeformers_amd.sampling import GraphedSampler
+
+    bmodel, inputs, _ = _build()
+    bf.set_compute_dtype("bf16")
+    sampler = GraphedSampler(bmodel, inputs, S)
+    bf.manual_seed(SEED)
+    out = []
+    for _ in range(replays):
+        raw, mean, lp, lq = sampler()
+        out.append((mean[0].float().cpu().numpy().copy(), float(lp), float(lq)))
+    sampler.close()
+    return out
+
+
 def _worker(rank, world, port, S, steps, q, rccl=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
@@ -69,7 +86,7 @@ def _worker(rank, world, port, S, steps, q, rccl=False):
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank,) + _run(S, steps))
+        q.put((rank,) + (_run(S, steps) if steps > 0 else (_run_graphed(S, -steps),)))
     finally:
         dist.destroy_process_group()
 
@@ -122,6 +139,46 @@ def test_two_ranks_on_one_gpu_match_single_process(rccl):
             assert np.abs(g[n] - grads[n]).max() <= 3e-2 * scale, (rank, n)
         for n in after:
             assert np.array_equal(a[n], res[0][4][n]), (rank, n)
+
+
+@pytest.mark.timeout(600)
+def test_graphed_sampler_on_two_ranks_matches_single_process():
+    """GraphedSampler under an S-shard group: every rank replays its own slice (3 + 2 samples) from its HIP graph, the
+    step's collective runs eagerly after the replay; three replays = the three eager steps of one process."""
+    S, replays, world = 5, 3, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, S, -replays, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    deadline = time.monotonic() + 500
+    while len(res) < len(procs):
+        try:
+            res.append(q.get(timeout=2))
+        except Exception:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f"a rank exited with {dead}"
+            assert time.monotonic() < deadline, "timed out"
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    import bayeformers_amd as bf
+    from bayeformers_amd.sampling import sample_bayesian
+
+    bmodel, inputs, _ = _build()
+    bf.set_compute_dtype("bf16")
+    bf.manual_seed(SEED)
+    with torch.no_grad():
+        want = [sample_bayesian(bmodel, inputs, S) for _ in range(replays)]
+    for rank, got in res:
+        for k in range(replays):
+            np.testing.assert_allclose(got[k][0], want[k][1][0].float().cpu().numpy(), rtol=1e-2, atol=1e-3)
+            assert got[k][1] == pytest.approx(float(want[k][2]), rel=1e-12)
+            assert got[k][2] == pytest.approx(float(want[k][3]), rel=1e-12)
 
 
 def test_bench_strong_scaling_shards_one_total_unevenly():
