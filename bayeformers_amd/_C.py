@@ -86,6 +86,8 @@ SYMBOLS = {
                                       _u32, _vp]),
     "bf_add_layernorm_dropout_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i64, _i, ctypes.c_float,
                                           ctypes.c_float, _u64, _u32, _u32, _vp]),
+    "bf_add_layernorm_bwd_sum": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i64, _i, ctypes.c_float,
+                                      ctypes.c_float, _u64, _u32, _u32, _vp]),
     "bf_profile_enable": (_i, [_i]),
     "bf_profile_reset": (_i, []),
     "bf_probe_stream_read": (_i, [_vp, _sz, _vp, _vp]),
@@ -98,7 +100,7 @@ SYMBOLS = {
 BF_PROF_SAMPLE, BF_PROF_GEMM, BF_PROF_FUSED_SMALL, BF_PROF_FUSED_WS = 0, 1, 2, 3
 BF_ACT_NONE, BF_ACT_GELU = 0, 1
 
-ABI_VERSION = 3  # bf_version() of the library these bindings describe (include/bayeformers_amd.h: BF_VERSION_*)
+ABI_VERSION = 4  # bf_version() of the library these bindings describe (include/bayeformers_amd.h: BF_VERSION_*)
 
 # developer-build entry points (csrc/bf_dev_api.h): bound when the loaded library has them (BF_LIB_PATH=..._dev.so)
 DEV_SYMBOLS = {

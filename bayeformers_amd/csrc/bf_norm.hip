@@ -195,7 +195,7 @@ template <typename T, typename GT, int VPL, bool DROP = false>
 __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_bwd_kernel(
     const T* __restrict__ x, const T* __restrict__ res, const GT* __restrict__ gamma, const T* __restrict__ dy,
     T* __restrict__ dz, float* __restrict__ partial, long long rows, int N, float eps, const bf_dropout_t drop,
-    T* __restrict__ dx) {
+    T* __restrict__ dx, const T* __restrict__ dy2) {
     extern __shared__ float sh[];  // [kRowsPerBlock][2][N]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = N >> 3;
@@ -224,6 +224,12 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_bwd_kernel(
                     for (int i = 0; i < 8; ++i) v[c][i] += r[i];
                 }
                 load8(dy + row * N + vi * 8, g[c]);
+                if (dy2) {  // the output had two consumers: their gradients are summed here, in fp32, not by a pass of their own
+                    float h[8];
+                    load8(dy2 + row * N + vi * 8, h);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) g[c][i] += h[i];
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) sum += v[c][i];
             }
@@ -316,7 +322,8 @@ constexpr int kBwdBlocks = BF_LN_BWD_BLOCKS;  // workgroups (each leaves one [2]
 
 template <typename T, typename GT>
 int launch_bwd_vpl(const void* x, const void* res, const void* gamma, const void* dy, void* dz, float* partial,
-                   int nblocks, long long rows, int N, float eps, hipStream_t stream, const bf_dropout_t* drop, void* dx) {
+                   int nblocks, long long rows, int N, float eps, hipStream_t stream, const bf_dropout_t* drop, void* dx,
+                   const void* dy2) {
     const int nvec = N >> 3;
     const size_t lds = (size_t)kRowsPerBlock * 2 * N * sizeof(float);
     const dim3 grid((unsigned)nblocks), block(64 * kRowsPerBlock);
@@ -325,10 +332,12 @@ int launch_bwd_vpl(const void* x, const void* res, const void* gamma, const void
     do {                                                                                                                    \
         if (d.thresh)                                                                                                       \
             hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, GT, VPL, true>), grid, block, lds, stream, (const T*)x,         \
-                               (const T*)res, (const GT*)gamma, (const T*)dy, (T*)dz, partial, rows, N, eps, d, (T*)dx);    \
+                               (const T*)res, (const GT*)gamma, (const T*)dy, (T*)dz, partial, rows, N, eps, d, (T*)dx,    \
+                               (const T*)dy2);                                                                              \
         else                                                                                                                \
             hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, GT, VPL, false>), grid, block, lds, stream, (const T*)x,        \
-                               (const T*)res, (const GT*)gamma, (const T*)dy, (T*)dz, partial, rows, N, eps, d, (T*)dx);    \
+                               (const T*)res, (const GT*)gamma, (const T*)dy, (T*)dz, partial, rows, N, eps, d, (T*)dx,    \
+                               (const T*)dy2);                                                                              \
     } while (0)
     if (nvec <= 64) BF_LNB_LAUNCH(1);
     else if (nvec <= 128) BF_LNB_LAUNCH(2);
@@ -551,7 +560,8 @@ size_t bf_add_layernorm_bwd_ws_bytes(long long rows, int N) {
 int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
                                 const void* d_dy, void* d_dz, float* d_dgamma, float* d_dbeta, void* d_workspace,
                                 size_t workspace_bytes, int dtype, long long rows, int N, float eps, hipStream_t stream,
-                                const bf_dropout_t* drop, void* d_dx) {
+                                const bf_dropout_t* drop, void* d_dx, const void* d_dy2) {
+    if ((uintptr_t)d_dy2 & 15) BF_FAIL("bf_add_layernorm_bwd: the second gradient must be 16-byte aligned");
     if (drop && drop->thresh && (!d_dx || ((uintptr_t)d_dx & 15)))
         BF_FAIL("bf_add_layernorm_bwd: dropout needs a 16-byte aligned d_dx (the gradient of the dropped input)");
     if (rows < 0 || N <= 0) BF_FAIL("bf_add_layernorm_bwd: bad shape rows=%lld N=%d", rows, N);
@@ -571,8 +581,8 @@ int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const v
     float* partial = reinterpret_cast<float*>(d_workspace);
     int rc = 1;
 #define BF_LNB_DISPATCH(T)                                                                                              \
-    rc = param_dtype == BF_DT_F32 ? launch_bwd_vpl<T, float>(d_x, d_residual, d_gamma, d_dy, d_dz, partial, nb, rows, N, eps, stream, drop, d_dx) \
-         : param_dtype == dtype   ? launch_bwd_vpl<T, T>(d_x, d_residual, d_gamma, d_dy, d_dz, partial, nb, rows, N, eps, stream, drop, d_dx)     \
+    rc = param_dtype == BF_DT_F32 ? launch_bwd_vpl<T, float>(d_x, d_residual, d_gamma, d_dy, d_dz, partial, nb, rows, N, eps, stream, drop, d_dx, d_dy2) \
+         : param_dtype == dtype   ? launch_bwd_vpl<T, T>(d_x, d_residual, d_gamma, d_dy, d_dz, partial, nb, rows, N, eps, stream, drop, d_dx, d_dy2)     \
                                   : (bf_set_error("bf_add_layernorm_bwd: gamma must be fp32 or have the activation dtype"), 1)
     switch (dtype) {
         case BF_DT_BF16: BF_LNB_DISPATCH(__bf16); break;

@@ -651,10 +651,11 @@ class AttentionFn(torch.autograd.Function):
 
 
 def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor, grad_out: Tensor, eps: float,
-                           drop: Optional[Dropout] = None):
+                           drop: Optional[Dropout] = None, grad_out2: Optional[Tensor] = None):
     """Gradients of add_layernorm (bf_add_layernorm_bwd): returns (dz, dgamma, dbeta); dz is the gradient of both x
     and residual, dgamma / dbeta are fp32.  With `drop` (bf_add_layernorm_dropout_bwd) returns (dz, dgamma, dbeta, dx):
-    dz is the residual's gradient, dx = dz o keep / (1 - p) the dropped input's."""
+    dz is the residual's gradient, dx = dz o keep / (1 - p) the dropped input's.  grad_out2: the gradient of the
+    output's second consumer, added to grad_out inside the kernel (bf_add_layernorm_bwd_sum)."""
     N = x.shape[-1]
     x2 = x.reshape(-1, N)
     x2 = x2 if x2.is_contiguous() else x2.contiguous()
@@ -670,6 +671,19 @@ def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor,
     lib = _C.lib()
     need = lib.bf_add_layernorm_bwd_workspace_bytes(x2.shape[0], N)
     ws = workspace(x.device, need)
+    if grad_out2 is not None:
+        h2 = grad_out2.reshape(-1, N)
+        h2 = (h2 if h2.dtype == x.dtype else h2.to(x.dtype)).contiguous()
+        dropping = drop is not None and drop.p > 0.0
+        dx = torch.empty_like(x2) if dropping else None
+        _C.check(lib.bf_add_layernorm_bwd_sum(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
+                                              _TORCH2BF[gamma.dtype], g2.data_ptr(), h2.data_ptr(), dz.data_ptr(),
+                                              dx.data_ptr() if dropping else None, dgamma.data_ptr(), dbeta.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), _TORCH2BF[x.dtype], x2.shape[0], N, float(eps),
+                                              drop.p if dropping else 0.0, drop.seed if dropping else 0,
+                                              drop.call if dropping else 0, drop.site if dropping else 0, _stream_ptr()),
+                 "bf_add_layernorm_bwd_sum")
+        return (dz.view(x.shape), dgamma, dbeta, dx.view(x.shape)) if dropping else (dz.view(x.shape), dgamma, dbeta)
     if drop is not None and drop.p > 0.0:
         dx = torch.empty_like(x2)
         _C.check(lib.bf_add_layernorm_dropout_bwd(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
@@ -685,31 +699,51 @@ def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor,
     return dz.view(x.shape), dgamma, dbeta
 
 
+_NO_TWIN = os.environ.get("BF_NO_LN_TWIN") is not None  # developer A/B: let autograd add the two consumers' gradients
+
+
 class AddLayerNormFn(torch.autograd.Function):
-    """LayerNorm(x + residual) * gamma + beta with both directions in the HIP kernels; nothing but the inputs is saved."""
+    """LayerNorm(x + residual) * gamma + beta with both directions in the HIP kernels; nothing but the inputs is saved.
+
+    twin=True returns the output TWICE — (y, an alias of y that shares its storage) — for the callers that know the output
+    has two consumers (in a transformer layer: the next dense layer and the next residual connection).  Each consumer takes
+    its own alias, so autograd hands backward() the two gradients separately and the kernel adds them on load
+    (bf_add_layernorm_bwd_sum) instead of autograd adding them with an activation-sized pass of its own.  Whatever the
+    graph looks like the result is the plain one: an alias nobody used has no gradient, further consumers of either alias
+    are summed by autograd as always."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, drop=None):
+    def forward(ctx, x, residual, gamma, beta, eps, drop=None, twin=False):
         ctx.eps, ctx.has_res = eps, residual is not None
         ctx.drop = drop if (drop is not None and drop.p > 0.0) else None
         ctx.save_for_backward(x, residual if residual is not None else x, gamma)
-        return add_layernorm(x, residual, gamma, beta, eps, ctx.drop)
+        y = add_layernorm(x, residual, gamma, beta, eps, ctx.drop)
+        if twin:
+            ctx.set_materialize_grads(False)  # an unused alias arrives as None, not as a tensor of zeros
+            return y, y.detach()
+        return y
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, grad_twin=None):
         x, residual, gamma = ctx.saved_tensors
+        if grad_out is None:
+            grad_out, grad_twin = grad_twin, None
+        if grad_out is None:
+            return None, None, None, None, None, None, None
         dx = None
         if ctx.drop is not None:  # the mask is regenerated from (seed, call, site): nothing was stored
-            dz, dgamma, dbeta, dx = add_layernorm_backward(x, residual if ctx.has_res else None, gamma, grad_out, ctx.eps, ctx.drop)
+            dz, dgamma, dbeta, dx = add_layernorm_backward(x, residual if ctx.has_res else None, gamma, grad_out, ctx.eps, ctx.drop,
+                                                           grad_out2=grad_twin)
         else:
-            dz, dgamma, dbeta = add_layernorm_backward(x, residual if ctx.has_res else None, gamma, grad_out, ctx.eps)
+            dz, dgamma, dbeta = add_layernorm_backward(x, residual if ctx.has_res else None, gamma, grad_out, ctx.eps,
+                                                       grad_out2=grad_twin)
         need = ctx.needs_input_grad
         if gamma.dtype != torch.float32 and (need[2] or need[3]):
             # dgamma and dbeta are the two rows of one fp32 buffer: cast them with one launch
             both = dgamma._base.to(gamma.dtype) if dgamma._base is not None else torch.stack((dgamma, dbeta)).to(gamma.dtype)
             dgamma, dbeta = both[0], both[1]
         return ((dx if dx is not None else dz) if need[0] else None, dz if (ctx.has_res and need[1]) else None,
-                dgamma if need[2] else None, dbeta if need[3] else None, None, None)
+                dgamma if need[2] else None, dbeta if need[3] else None, None, None, None)
 
 
 def layernorm_supported(x: Tensor, residual: Optional[Tensor], ln) -> bool:

@@ -25,8 +25,9 @@ extern "C" {
 #endif
 
 #define BF_VERSION_MAJOR 0
-#define BF_VERSION_MINOR 3  /* 2: bf_embed_layernorm takes the table row counts; 3: bf_sample_table_build reports the
-                               tensors' effective prior kinds, bf_sample_logprob_table takes the launch's set of them */
+#define BF_VERSION_MINOR 4  /* 2: bf_embed_layernorm takes the table row counts; 3: bf_sample_table_build reports the
+                               tensors' effective prior kinds, bf_sample_logprob_table takes the launch's set of them;
+                               4: bf_add_layernorm_bwd_sum */
 
 /* element types of activations / sampled weights */
 enum { BF_DT_F32 = 0, BF_DT_BF16 = 1, BF_DT_F16 = 2 };
@@ -333,6 +334,16 @@ int bf_add_layernorm_dropout_bwd(const void* d_x, const void* d_residual, const 
                                  const void* d_dy, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
                                  size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
                                  uint32_t call, uint32_t site, void* stream);
+
+/* bf_add_layernorm_bwd / bf_add_layernorm_dropout_bwd (p_drop = 0: no dropout, d_dx unused) for an output that had TWO
+ * consumers — in a transformer layer the normalised rows feed the next dense layer AND the next residual connection
+ * (HF BertLayer: attention_output -> intermediate(...) and output(..., attention_output)).  Autograd would add the two
+ * gradients with a pass of its own (read 2, write 1 activation-sized tensors) before this backward reads the sum; here
+ * d_dy2 (nullable) is added to d_dy on load, in fp32. */
+int bf_add_layernorm_bwd_sum(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,
+                             const void* d_dy2, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
+                             size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
+                             uint32_t call, uint32_t site, void* stream);
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * While enabled, every sampling launch (kind BF_PROF_SAMPLE) and every GEMM launch (BF_PROF_GEMM) made through

@@ -786,3 +786,108 @@ def test_add_layernorm_backward_matches_autograd(dtype, tol, rows, N, with_res):
     for got, want in pairs:
         scale = want.abs().max().item() + 1e-30
         assert (got.float() - want).abs().max().item() <= tol * scale
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+@pytest.mark.parametrize("use", ["both", "first", "alias"])
+def test_add_layernorm_twin_outputs_sum_their_gradients_in_the_kernel(dtype, tol, p, use):
+    """AddLayerNormFn(twin=True) hands out the output and an alias of it; two consumers that take one each send their
+    gradients to ONE backward launch that adds them on load (bf_add_layernorm_bwd_sum).  Gradients must equal those of the
+    plain function whose single output feeds both consumers (autograd adds), whichever of the aliases is actually used."""
+    from bayeformers_amd import ops
+
+    rows, N = 300, 768
+    g = torch.Generator().manual_seed(11)
+    mk = lambda: torch.randn(rows, N, generator=g).to(dtype).cuda()
+    x0, r0, w1, w2 = mk(), mk(), mk(), mk()
+    gamma0 = (1 + 0.1 * torch.randn(N, generator=g)).cuda()
+    beta0 = (0.1 * torch.randn(N, generator=g)).cuda()
+    drop = ops.Dropout(p, 0xABC, 3, 5) if p else None
+    if use == "first":
+        w2 = None
+    if use == "alias":
+        w1 = None
+
+    def run(twin):
+        x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        gamma, beta = gamma0.clone().requires_grad_(True), beta0.clone().requires_grad_(True)
+        if twin:
+            y, y2 = ops.AddLayerNormFn.apply(x, r, gamma, beta, 1e-12, drop, True)
+            assert y2.data_ptr() == y.data_ptr() and torch.equal(y, y2)
+        else:
+            y = y2 = ops.AddLayerNormFn.apply(x, r, gamma, beta, 1e-12, drop)
+        loss = 0
+        if w1 is not None:
+            loss = loss + (y.float() * w1.float()).sum()
+        if w2 is not None:
+            loss = loss + (y2.float() * w2.float()).sum()
+        loss.backward()
+        return y.detach(), [x.grad, r.grad, gamma.grad, beta.grad]
+
+    calls = []
+    orig = ops.add_layernorm_backward
+
+    def spy(*a, **k):
+        calls.append(k.get("grad_out2") is not None)
+        return orig(*a, **k)
+
+    ops.add_layernorm_backward = spy
+    try:
+        y_t, got = run(True)
+    finally:
+        ops.add_layernorm_backward = orig
+    assert calls == [use == "both"]  # one launch; the second gradient only when both aliases were used
+    y_p, want = run(False)
+    assert torch.equal(y_t, y_p)
+    for a, b in zip(got, want):
+        scale = b.float().abs().max().item() + 1e-30
+        assert (a.float() - b.float()).abs().max().item() <= tol * scale
+
+
+def test_fused_residual_blocks_pass_the_alias_along():
+    """In a converted BERT the residual connection of every fused `*Output` block reads the previous block's alias: of a
+    2-layer model's four blocks, three backward launches get their two gradients separately (the last block's output only
+    feeds the pooler) — and a block whose input is not such an output works as before."""
+    import bayeformers_amd as bf
+    from bayeformers_amd import ops
+    from bayeformers_amd.sampling import sample_bayesian
+    from transformers import BertConfig, BertForSequenceClassification
+
+    cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, vocab_size=500,
+                     max_position_embeddings=64, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(0)
+    # fp32 end to end: what differs between the two runs is then only WHERE the two gradients are added
+    bmodel = bf.to_bayesian(BertForSequenceClassification(cfg), delta=0.05, freeze=True).cuda().train()
+    bf.fuse_activations(bmodel), bf.fuse_residual_layernorm(bmodel), bf.fuse_shared_inputs(bmodel)
+    ids = torch.randint(0, 500, (2, 32), device="cuda")
+    inputs = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+
+    def grads(no_twin):
+        calls = []
+        orig, flag = ops.add_layernorm_backward, ops._NO_TWIN
+
+        def spy(*a, **k):
+            calls.append(k.get("grad_out2") is not None)
+            return orig(*a, **k)
+
+        ops.add_layernorm_backward, ops._NO_TWIN = spy, no_twin
+        try:
+            bf.set_compute_dtype("fp32")
+            bf.manual_seed(77)
+            bmodel.zero_grad(set_to_none=True)
+            raw, mean, lp, lq = sample_bayesian(bmodel, inputs, 2)
+            mean[0].float().square().sum().backward()
+        finally:
+            ops.add_layernorm_backward, ops._NO_TWIN = orig, flag
+            bf.set_compute_dtype("bf16")
+        return calls, {n: p.grad.float().clone() for n, p in bmodel.named_parameters() if p.grad is not None}
+
+    calls_t, g_t = grads(False)
+    calls_p, g_p = grads(True)
+    assert sum(calls_t) == 3 and sum(calls_p) == 0 and len(calls_t) == len(calls_p)
+    assert g_t.keys() == g_p.keys() and len(g_t) > 20
+    worst = {n: (g_t[n] - g_p[n]).abs().max().item() / (g_p[n].abs().max().item() + 1e-30) for n in g_p}
+    # (the softmax does not depend on the key bias: that gradient is zero in exact arithmetic, rounding noise in any other)
+    bad = {n: round(v, 6) for n, v in worst.items() if v > 1e-3 and ".key.bias" not in n}
+    assert not bad, bad

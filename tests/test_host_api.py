@@ -111,7 +111,7 @@ def test_header_and_library_export_the_same_symbols():
     lib = ctypes.CDLL(_C.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _C.lib().bf_version() == _C.ABI_VERSION == 3
+    assert _C.lib().bf_version() == _C.ABI_VERSION == 4
 
 
 def test_struct_layout_matches_header():
