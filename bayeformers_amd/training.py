@@ -199,8 +199,9 @@ def grad_norm(tensors: List[Tensor]) -> Tensor:
     by_dtype = {}
     for t in tensors:
         by_dtype.setdefault(t.dtype, []).append(t)
-    norms = [n.float() for ts in by_dtype.values() for n in torch._foreach_norm(ts)]
-    return torch.linalg.vector_norm(torch.stack(norms))
+    # (one stack + one cast per dtype: a .float() per 0-d norm is a launch per gradient tensor)
+    norms = [torch.stack(torch._foreach_norm(ts)).float() for ts in by_dtype.values()]
+    return torch.linalg.vector_norm(torch.cat(norms) if len(norms) > 1 else norms[0])
 
 
 def clip_gradients(optimizer: torch.optim.Optimizer, tensors: List[Tensor], max_norm: float) -> Tensor:
