@@ -162,3 +162,34 @@ def test_repeated_inputs_are_cached_until_the_input_changes():
     y = torch.ones(2, 3, requires_grad=True)
     r = repeat_inputs(y, 3)                            # differentiable inputs are never cached
     assert r.requires_grad and r.shape == (6, 3)
+
+
+def test_graphed_sampler_refuses_what_it_cannot_replay():
+    """No GPU needed: a model in training mode (per-step dropout masks) and host-resident inputs are refused before
+    anything is captured; the sample counter stays on the host."""
+    from bayeformers_amd.sampling import GraphedSampler
+
+    x = torch.randn(4, 5)
+    with pytest.raises(RuntimeError, match="training mode"):
+        GraphedSampler(StubModel().train(), x, 3)
+    with pytest.raises(RuntimeError, match="on the GPU"):
+        GraphedSampler(StubModel().eval(), x, 3)
+    with pytest.raises(RuntimeError, match="on the GPU"):
+        GraphedSampler(StubModel().eval(), {"n": 5}, 3)
+    assert bfr.STATE.device_counter is None
+
+
+def test_local_step_and_finish_are_sample_bayesian():
+    """sample_bayesian = _local_step + _finish_step (what GraphedSampler captures and what it runs after the replay)."""
+    from bayeformers_amd.sampling import _finish_step, _local_step
+
+    m, x = StubModel().eval(), torch.randn(4, 5)
+    bfr.manual_seed(1, next_sample=7)
+    with torch.no_grad():
+        raw, mean, lp, lq = sample_bayesian(m, x, 3)
+    bfr.manual_seed(1, next_sample=7)
+    with torch.no_grad():
+        raw2, sizes, local = _local_step(m, repeat_inputs(x, 3), 3, None, 0, 1, repeated=True)
+        mean2, lp2, lq2 = _finish_step(raw2, sizes, local, 3, None, False)
+    assert torch.equal(raw[0], raw2[0]) and torch.equal(mean[0], mean2[0]) and lp == lp2 and lq == lq2
+    assert len(local) == 1 and local[0].dtype == torch.float64 and local[0].numel() == sizes[0] + 2
