@@ -209,6 +209,9 @@ def elbo(log_prior: Tensor, log_variational_posterior: Tensor, nll: Tensor, n_ba
     return torch.add(nll, log_variational_posterior - log_prior, alpha=1.0 / n_batches)
 
 
+_GRAPH_USERS = {"n": 0, "moved": False}  # open GraphedSamplers; whether the first of them moved the sample counter to the device
+
+
 class GraphedSampler:
     """`sample_bayesian` for ONE batch signature, replayed from a HIP graph (inference / evaluation).
 
@@ -245,17 +248,25 @@ class GraphedSampler:
         # sample axis) and the captured step starts at the model's forward
         self._signature = self._sig(inputs)
         self._rep = self._map(inputs, lambda v: v.repeat(self._s_local, *([1] * (v.dim() - 1))) if v.dim() > 0 else v.clone())
-        self._owns_counter = bfr.STATE.device_counter is None
+        # the captured kernels hold the counter's ADDRESS: it must stay on the device until the last sampler is closed
+        if _GRAPH_USERS["n"] == 0:
+            _GRAPH_USERS["moved"] = bfr.STATE.device_counter is None
+        _GRAPH_USERS["n"] += 1
+        self._open = True
         bfr.use_device_counter(True, device=self.device)
-        self.graph = None
-        with torch.no_grad(), torch.cuda.device(self.device):
-            for _ in range(max(1, int(warmup))):  # plans, workspaces and tile schedules are built outside the capture
-                self._step()
-            torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._static = self._step()
-            self.graph = graph
+        self.graph = self._static = None
+        try:
+            with torch.no_grad(), torch.cuda.device(self.device):
+                for _ in range(max(1, int(warmup))):  # plans, workspaces and tile schedules are built outside the capture
+                    self._step()
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._static = self._step()
+                self.graph = graph
+        except BaseException:
+            self.close()  # a failed capture leaves nothing behind (the counter goes back where it was)
+            raise
 
     # ------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -308,10 +319,13 @@ class GraphedSampler:
         return raw, tuple(means), log_prior, lvp
 
     def close(self) -> None:
-        """Drop the graph and, if this object moved the sample counter to the device, move it back to the host."""
+        """Drop the graph; when the last open sampler closes and the samplers had moved the sample counter to the device,
+        it moves back to the host (advanced by what the replays consumed)."""
         from . import random as bfr
 
         self.graph = self._static = None
-        if self._owns_counter:
-            bfr.use_device_counter(False)
-            self._owns_counter = False
+        if self._open:
+            self._open = False
+            _GRAPH_USERS["n"] -= 1
+            if _GRAPH_USERS["n"] == 0 and _GRAPH_USERS["moved"]:
+                bfr.use_device_counter(False)

@@ -74,3 +74,29 @@ def test_training_mode_is_refused():
     bmodel.train()
     with pytest.raises(RuntimeError, match="training mode"):
         GraphedSampler(bmodel, batches[0], 2)
+
+
+def test_two_samplers_share_the_device_counter_until_the_last_one_closes():
+    """The captured kernels hold the counter's address: closing one sampler must not move the counter back to the host
+    while another one is open; the two draw from ONE sequence of sample indices, like two eager callers."""
+    import bayeformers_amd as bf
+    from bayeformers_amd import random as bfr
+    from bayeformers_amd.sampling import GraphedSampler, sample_bayesian
+
+    bmodel, batches = _build()
+    bf.set_compute_dtype("bf16")
+    bf.manual_seed(SEED)
+    with torch.no_grad():
+        eager = [_host(sample_bayesian(bmodel, batches[0], 2)), _host(sample_bayesian(bmodel, batches[1], 3)),
+                 _host(sample_bayesian(bmodel, batches[1], 3))]
+    a = GraphedSampler(bmodel, batches[0], 2)
+    b = GraphedSampler(bmodel, batches[1], 3)
+    bf.manual_seed(SEED)
+    got_a = _host(a())
+    a.close()
+    assert bfr.STATE.device_counter is not None  # b is still open
+    got_b = [_host(b()), _host(b())]
+    b.close()
+    assert bfr.STATE.device_counter is None and bfr.get_state()[1] == 2 + 3 + 3
+    for got, want in zip([got_a] + got_b, eager):
+        assert np.array_equal(got[0], want[0]) and got[2] == want[2] and got[3] == want[3]
