@@ -112,13 +112,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         x_bytes = (unsigned)M * (unsigned)K * 2u;
     };
     // one 1 KiB piece: `base` (a buffer of `bytes`) + per-lane byte offset `off` + wave-uniform byte offset `soff` -> LDS `dst`
-    auto piece = [&](const T* base, unsigned bytes, unsigned off, int soff, char* dst) {
-#ifdef BF_DEV
-        if (p.flags & 1) return;  // ablation: no DMA in the k-loop
+#ifndef BF_R5_AUX_X
+#define BF_R5_AUX_X 0  // cache policy bits of the x / W pieces (1 = sc0, 2 = nt, 16 = sc1): experiment, see DESIGN.md 4.2b
 #endif
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)bytes, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, (int)off, soff, 0, 0);
-    };
+#ifndef BF_R5_AUX_W
+#define BF_R5_AUX_W 0
+#endif
+#ifdef BF_DEV
+#define BF_R5_PIECE_GUARD if (p.flags & 1) return;  /* ablation: no DMA in the k-loop */
+#else
+#define BF_R5_PIECE_GUARD
+#endif
+#define BF_R5_PIECE(NAME, AUX)                                                                                              \
+    auto NAME = [&](const T* base, unsigned bytes, unsigned off, int soff, char* dst) {                                     \
+        BF_R5_PIECE_GUARD                                                                                                   \
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)bytes, 0x00020000); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, (int)off, soff, 0, AUX);                            \
+    }
+    BF_R5_PIECE(piece_x, BF_R5_AUX_X);
+    BF_R5_PIECE(piece_w, BF_R5_AUX_W);
+#undef BF_R5_PIECE
+#undef BF_R5_PIECE_GUARD
     // segmented contraction: k-step kt lies in segment kt / (K / TK) (wave-uniform arithmetic)
     auto segment = [&](int& kt) -> int {
         if constexpr (SEG) {
@@ -146,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         const T* xs = SEG ? xb + (long long)seg * p.x_seg_stride : xb;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i >= lo && i < hi && (i * 8 + 7 < h4 || i * 8 + wid < h4)) piece(xs, x_bytes, xo + i * rowblk, kt * (TK * 2), base + i * 8192);
+            if (i >= lo && i < hi && (i * 8 + 7 < h4 || i * 8 + wid < h4)) piece_x(xs, x_bytes, xo + i * rowblk, kt * (TK * 2), base + i * 8192);
     };
     auto issue_w = [&](int kt, int slot, int lo = 0, int hi = 4) {
 #ifdef BF_DEV
@@ -158,8 +172,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i < lo || i >= hi) continue;
-            if constexpr (TRW) piece(ws, w_bytes, wo, (kt * TK + i * 16) * N * 2, base + i * 8192);
-            else piece(ws, w_bytes, wo + i * rowblk, kt * (TK * 2), base + i * 8192);
+            if constexpr (TRW) piece_w(ws, w_bytes, wo, (kt * TK + i * 16) * N * 2, base + i * 8192);
+            else piece_w(ws, w_bytes, wo + i * rowblk, kt * (TK * 2), base + i * 8192);
         }
     };
 
