@@ -269,16 +269,16 @@ _ATTENTION_NAME = "bayeformers_amd"
 def _attention_interface(module, query, key, value, attention_mask, dropout: float = 0.0, scaling=None, **kwargs):
     """Attention function in the HuggingFace `AttentionInterface` convention: query/key/value [B, H, T, D], returns
     ([B, T, H, D], None).  Runs bf_attention_fwd (with bf_attention_bwd as its backward when a gradient is needed) when
-    it applies (no dropout, head size 64, T a multiple of 128, no mask or a key-padding mask); anything else goes to the
+    it applies (head size 64, T a multiple of 128, no mask or a key-padding mask; attention_probs_dropout runs inside the
+    kernels on the Philox keep-mask of csrc/bf_philox.h); anything else goes to the
     framework's scaled-dot-product attention."""
     from transformers.integrations.sdpa_attention import sdpa_attention_forward
 
     from . import ops
 
     need_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
-    # attention_probs_dropout (training mode) runs inside the kernels; its backward exists for one-tile sequences (T = 128)
-    usable = (not kwargs.get("is_causal", False) and ops.attention_supported(query, key, value)
-              and (dropout == 0.0 or not need_grad or query.shape[2] == 128))
+    # attention_probs_dropout (training mode) runs inside the kernels, forward and backward, for any supported length
+    usable = not kwargs.get("is_causal", False) and ops.attention_supported(query, key, value)
     key_mask = mask_off = None
     ready = getattr(attention_mask, "_bf_key_mask", None) if attention_mask is not None else None
     if usable and ready is not None and ready.shape == (query.shape[0], query.shape[2]):

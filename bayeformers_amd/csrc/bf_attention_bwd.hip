@@ -110,7 +110,7 @@ __device__ __forceinline__ typename Mfma<T>::frag pack2(const f32x4_t a, const f
 }
 
 // ---------------------------------------------------------------------------------------------------- dQ (+ delta)
-template <typename T>
+template <typename T, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void attention_bwd_dq_kernel(const BwdParams p) {
     using frag = typename Mfma<T>::frag;
     using half4 = typename Mfma<T>::half4;
@@ -170,6 +170,11 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dq_kernel(const BwdParam
         __syncthreads();
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
+            // DROP: the lane's 32 probabilities of this (query, key tile) are the 32 bits of ONE keep word, in the
+            // forward's own layout (word (query, key tile, lg), bit 4 kbk + j) — loaded ahead of the products
+            uint32_t kw = 0;
+            if constexpr (DROP)
+                kw = p.keep_bits[((((long long)b * p.H + h) * p.T + (q0 + qi * 16 + li)) * (p.T / TT) + key0 / TT) * 4 + lg];
             // S^T and dP^T [key][query]: lane (query li, group lg) holds keys kbk*16 + 4 lg + 0..3 of each block
             f32x4_t s[8], dp[8];
 #pragma unroll
@@ -188,7 +193,12 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dq_kernel(const BwdParam
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float pr = __builtin_amdgcn_exp2f(fmaf(s[kbk][j], p.scale_log2e, mk[j]) - lse[qi]);
-                    s[kbk][j] = pr * (dp[kbk][j] - delta[qi]);  // dS^T
+                    if constexpr (DROP) {
+                        const float m = ((kw >> (kbk * 4 + j)) & 1u) ? p.inv_keep : 0.f;
+                        s[kbk][j] = pr * (dp[kbk][j] * m - delta[qi]);  // dS^T = P o (keep / (1 - p) o dP~ - delta)
+                    } else {
+                        s[kbk][j] = pr * (dp[kbk][j] - delta[qi]);  // dS^T
+                    }
                 }
             }
             // dQ^T[d][query] += K^T[d][k] dS^T[k][query], k walking 32 keys at a time in the order the blocks give
@@ -213,23 +223,27 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dq_kernel(const BwdParam
 
 // ---------------------------------------------------------------------------------------------------- dK, dV
 // 8 waves, each owning 16 keys of the workgroup's 128 (32 keys per wave need 117 spilled registers).
-template <typename T>
+template <typename T, bool DROP = false>
 __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdParams p) {
     using frag = typename Mfma<T>::frag;
     using half4 = typename Mfma<T>::half4;
-    __shared__ __attribute__((aligned(16))) char smem[2 * S_BYTES + 2 * P_BYTES + 2 * TT * 4];
+    __shared__ __attribute__((aligned(16))) char smem[2 * S_BYTES + 2 * P_BYTES + 2 * TT * 4 + (DROP ? TT * 16 : 0)];
     char* const qs = smem;                               // Q, swizzled: row operand of S
     char* const dos = smem + S_BYTES;                    // dO, swizzled: row operand of dP
     char* const qp = smem + 2 * S_BYTES;                 // Q, padded: Q^T through the transpose read
     char* const dop = smem + 2 * S_BYTES + P_BYTES;      // dO, padded: dO^T through the transpose read
     float* const lse_s = reinterpret_cast<float*>(smem + 2 * S_BYTES + 2 * P_BYTES);
     float* const del_s = lse_s + TT;
+    uint32_t* const keep_s = reinterpret_cast<uint32_t*>(del_s + TT);  // DROP: [128 queries][4 lg] keep words of this (query tile, key tile)
     const float* const mask = (p.mask && !(p.mask_off && *p.mask_off)) ? p.mask : nullptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
     const int h = blockIdx.y, b = blockIdx.z;
     const long long key = blockIdx.x * TT + wid * 16 + li;
+    // DROP: this lane's key sits in word (query, key tile, lg_f) at one fixed bit (the forward's layout)
+    const int key_i = wid * 16 + li;
+    const int keep_word = (key_i >> 2) & 3, keep_bit = ((key_i >> 5) << 3) | (((key_i >> 4) & 1) << 2) | (key_i & 3);
     const long long hoff = (long long)h * HD;
     const T* qb = reinterpret_cast<const T*>(p.q) + (long long)b * p.T * p.tok_stride + hoff;
     const T* kb = reinterpret_cast<const T*>(p.k) + (long long)b * p.T * p.tok_stride + hoff;
@@ -259,6 +273,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
             *reinterpret_cast<f32x4_t*>(lse_s + tid * 4) = *reinterpret_cast<const f32x4_t*>(lse_g + q0 + tid * 4);
             *reinterpret_cast<f32x4_t*>(del_s + tid * 4) = *reinterpret_cast<const f32x4_t*>(del_g + q0 + tid * 4);
         }
+        if constexpr (DROP)  // 512 words = 128 queries x 4 groups of this tile pair
+            keep_s[tid] = p.keep_bits[((((long long)b * p.H + h) * p.T + q0 + (tid >> 2)) * (p.T / TT) + blockIdx.x) * 4 + (tid & 3)];
         __syncthreads();
         // S and dP [query][key]: lane (key li, group lg) holds queries qbk*16 + 4 lg + 0..3 of each block
         f32x4_t s[8], dp[8];
@@ -278,8 +294,15 @@ __global__ __launch_bounds__(512, 2) void attention_bwd_dkv_kernel(const BwdPara
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float pr = __builtin_amdgcn_exp2f(fmaf(s[qbk][j], p.scale_log2e, mk) - l4[j]);
-                s[qbk][j] = pr;                          // P
-                dp[qbk][j] = pr * (dp[qbk][j] - d4[j]);  // dS
+                if constexpr (DROP) {
+                    const uint32_t wrd = keep_s[(qbk * 16 + lg * 4 + j) * 4 + keep_word];
+                    const float m = ((wrd >> keep_bit) & 1u) ? p.inv_keep : 0.f;
+                    s[qbk][j] = pr * m;                          // P~ = P o keep / (1 - p)
+                    dp[qbk][j] = pr * (dp[qbk][j] * m - d4[j]);  // dS
+                } else {
+                    s[qbk][j] = pr;                          // P
+                    dp[qbk][j] = pr * (dp[qbk][j] - d4[j]);  // dS
+                }
             }
         }
         // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
@@ -505,10 +528,17 @@ int bf_launch_attention_bwd(const void* d_q, const void* d_k, const void* d_v, c
     p.inv_keep = inv_keep;
     const dim3 grid(T / TT, H, B);
     if (d_keep_bits) {
-        if (T != TT) BF_FAIL("bf_attention_bwd: dropout is supported for one-tile sequences only (T = %d, got %d)", TT, T);
         if ((uintptr_t)d_keep_bits & 3) BF_FAIL("bf_attention_bwd: keep bits must be 4-byte aligned");
-        if (dtype == BF_DT_BF16) hipLaunchKernelGGL((attention_bwd_tile_kernel<__bf16, true>), grid, dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL((attention_bwd_tile_kernel<_Float16, true>), grid, dim3(512), 0, stream, p);
+        if (T == TT) {
+            if (dtype == BF_DT_BF16) hipLaunchKernelGGL((attention_bwd_tile_kernel<__bf16, true>), grid, dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL((attention_bwd_tile_kernel<_Float16, true>), grid, dim3(512), 0, stream, p);
+        } else if (dtype == BF_DT_BF16) {
+            hipLaunchKernelGGL((attention_bwd_dq_kernel<__bf16, true>), grid, dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((attention_bwd_dkv_kernel<__bf16, true>), grid, dim3(512), 0, stream, p);
+        } else {
+            hipLaunchKernelGGL((attention_bwd_dq_kernel<_Float16, true>), grid, dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((attention_bwd_dkv_kernel<_Float16, true>), grid, dim3(512), 0, stream, p);
+        }
         BF_HIP_CHECK(hipGetLastError());
         return 0;
     }

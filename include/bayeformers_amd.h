@@ -314,7 +314,7 @@ int bf_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const fl
  *   probability (b, h, q, key): g = (((b*H + h)*T + q) * (T/32) + (key/128)*4 + c) * 4 + lg, field e*4 + j, where
  *   key % 128 = (2c + e)*16 + 4 lg + j.  d_keep_bits (nullable; needed by the backward): [B][H][T][T/32] words, word
  *   (b, h, q, key/128, lg), bit c*8 + e*4 + j.
- * bf_attention_bwd_dropout: bf_attention_bwd for that forward; sequences of ONE tile (T = 128) only.
+ * bf_attention_bwd_dropout: bf_attention_bwd for that forward (any supported T; d_keep_bits as the forward wrote them).
  * bf_add_layernorm_dropout: LayerNorm(dropout(x) + residual); group of element (row, n): row * (N/8) + n/8, field n % 8.
  * bf_add_layernorm_dropout_bwd: its backward; d_dz = gradient of the residual, d_dx = d_dz o keep / (1 - p). */
 int bf_dropout_keep_host(uint8_t* out, uint64_t first_group, uint64_t n_groups, float p_drop, uint64_t seed, uint32_t call,
