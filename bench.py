@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — MC-samples/sec (fwd+ELBO) of the MI355X Monte-Carlo variational forward path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bert_base|linear768|linear768_m32|mlp]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bert_base|bert_large_qa|bert_base_train|bert_large_qa_train|linear768|linear768_m32|mlp]
 
 With --gpus N > 1 and no torch.distributed environment (WORLD_SIZE unset) this process only LAUNCHES the job: it starts
 `python -m torch.distributed.run --nproc-per-node N ... bench.py <same flags>` as a child process (it never touches a
@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="bert_base", choices=["bert_base", "bert_large_qa", "linear768", "linear768_m32", "mlp", "bert_base_train"])
+    ap.add_argument("--workload", default="bert_base", choices=["bert_base", "bert_large_qa", "linear768", "linear768_m32", "mlp", "bert_base_train", "bert_large_qa_train"])
     ap.add_argument("--samples", type=int, default=None, help="MC samples per GPU per step (default: workload's)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--strong", action="store_true",
@@ -244,8 +244,10 @@ def make_bert(device, S, dtype, train=False, train_mode=False):
     return step, cpu_baseline, cfgd, bmodel
 
 
-def make_bert_large_qa(device, S, dtype):
-    """BASELINE config 5: to_bayesian(BERT-large QA) SQuAD-shaped forward + ELBO, seq=384, batch=16."""
+def make_bert_large_qa(device, S, dtype, train=False, train_mode=False):
+    """BASELINE config 5: to_bayesian(BERT-large QA) SQuAD-shaped forward + ELBO, seq=384, batch=16.  train: the training
+    step of the reference's SQuAD loop (examples/bert_squad.py:456-491: forward of S samples, ELBO with the mean of the
+    start / end cross-entropies, backward, clip_grad_norm_(1), AdamW) on the same batch."""
     import bayeformers_amd as bf
     from bayeformers_amd.sampling import elbo, sample_bayesian
     from transformers import BertConfig, BertForQuestionAnswering
@@ -277,10 +279,27 @@ def make_bert_large_qa(device, S, dtype):
             return elbo(lp, lq, nll.double(), n_batches)
 
     step.harness = harness
+    if train:
+        from bayeformers_amd.training import GradientBuckets, training_step
+
+        if train_mode:
+            bmodel.train()
+        params = [p for p in bmodel.parameters() if p.requires_grad]
+        opt = torch.optim.AdamW(params, lr=3e-5, eps=1e-8, weight_decay=0.0, fused=True)
+        buckets = GradientBuckets(params) if _ranks() > 1 else None
+
+        def nll_fn(mean):
+            ce = torch.nn.functional.cross_entropy
+            return 0.5 * (ce(mean[0].float(), sp) + ce(mean[1].float(), ep))
+
+        def step():  # noqa: F811
+            return training_step(bmodel, inputs, S * _world(), nll_fn, opt, n_batches, buckets=buckets, max_grad_norm=1.0)
 
     def cpu_baseline():
         from oracle.model_oracle import log_probs, to_oracle
 
+        if train:
+            return None
         omodel = to_oracle(model, delta=0.05).eval()
         mask = torch.ones(B, L, dtype=torch.long)
 
@@ -292,7 +311,11 @@ def make_bert_large_qa(device, S, dtype):
         best, times, sweep = timed_cpu(one_sample, 2)
         return cpu_line(1, times, best, sweep, "serial MC samples (fwd + log-probs) of the same BERT-large B=16 L=384 batch")
 
-    cfgd = {"workload": "to_bayesian(BERT-large QA, delta=0.05, freeze=True) fwd+ELBO", "samples_per_gpu": S, "batch": B,
+    what = "fwd+ELBO"
+    if train:
+        what = ("training step: fwd+ELBO+backward+clip+AdamW, " +
+                ("model.train(): HF dropout 0.1 inside the fused kernels" if train_mode else "dropout off (--no-dropout)"))
+    cfgd = {"workload": f"to_bayesian(BERT-large QA, delta=0.05, freeze=True) {what}", "samples_per_gpu": S, "batch": B,
             "allreduce_values": 2 * B * L + 2,
             "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "gelu_fused_into_gemm": n_fused,
             "residual_layernorm_fused": n_ln, "qkv_in_one_launch": n_qkv,
@@ -694,7 +717,7 @@ def main():
     if args.calibrate_traffic:
         cal_shapes, cal_m, cal_dt = bert_gemm_shapes(args.workload)
         calibration_probes(device, cal_shapes, S=args.samples or 10, M=cal_m or 4096, dtype=cal_dt or torch.bfloat16)
-    defaults = {"bert_base": (10, "bf16"), "bert_base_train": (10, "bf16"), "bert_large_qa": (10, "fp16"), "linear768": (10, "bf16"), "linear768_m32": (10, "bf16"), "mlp": (5, "bf16")}
+    defaults = {"bert_base": (10, "bf16"), "bert_base_train": (10, "bf16"), "bert_large_qa": (10, "fp16"), "bert_large_qa_train": (10, "bf16"), "linear768": (10, "bf16"), "linear768_m32": (10, "bf16"), "mlp": (5, "bf16")}
     S = args.samples or defaults[args.workload][0]
     dtype = args.dtype or defaults[args.workload][1]
     bf.set_compute_dtype(dtype)
@@ -705,6 +728,8 @@ def main():
         step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype, train=True, train_mode=not args.no_dropout)
     elif args.workload == "bert_large_qa":
         step, cpu_baseline, cfgd, bmodel = make_bert_large_qa(device, S, dtype)
+    elif args.workload == "bert_large_qa_train":
+        step, cpu_baseline, cfgd, bmodel = make_bert_large_qa(device, S, dtype, train=True, train_mode=not args.no_dropout)
     elif args.workload == "linear768":
         step, cpu_baseline, cfgd, bmodel = make_linear(device, S, dtype, 4096)
     elif args.workload == "linear768_m32":
