@@ -77,7 +77,12 @@ struct AttnParams {
 };
 
 template <typename T, bool DROP = false>
-__global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams p) {
+#ifndef BF_ATTN_DROP_WGS
+#define BF_ATTN_DROP_WGS 3  // workgroups per CU the DROP instantiation is compiled for.  At 3 it spills 12 registers (168 VGPRs + 48 B
+// of scratch), at 2 it does not (178 VGPRs); measured back to back, same box: 69.9 vs 72.0 us at the BERT-base shape, 278 vs
+// 304 us at 160 x 16 heads x 384 tokens — the third workgroup is worth more than the spills cost.
+#endif
+__global__ __launch_bounds__(256, DROP ? BF_ATTN_DROP_WGS : 3) void attention_fwd_kernel(const AttnParams p) {
     using frag = typename Mfma<T>::frag;
     using half4 = typename Mfma<T>::half4;
     __shared__ __attribute__((aligned(16))) char smem[K_BYTES + V_BYTES + TKEY * 4];
