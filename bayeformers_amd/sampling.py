@@ -167,7 +167,7 @@ def _finish_step(raw, sizes, local, samples: int, group, distributed: bool):
 
 
 def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callable] = None,
-                    group: Optional["dist.ProcessGroup"] = None, gather_raw: bool = False
+                    group: Optional["dist.ProcessGroup"] = None, gather_raw: bool = False, graph: bool = False
                     ) -> Tuple[Tuple[Tensor, ...], Tuple[Tensor, ...], Tensor, Tensor]:
     """Run `samples` Monte-Carlo forwards of `model` as one batched forward.
 
@@ -184,7 +184,16 @@ def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callabl
         raw   tuple of [S_local, B, ...] per-sample outputs of this rank, S_local = shard_span(...)[1] (all S if gather_raw),
         mean  tuple of [B, ...] means over ALL S samples,
         log_prior, log_variational_posterior: 0-d float64 means over ALL S samples.
+    graph: evaluation loops — replay the step from a HIP graph (`GraphedSampler`, kept for the last two batch signatures of
+        this model; results are the graph's buffers, valid until the next call with the same signature).  Needs no_grad /
+        inference mode and a model in eval mode; not combined with gather_raw.
     """
+    if graph:
+        if gather_raw:
+            raise ValueError("sample_bayesian: graph=True does not gather the ranks' raw outputs")
+        if torch.is_grad_enabled():
+            raise RuntimeError("sample_bayesian: graph=True replays a captured forward — call it under torch.no_grad()")
+        return _graphed(model, inputs, samples, select, group)
     distributed, rank, world = _shard_group(group)
     raw, sizes, local = _local_step(model, inputs, samples, select, rank, world)
     means, log_prior, lvp = _finish_step(raw, sizes, local, samples, group, distributed)
@@ -202,6 +211,23 @@ def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callabl
             gathered.append(torch.cat([part[:c] for part, c in zip(parts, counts)], 0))
         raw = tuple(gathered)
     return raw, tuple(means), log_prior, lvp
+
+
+_GRAPHED_KEEP = 2  # GraphedSamplers kept per model by sample_bayesian(graph=True): the last two batch signatures
+
+
+def _graphed(model: Model, inputs, samples: int, select, group):
+    cache = model.__dict__.setdefault("_bf_graphed", [])  # [(key, sampler)], most recent last
+    key = (GraphedSampler._sig(inputs), int(samples), select, group)
+    for i, (k, sampler) in enumerate(cache):
+        if k == key and sampler.graph is not None:
+            cache.append(cache.pop(i))
+            return sampler(inputs)
+    while len(cache) >= _GRAPHED_KEEP:
+        cache.pop(0)[1].close()
+    sampler = GraphedSampler(model, inputs, samples, select=select, group=group)
+    cache.append((key, sampler))
+    return sampler()
 
 
 def elbo(log_prior: Tensor, log_variational_posterior: Tensor, nll: Tensor, n_batches: int) -> Tensor:

@@ -100,3 +100,34 @@ def test_two_samplers_share_the_device_counter_until_the_last_one_closes():
     assert bfr.STATE.device_counter is None and bfr.get_state()[1] == 2 + 3 + 3
     for got, want in zip([got_a] + got_b, eager):
         assert np.array_equal(got[0], want[0]) and got[2] == want[2] and got[3] == want[3]
+
+
+def test_sample_bayesian_graph_flag_caches_two_signatures():
+    """sample_bayesian(graph=True): the evaluation-loop form — a sampler per batch signature, the last two kept with the model;
+    a replay equals the eager call from the same counter, needs no_grad."""
+    import bayeformers_amd as bf
+    from bayeformers_amd import random as bfr
+    from bayeformers_amd.sampling import sample_bayesian
+
+    bmodel, batches = _build()
+    bf.set_compute_dtype("bf16")
+    with pytest.raises(RuntimeError, match="no_grad"):
+        sample_bayesian(bmodel, batches[0], 2, graph=True)
+    with torch.no_grad():
+        sample_bayesian(bmodel, batches[0], 2, graph=True)  # captures
+        first = bmodel._bf_graphed[0][1]
+        bf.manual_seed(SEED)
+        got = _host(sample_bayesian(bmodel, batches[1], 2, graph=True))  # same signature: the cached sampler, new batch
+        assert len(bmodel._bf_graphed) == 1 and bmodel._bf_graphed[0][1] is first
+        bf.manual_seed(SEED)
+        want = _host(sample_bayesian(bmodel, batches[1], 2))
+        assert np.array_equal(got[0], want[0]) and got[2] == want[2] and got[3] == want[3]
+        small = {k: v[:2].clone() for k, v in batches[0].items()}
+        tiny = {k: v[:1].clone() for k, v in batches[0].items()}
+        sample_bayesian(bmodel, small, 2, graph=True)
+        sample_bayesian(bmodel, tiny, 2, graph=True)
+        assert len(bmodel._bf_graphed) == 2 and first.graph is None  # the oldest signature was closed
+        for _, s in bmodel._bf_graphed:
+            s.close()
+        bmodel._bf_graphed.clear()
+    assert bfr.STATE.device_counter is None
