@@ -334,6 +334,9 @@ class GraphedSampler:
     def __call__(self, inputs=None):
         if self.graph is None:
             raise RuntimeError("GraphedSampler: closed")
+        if self.model.training:
+            raise RuntimeError("GraphedSampler: the model was switched to training mode after the capture; the captured "
+                               "forward is the evaluation one — call model.eval(), or build a new sampler")
         if inputs is not None:
             self.load(inputs)
         self.graph.replay()
