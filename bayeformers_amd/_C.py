@@ -20,6 +20,9 @@ class bf_prior_t(ctypes.Structure):
         ("sigma2", ctypes.c_float),
         ("d_mu", ctypes.c_void_p),
         ("d_rho", ctypes.c_void_p),
+        ("d_pi", ctypes.c_void_p),      # mixture: the device scalars pi / sigma1 / sigma2 were read from (re-checked by
+        ("d_sigma1", ctypes.c_void_p),  # the kernels, bf_stale_counter)
+        ("d_sigma2", ctypes.c_void_p),
     ]
 
 
@@ -42,6 +45,7 @@ _tp = ctypes.POINTER(bf_tensor_t)
 SYMBOLS = {
     "bf_version": (_i, []),
     "bf_last_error": (ctypes.c_char_p, []),
+    "bf_stale_counter": (_i, [ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32))]),
     "bf_set_sample_counter": (_i, [_vp]),
     "bf_get_sample_counter": (_vp, []),
     "bf_device_info": (_i, [ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
@@ -100,7 +104,7 @@ SYMBOLS = {
 BF_PROF_SAMPLE, BF_PROF_GEMM, BF_PROF_FUSED_SMALL, BF_PROF_FUSED_WS = 0, 1, 2, 3
 BF_ACT_NONE, BF_ACT_GELU = 0, 1
 
-ABI_VERSION = 4  # bf_version() of the library these bindings describe (include/bayeformers_amd.h: BF_VERSION_*)
+ABI_VERSION = 5  # bf_version() of the library these bindings describe (include/bayeformers_amd.h: BF_VERSION_*)
 
 # developer-build entry points (csrc/bf_dev_api.h): bound when the loaded library has them (BF_LIB_PATH=..._dev.so)
 DEV_SYMBOLS = {
@@ -139,6 +143,21 @@ def lib():
                 "`python -m bayeformers_amd.build`")
         _lib = l
     return _lib
+
+
+_stale = None
+
+
+def stale_counter() -> int:
+    """Current value of the library's stale-prior counter (bf_stale_counter): a host-memory word the kernels bump when a
+    prior's baked constants fail their device-side re-check.  Reading it does not synchronise."""
+    global _stale
+    if _stale is None:
+        p = ctypes.POINTER(ctypes.c_uint32)()
+        if lib().bf_stale_counter(ctypes.byref(p)) != 0:
+            return 0  # no HIP device in this process (host-only tests): nothing can have bumped it
+        _stale = p
+    return int(_stale[0])
 
 
 def check(rc, what):

@@ -19,10 +19,11 @@ from .nn.model import Model
 from .nn.parameters.base import Parameter
 from .nn.parameters.gaussian import DEFAULT_SCALED_GAUSSIAN_MIXTURE
 from .nn.parameters.initializations import DEFAULT_UNIFORM, Initialization
+from .ops import invalidate_caches  # noqa: F401
 from .random import (get_compute_dtype, manual_seed, set_compute_dtype, set_kl_gradient,  # noqa: F401
                      use_device_counter)
 
-__all__ = ["to_bayesian", "fuse_activations", "fuse_residual_layernorm", "fuse_shared_inputs", "fuse_attention", "fuse_embeddings", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
+__all__ = ["to_bayesian", "invalidate_caches", "fuse_activations", "fuse_residual_layernorm", "fuse_shared_inputs", "fuse_attention", "fuse_embeddings", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
            "use_device_counter", "set_kl_gradient"]
 
 

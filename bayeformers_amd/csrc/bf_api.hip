@@ -101,6 +101,23 @@ __global__ __launch_bounds__(256) void bf_probe_read_kernel(const uint4* __restr
     if (acc == 0x9E3779B9u) *sink = acc;  // never true for the buffers bench.py fills; keeps the loads alive
 }
 
+// the stale-prior counter: one pinned, device-mapped word for the process (bf_stale_counter)
+static uint32_t* g_stale_host = nullptr;
+static uint32_t* g_stale_dev = nullptr;
+static std::once_flag g_stale_once;
+uint32_t* bf_stale_counter_dev() {
+    std::call_once(g_stale_once, [] {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return; }
+        *reinterpret_cast<uint32_t*>(h) = 0;
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+        g_stale_host = reinterpret_cast<uint32_t*>(h);
+        g_stale_dev = reinterpret_cast<uint32_t*>(d);
+    });
+    return g_stale_dev;
+}
+
 extern "C" {
 
 int bf_profile_enable(int on) {
@@ -139,6 +156,13 @@ int bf_profile_read(int kind, uint64_t* launches, double* total_ms, double* tota
 }
 
 int bf_version(void) { return BF_VERSION_MAJOR * 1000 + BF_VERSION_MINOR; }
+
+int bf_stale_counter(const uint32_t** h_counter) {
+    if (!h_counter) BF_FAIL("bf_stale_counter: h_counter is NULL");
+    if (!bf_stale_counter_dev()) BF_FAIL("bf_stale_counter: the pinned counter could not be allocated");
+    *h_counter = g_stale_host;
+    return 0;
+}
 
 // Measurement utility (bench.py's traffic leg): one streaming pass of 16-byte loads over `bytes` of device memory, the
 // access shape of the GEMM's LDS-DMA pieces and of the sampling kernel's parameter reads.  Run under a PMC pass it

@@ -325,6 +325,8 @@ struct KlParams {
     int S;
     uint32_t k0, k1, sample_base, stream;
     const uint32_t* counter;
+    bf_prior_check_t chk;  // mixture constants against the device scalars they were read from (bf_prior_t)
+    uint32_t* stale;       // bf_stale_counter
 };
 
 __global__ __launch_bounds__(256) void kl_grad_kernel(const KlParams p) {
@@ -373,9 +375,11 @@ __global__ __launch_bounds__(256) void kl_grad_kernel(const KlParams p) {
             ar[i] += gp * score * z[i] - gq / sg[i];
         }
     }
+    const bool stale = bf_prior_check_failed(p.chk);  // stale constants: the gradient is poisoned, the host is told
+    if (stale && g == 0) bf_stale_bump(p.stale);
     for (int i = 0; i < nv; ++i) {
-        if (p.dmu) p.dmu[e0 + i] = am[i];
-        p.drho[e0 + i] = ar[i] * dsp[i];
+        if (p.dmu) p.dmu[e0 + i] = stale ? __builtin_nanf("") : am[i];
+        p.drho[e0 + i] = stale ? __builtin_nanf("") : ar[i] * dsp[i];
     }
 }
 
@@ -499,6 +503,8 @@ int bf_launch_kl_grad(const bf_tensor_t* t, int S, uint64_t seed, uint32_t sampl
     p.g = d_g; p.dmu = d_dmu; p.drho = d_drho; p.n = t->n; p.prior = t->prior.kind; p.S = S;
     p.k0 = (uint32_t)seed; p.k1 = (uint32_t)(seed >> 32); p.sample_base = sample_base; p.stream = t->stream_id;
     p.counter = bf_sample_counter();
+    p.chk = bf_prior_check_of(t->prior);
+    p.stale = bf_stale_counter_dev();
     if (p.prior == BF_PRIOR_MIXTURE) {
         const double pi = t->prior.pi, s1 = t->prior.sigma1, s2 = t->prior.sigma2;
         if (!(s1 > 0.0) || !(s2 > 0.0) || !(pi >= 0.0) || !(pi <= 1.0)) BF_FAIL("bf_kl_grad: bad mixture prior");

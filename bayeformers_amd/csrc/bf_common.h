@@ -36,6 +36,34 @@ static inline size_t bf_dtype_size(int dt) { return dt == BF_DT_F32 ? 4 : 2; }
 // optional device-resident Monte-Carlo sample counter (bf_set_sample_counter): kernels add *counter to sample_base
 const uint32_t* bf_sample_counter();
 
+// device-visible address of the stale-prior counter (bf_stale_counter; pinned host memory), NULL if it could not be set up
+uint32_t* bf_stale_counter_dev();
+
+// A prior's baked constants against the device scalars they were read from (bf_prior_t.d_pi / d_sigma1 / d_sigma2): true =
+// they differ (the module's tensors were edited in place behind the host's back).
+struct bf_prior_check_t {
+    const float* p[3];
+    float v[3];
+};
+static inline bf_prior_check_t bf_prior_check_of(const bf_prior_t& pr) {
+    bf_prior_check_t c{};
+    if (pr.kind == BF_PRIOR_MIXTURE && pr.d_pi && pr.d_sigma1 && pr.d_sigma2) {
+        c.p[0] = pr.d_pi; c.p[1] = pr.d_sigma1; c.p[2] = pr.d_sigma2;
+        c.v[0] = pr.pi; c.v[1] = pr.sigma1; c.v[2] = pr.sigma2;
+    }
+    return c;
+}
+__device__ __forceinline__ bool bf_prior_check_failed(const bf_prior_check_t& c) {
+    if (!c.p[0]) return false;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bad |= __float_as_uint(*c.p[i]) != __float_as_uint(c.v[i]);
+    return bad;
+}
+__device__ __forceinline__ void bf_stale_bump(uint32_t* counter) {
+    if (counter) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // internal launchers (defined in bf_sample.hip / bf_gemm.hip), all asynchronous on `stream`
 int bf_launch_philox_normal(float* d_out, uint64_t n, int S, uint64_t seed, uint32_t sample_base, uint32_t stream_id,
                             hipStream_t stream);

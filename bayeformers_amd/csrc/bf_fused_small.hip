@@ -42,6 +42,8 @@ struct FusedParams {
     int prior_w, prior_b;
     int M, N, K, S;
     uint32_t k0, k1, sample_base, stream_w, stream_b;
+    bf_prior_check_t chk_w, chk_b;  // mixture constants against the device scalars they were read from (bf_prior_t)
+    uint32_t* stale;                // bf_stale_counter
 };
 
 template <typename T>
@@ -256,6 +258,10 @@ __global__ __launch_bounds__(NW * 64) void fused_small_kernel(const FusedParams 
                 tp += (double)lpsum[w][0];
                 tq += (double)lpsum[w][1];
             }
+            if (bf_prior_check_failed(p.chk_w) || bf_prior_check_failed(p.chk_b)) {  // stale constants: poison, report
+                tp = (double)__builtin_nanf("");
+                bf_stale_bump(p.stale);
+            }
             double* row = p.partials + ((size_t)blockIdx.x * p.S + s) * 2;
             row[0] = tp;
             row[1] = tq;
@@ -346,6 +352,9 @@ int bf_launch_fused_small(const void* d_x, int x_dtype, int64_t x_sample_stride,
     p.rho_pw = weight->prior.d_rho;
     p.prior_w = weight->prior.kind;
     if (p.prior_w == BF_PRIOR_MIXTURE) mixture_consts(weight->prior, p.a1, p.b1, p.a2, p.b2);
+    p.chk_w = bf_prior_check_of(weight->prior);
+    p.chk_b = bf_prior_check_t{};
+    p.stale = bf_stale_counter_dev();
     p.prior_b = BF_PRIOR_NONE;
     if (bias) {
         p.mu_b = bias->d_mu;
@@ -354,6 +363,7 @@ int bf_launch_fused_small(const void* d_x, int x_dtype, int64_t x_sample_stride,
         p.rho_pb = bias->prior.d_rho;
         p.prior_b = bias->prior.kind;
         if (p.prior_b == BF_PRIOR_MIXTURE) mixture_consts(bias->prior, p.ba1, p.bb1, p.ba2, p.bb2);
+        p.chk_b = bf_prior_check_of(bias->prior);
         p.stream_b = bias->stream_id;
     }
     p.partials = d_partials;

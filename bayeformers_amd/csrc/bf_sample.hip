@@ -58,6 +58,7 @@ struct SegDesc {
     uint32_t block_begin;
     int vec_in;   // mu/rho(/prior) 16B-aligned -> float4 loads on full chunks
     int vec_out;  // out rows aligned for one vector store per thread (n % 4 == 0 and base aligned)
+    float rho_alias;  // asserted alias: the constant value of rho_p (spot-checked)
 };
 
 struct SampleParams {
@@ -71,6 +72,8 @@ struct SampleParams {
     const uint32_t* counter;  // optional device counter added to sample_base
     uint32_t nblk;
     double* partials;  // [nblk][S][2]
+    bf_prior_check_t chk;  // mixture: the device scalars the constants were read from
+    uint32_t* stale;       // bf_stale_counter
 };
 
 
@@ -128,6 +131,9 @@ struct BodyArgs {
     int S, ny;
     uint32_t k0, k1, sample_base;
     double* partial_row;  // this block's [S][2] row of the partials
+    bf_prior_check_t chk;  // mixture constants re-check (p[0] == NULL: none)
+    float rho_alias;       // asserted alias: the constant value of rho_p
+    uint32_t* stale;
 };
 
 // block = 256 threads; a thread owns kGPT groups of 4 consecutive scalars (group j of thread t = group j*256 + t of the
@@ -175,6 +181,24 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][k
                     pinv[j][i] = 0.5f * __builtin_amdgcn_rcpf(sp * sp);
                     if (i < nvalid[j]) constp += -kLogSqrt2Pi - log_fast(sp);
                 }
+            }
+        }
+    }
+
+    // The prior's baked constants against the device state they are a copy of (bf_prior_t; an in-place edit through .data
+    // leaves no trace on the host): a failed check poisons this block's log-prior partial and bumps the stale counter.
+    if constexpr (PRIOR == BF_PRIOR_MIXTURE) {
+        if (tid == 0 && bf_prior_check_failed(a.chk)) {
+            constp = __builtin_nanf("");
+            bf_stale_bump(a.stale);
+        }
+    }
+    if constexpr (PRIOR == PRIOR_GAUSS_ALIAS) {
+        if (lane == 0 && nvalid[0] > 0) {  // one element per wave: prior.mu == mu and prior.rho == the asserted constant
+            const float m = a.mu_p[e0[0]], r = a.rho_p[e0[0]];
+            if (__float_as_uint(m) != __float_as_uint(mu[0][0]) || __float_as_uint(r) != __float_as_uint(a.rho_alias)) {
+                constp = __builtin_nanf("");
+                bf_stale_bump(a.stale);
             }
         }
     }
@@ -331,6 +355,7 @@ __global__ __launch_bounds__(kThreads) void bf_sample_logprob_kernel(const Sampl
     a.S = p.S; a.ny = p.ny; a.k0 = p.k0; a.k1 = p.k1;
     a.sample_base = p.sample_base + (p.counter ? *p.counter : 0u);
     a.partial_row = p.partials + (size_t)blockIdx.x * p.S * 2;
+    a.chk = p.chk; a.rho_alias = sg.rho_alias; a.stale = p.stale;
     if (si == 0) sample_body<PRIOR, OUT_DT>(a, red, cst);
     else sample_body<PRIOR, BF_DT_F32>(a, red, cst);
 }
@@ -349,6 +374,9 @@ struct TableEntry {
     int prior_kind;
     int out_dt;
     int vec_in, vec_out;
+    bf_prior_check_t chk;  // mixture constants re-check
+    float rho_alias;       // asserted alias: the constant value of rho_p
+    int pad_;
 };
 
 // ONLY >= 0: every tensor of the launch has that (effective) prior kind — the caller says so (bf_sample_logprob_table's
@@ -366,7 +394,7 @@ __global__ __launch_bounds__(kThreads, ONLY >= 0 ? BF_SAMPLE_ONLY_WAVES : 1) voi
                                                                    uint32_t block0, int S, int ny, uint32_t k0,
                                                                    uint32_t k1, uint32_t sample_base,
                                                                    const uint32_t* __restrict__ counter,
-                                                                   double* __restrict__ partials) {
+                                                                   double* __restrict__ partials, uint32_t* stale) {
     __shared__ float red[4][4][kMaxSChunk][2];
     __shared__ float cst[4][2];
     const uint32_t gb = block0 + blockIdx.x;
@@ -379,6 +407,7 @@ __global__ __launch_bounds__(kThreads, ONLY >= 0 ? BF_SAMPLE_ONLY_WAVES : 1) voi
     a.S = S; a.ny = ny; a.k0 = k0; a.k1 = k1;
     a.sample_base = sample_base + (counter ? *counter : 0u);
     a.partial_row = partials + (size_t)gb * S * 2;
+    a.chk = e.chk; a.rho_alias = e.rho_alias; a.stale = stale;
     if constexpr (ONLY >= 0) {
         sample_body<ONLY, OUT_RUNTIME>(a, red, cst);
         return;
@@ -506,8 +535,11 @@ static int launch_group(const bf_tensor_t* tensors, int first, int count, uint32
         const size_t osz = t == 0 ? bf_dtype_size(T.out_dtype) : 4;
         sg.vec_out = T.d_sample_out && ((uintptr_t)T.d_sample_out % (4 * osz)) == 0 && (T.n % 4) == 0;
         sg.block_begin = blk;
+        sg.rho_alias = T.prior.sigma2;
         blk += blocks_for(T.n);
     }
+    p.stale = bf_stale_counter_dev();
+    if (prior_kind == BF_PRIOR_MIXTURE) p.chk = bf_prior_check_of(tensors[first].prior);
     if (prior_kind == BF_PRIOR_MIXTURE) {
         const double pi = tensors[first].prior.pi, s1 = tensors[first].prior.sigma1, s2 = tensors[first].prior.sigma2;
         p.a1 = (float)(-0.5 / (s1 * s1));
@@ -619,7 +651,9 @@ int bf_table_build(const bf_tensor_t* tensors, int n_tensors, void* h_blob, size
             const double sp = T.prior.sigma1;
             e.a1 = (float)(0.5 / (sp * sp));
             e.b1 = (float)(-0.91893853320467274178 - log(sp));
+            e.rho_alias = T.prior.sigma2;
         }
+        e.chk = bf_prior_check_of(T.prior);
         if (h_block_begin) h_block_begin[t] = blk;
         const uint32_t nb = blocks_for(T.n);
         for (uint32_t b = 0; b < nb; ++b) map[blk + b] = (uint32_t)t;
@@ -640,7 +674,8 @@ int bf_launch_sample_table(const void* d_blob, int n_tensors, uint32_t block_beg
     const int ny = pick_ny(blk, S);
 #define BF_TABLE_LAUNCH(ONLY)                                                                                          \
     hipLaunchKernelGGL(bf_sample_table_kernel<ONLY>, dim3(blk, (uint32_t)ny), dim3(kThreads), 0, stream, ent, map,      \
-                       block_begin, S, ny, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, bf_sample_counter(), d_partials)
+                       block_begin, S, ny, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, bf_sample_counter(), d_partials, \
+                       bf_stale_counter_dev())
     if (prior_kinds == (1 << PRIOR_GAUSS_ALIAS)) BF_TABLE_LAUNCH(PRIOR_GAUSS_ALIAS);
     else if (prior_kinds == (1 << BF_PRIOR_MIXTURE)) BF_TABLE_LAUNCH(BF_PRIOR_MIXTURE);
     else BF_TABLE_LAUNCH(-1);
@@ -686,10 +721,11 @@ int bf_launch_sample_logprob(const bf_tensor_t* tensors, int n_tensors, int S, u
     bool together = n_tensors == 2 && effective_prior(tensors[0].prior) == effective_prior(tensors[1].prior) &&
                     (!tensors[1].d_sample_out || tensors[1].out_dtype == BF_DT_F32);
     if (together && effective_prior(tensors[0].prior) == PRIOR_GAUSS_ALIAS)
-        together = tensors[0].prior.sigma1 == tensors[1].prior.sigma1;
+        together = tensors[0].prior.sigma1 == tensors[1].prior.sigma1 && tensors[0].prior.sigma2 == tensors[1].prior.sigma2;
     if (together && tensors[0].prior.kind == BF_PRIOR_MIXTURE)
         together = tensors[0].prior.pi == tensors[1].prior.pi && tensors[0].prior.sigma1 == tensors[1].prior.sigma1 &&
-                   tensors[0].prior.sigma2 == tensors[1].prior.sigma2;
+                   tensors[0].prior.sigma2 == tensors[1].prior.sigma2 && tensors[0].prior.d_pi == tensors[1].prior.d_pi &&
+                   tensors[0].prior.d_sigma1 == tensors[1].prior.d_sigma1 && tensors[0].prior.d_sigma2 == tensors[1].prior.d_sigma2;
     int rc;
     if (n_tensors == 1 || together) {
         rc = launch_group(tensors, 0, n_tensors, 0, S, seed, sample_base, partials, nblk, stream);

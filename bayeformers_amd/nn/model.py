@@ -20,6 +20,7 @@ import torch
 from torch import Tensor
 from torch.nn import Module
 
+from .. import ops
 from .. import random as bfr
 from ..plan import SamplePlan
 from .layers.base import KernelLayer
@@ -125,6 +126,14 @@ class Model(Module):
             return super(Model, self).__call__(*args, **kwargs)
         S = self._mc_samples
         layers = self.fused_children()
+        if layers and ops.stale_priors_seen():
+            # a kernel of an earlier forward found a prior's baked constants different from the tensors they were read
+            # from (an in-place edit through .data: no version counter moved).  That forward's log-prior is NaN; from
+            # this one on every cached copy is dropped and the priors are described again.
+            ops.invalidate_caches(self)
+            warnings.warn("bayeformers_amd: a prior's tensors were edited in place through `.data` after a forward had "
+                          "cached their state; the log_prior of the forward(s) since the edit is NaN — the caches are "
+                          "dropped now (call bayeformers_amd.invalidate_caches(model) after such an edit)")
         slots = {}
         if layers:
             dev = layers[0].weight.mu.device

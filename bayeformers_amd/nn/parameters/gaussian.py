@@ -89,8 +89,14 @@ class ScaledGaussianMixture(Parameter):
         self._consts = None
 
     def constants(self):
-        """(pi, sigma1, sigma2) as the fp32 values the parameters hold, cached on the host so that a forward never
-        synchronises on them; the cache follows load_state_dict and in-place edits via the version counters."""
+        """(pi, sigma1, sigma2) as the fp32 values the parameters hold.  Device-resident parameters are read once and
+        cached on the host so that a forward never synchronises on them; the cache follows load_state_dict, `.to()` and
+        in-place edits via the version counters and addresses, and an edit through `.data` — which moves neither — is
+        caught on the device: every kernel that evaluates the prior compares the cached values with the scalars
+        themselves (bf_prior_t.d_pi / d_sigma1 / d_sigma2) and reports a mismatch through the stale counter, after which
+        `bayeformers_amd.invalidate_caches` drops this cache.  Host-resident parameters are simply read on every call."""
+        if not self.pi.is_cuda:
+            return float(self.pi), float(self.sigma1), float(self.sigma2)
         key = (self.pi._version, self.sigma1._version, self.sigma2._version,
                self.pi.data_ptr(), self.sigma1.data_ptr(), self.sigma2.data_ptr())
         if self._consts is None or self._consts[0] != key:

@@ -81,7 +81,11 @@ def prior_alias(gaussian, prior) -> Optional[float]:
     8 instead of 16 bytes per scalar (bf_prior_t.pi == 1).  Checked on the tensors' CONTENTS (after a device move the two
     means are equal copies, no longer one storage), once per state: the verdict is cached with the tensors' addresses and
     version counters, so an in-place edit of either (an optimizer step on a trainable mean, load_state_dict) is seen and
-    re-checked.  A trainable mean is never aliased: it leaves the prior's at its first update."""
+    re-checked.  A trainable mean is never aliased: it leaves the prior's at its first update.
+    An edit through `.data` (the reference's idiom, layers/linear.py:140-150) moves no version counter: the sampling kernels
+    therefore spot-check the assertion on the device (one element per wave against prior.mu / prior.rho), poison the
+    log-prior and bump the library's stale counter when it fails; `stale_priors_seen()` notices that at the next forward
+    and `invalidate_caches(model)` drops every cached verdict."""
     mu, pmu, prho = gaussian.mu, prior.mu, prior.rho
     if _NO_ALIAS or mu.requires_grad or pmu.shape != mu.shape or prho.shape != mu.shape or pmu.dtype != torch.float32:
         return None
@@ -90,14 +94,47 @@ def prior_alias(gaussian, prior) -> Optional[float]:
     if hit is not None and hit[0] == state:
         return hit[1]
     with torch.no_grad():
-        sigma_p = None
+        sigma_p, rho_p = None, 0.0
         lo, hi = torch.aminmax(prho)
         if bool(lo == hi) and (pmu.data_ptr() == mu.data_ptr() or torch.equal(pmu, mu)):
-            sigma_p = float(torch.nn.functional.softplus(lo.float()))
+            sigma_p, rho_p = float(torch.nn.functional.softplus(lo.float())), float(lo)
             if not (sigma_p > 0.0 and sigma_p < float("inf")):
                 sigma_p = None
-    prior._bf_alias = (state, sigma_p)
+    prior._bf_alias = (state, sigma_p, rho_p)
     return sigma_p
+
+
+_STALE_SEEN = [None]
+
+
+def stale_priors_seen() -> bool:
+    """True once per change of the library's stale-prior counter (bf_stale_counter): some kernel found a prior's baked
+    constants — an asserted MOPED alias, a mixture's pi / sigma1 / sigma2 — different from the tensors they were read from
+    (an in-place edit through `.data`).  Reads a word of pinned host memory: no synchronisation."""
+    now = _C.stale_counter()
+    if _STALE_SEEN[0] is None:
+        _STALE_SEEN[0] = now
+    if now != _STALE_SEEN[0]:
+        _STALE_SEEN[0] = now
+        return True
+    return False
+
+
+def invalidate_caches(module) -> None:
+    """Forget every host-side copy of `module`'s prior state: the MOPED-alias verdicts (`prior_alias`), the mixture priors'
+    constants (`ScaledGaussianMixture.constants`) and the sampling plans built on them.  Call it after editing a prior's or
+    a frozen mean's tensors in place through `.data` — every other edit (optimizer steps, load_state_dict, `.to()`,
+    in-place ops on the parameter itself) is seen through the version counters and addresses."""
+    from .nn.model import Model
+    from .nn.parameters.gaussian import Gaussian, ScaledGaussianMixture
+
+    for m in module.modules():
+        if isinstance(m, Gaussian):
+            m.__dict__.pop("_bf_alias", None)
+        elif isinstance(m, ScaledGaussianMixture):
+            m._consts = None
+        elif isinstance(m, Model):
+            m._plan = None
 
 
 def fill_prior(dst: "_C.bf_prior_t", prior, gaussian=None) -> bool:
@@ -109,17 +146,24 @@ def fill_prior(dst: "_C.bf_prior_t", prior, gaussian=None) -> bool:
         pi, s1, s2 = prior.constants()
         dst.kind, dst.pi, dst.sigma1, dst.sigma2 = _C.BF_PRIOR_MIXTURE, pi, s1, s2
         dst.d_mu = dst.d_rho = None
+        # the kernels compare the three values with the device scalars they are a copy of (an edit through .data is
+        # invisible to the host-side cache; host-resident scalars are re-read by constants() on every call instead)
+        on_dev = prior.pi.is_cuda and prior.sigma1.is_cuda and prior.sigma2.is_cuda
+        dst.d_pi, dst.d_sigma1, dst.d_sigma2 = ((prior.pi.data_ptr(), prior.sigma1.data_ptr(), prior.sigma2.data_ptr())
+                                                if on_dev else (None, None, None))
         return True
     if isinstance(prior, Gaussian):
         _require_device(prior.mu, "prior.mu")
         dst.kind = _C.BF_PRIOR_GAUSSIAN
         dst.d_mu, dst.d_rho = prior.mu.data_ptr(), prior.rho.data_ptr()
         sigma_p = prior_alias(gaussian, prior) if gaussian is not None else None
-        dst.pi, dst.sigma1 = (1.0, sigma_p) if sigma_p is not None else (0.0, 0.0)
+        # (asserted alias: sigma2 carries the constant rho the kernels spot-check prior.rho against)
+        dst.pi, dst.sigma1, dst.sigma2 = (1.0, sigma_p, prior._bf_alias[2]) if sigma_p is not None else (0.0, 0.0, 0.0)
+        dst.d_pi = dst.d_sigma1 = dst.d_sigma2 = None
         return True
     if prior is None or isinstance(prior, NoneParameter):
         dst.kind = _C.BF_PRIOR_NONE
-        dst.d_mu = dst.d_rho = None
+        dst.d_mu = dst.d_rho = dst.d_pi = dst.d_sigma1 = dst.d_sigma2 = None
         return True
     return False
 

@@ -25,9 +25,10 @@ extern "C" {
 #endif
 
 #define BF_VERSION_MAJOR 0
-#define BF_VERSION_MINOR 4  /* 2: bf_embed_layernorm takes the table row counts; 3: bf_sample_table_build reports the
+#define BF_VERSION_MINOR 5  /* 2: bf_embed_layernorm takes the table row counts; 3: bf_sample_table_build reports the
                                tensors' effective prior kinds, bf_sample_logprob_table takes the launch's set of them;
-                               4: bf_add_layernorm_bwd_sum */
+                               4: bf_add_layernorm_bwd_sum; 5: bf_prior_t carries the device addresses its constants were
+                               read from (re-checked by the kernels), bf_stale_counter */
 
 /* element types of activations / sampled weights */
 enum { BF_DT_F32 = 0, BF_DT_BF16 = 1, BF_DT_F16 = 2 };
@@ -49,7 +50,17 @@ typedef struct bf_prior {
      * softplus(d_rho[i]) equals sigma1 for every i — the MOPED prior of a frozen mean
      * (/root/reference/bayeformers/nn/layers/linear.py:147-150: prior.mu is the pretrained tensor the posterior mean shares,
      * prior.rho = ones).  bf_sample_logprob / bf_sample_logprob_table then read neither (8 instead of 16 bytes per
-     * scalar); every other entry point ignores the assertion and reads d_mu / d_rho, which stay valid.  pi == 0: no claim. */
+     * scalar); every other entry point ignores the assertion and reads d_mu / d_rho, which stay valid.  pi == 0: no claim.
+     * With pi == 1, sigma2 is the constant VALUE of d_rho (softplus(sigma2) == sigma1). */
+    const float* d_pi;      /* mixture, optional: the device scalars pi / sigma1 / sigma2 were read from (ScaledGaussianMixture's */
+    const float* d_sigma1;  /* parameters, gaussian.py:139-141).  All three non-NULL: every kernel that evaluates the prior   */
+    const float* d_sigma2;  /* re-reads them and compares with the values above, bit for bit — see bf_stale_counter.          */
+    /* What the struct bakes in is a HOST copy of device state: an in-place edit of the module's tensors through `.data` (the
+     * reference's own idiom, layers/linear.py:140-150) changes the device state with no host-visible trace.  So the kernels
+     * re-check it: the mixture constants exactly (three scalar loads per workgroup), an asserted alias (pi == 1) on one
+     * element per wave (d_mu[i] against the tensor's mean, d_rho[i] against sigma2) — a wholesale edit (fill_, copy_, mul_)
+     * cannot pass, a single edited element can.  A failed check makes the log-prior of that tensor NaN for the launch and
+     * increments the counter of bf_stale_counter; there is no host synchronisation. */
 } bf_prior_t;
 
 /* One Gaussian variational parameter (a weight or a bias): Gaussian(mu, rho) of
@@ -66,6 +77,11 @@ typedef struct bf_tensor {
 
 int bf_version(void);
 const char* bf_last_error(void);
+
+/* *h_counter = address of a host-resident (pinned, device-visible) uint32, valid for the life of the process, that the
+ * kernels increment whenever a bf_prior_t's baked constants fail their device-side re-check (see bf_prior_t).  The caller
+ * polls it without synchronising — a change means: drop every cached copy of prior state and describe the priors again. */
+int bf_stale_counter(const uint32_t** h_counter);
 
 /* Device-resident Monte-Carlo sample counter (optional; one per HIP device, set for / read from the calling
  * thread's current device; NULL = off, the default).  While set, every kernel launched on that device adds the

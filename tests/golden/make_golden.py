@@ -213,6 +213,10 @@ def mlp_case():
 
 
 # ---------------------------------------------------------------------------------------------- C3: BERT
+HIDDEN_AT = [(0, 1), (3, 17), (7, 40), (12, 63), (16, 64), (21, 90), (27, 126), (31, 127)]   # (sequence, token)
+HIDDEN_AT_TINY = [(0, 1), (1, 7), (2, 8), (3, 15)]
+
+
 def bert_case(tiny, samples=None):
     from transformers import BertConfig, BertForSequenceClassification
 
@@ -238,19 +242,33 @@ def bert_case(tiny, samples=None):
     logits = torch.zeros(S, B, 2)
     lp = torch.zeros(S, dtype=torch.float64)
     lq = torch.zeros(S, dtype=torch.float64)
+    # the reference's LAST-LAYER hidden states at 8 (sequence, token) positions spread over the batch — one per two 256-row
+    # bands of the [B L, hidden] activation the GEMMs see — so that rows other than [CLS] are pinned to the reference too
+    # (the seq-cls logits read token 0 of the last layer only).  Not stored for the S = 64 fixture (size).
+    hidden_at = HIDDEN_AT_TINY if tiny else HIDDEN_AT
+    keep_hidden = samples is None
+    hidden = torch.zeros(S, len(hidden_at), cfg.hidden_size)
     t0 = time.time()
     with torch.no_grad():
         for s in range(S):  # sample_bayesian, examples/bert_glue.py:63-66
             clock["sample"] = s
-            out = bmodel(input_ids=ids, attention_mask=mask, labels=labels)
+            out = bmodel(input_ids=ids, attention_mask=mask, labels=labels, output_hidden_states=keep_hidden)
             logits[s] = out[1]
+            if keep_hidden:
+                last = out.hidden_states[-1]
+                for i, (b, t) in enumerate(hidden_at):
+                    hidden[s, i] = last[b, t]
             lp[s] = float(bmodel.log_prior())
             lq[s] = float(bmodel.log_variational_posterior())
         nll = torch.nn.functional.cross_entropy(logits.mean(0), labels)  # bert_glue.py:234
     print(f"  bert tiny={tiny}: {len(layers)} layers, {time.time() - t0:.1f}s for {S} samples", flush=True)
-    return {"S": S, "B": B, "L": L, "model_seed": 0, "input_seed": 321, "delta": 0.05, "n_layers": len(layers),
-            "checksum": csum, "ids_sum": int(ids.sum()), "labels": t2n(labels), "logits": t2n(logits),
-            "log_prior": t2n(lp), "lvp": t2n(lq), "nll": float(nll)}
+    out = {"S": S, "B": B, "L": L, "model_seed": 0, "input_seed": 321, "delta": 0.05, "n_layers": len(layers),
+           "checksum": csum, "ids_sum": int(ids.sum()), "labels": t2n(labels), "logits": t2n(logits),
+           "log_prior": t2n(lp), "lvp": t2n(lq), "nll": float(nll)}
+    if keep_hidden:
+        out["hidden_at"] = np.array(hidden_at, dtype=np.int64)
+        out["hidden"] = t2n(hidden)
+    return out
 
 
 def grad_cases():
@@ -448,6 +466,7 @@ def main():
     ap.add_argument("--skip-bert", action="store_true")
     ap.add_argument("--only-grads", action="store_true")
     ap.add_argument("--only-bert-large", action="store_true")
+    ap.add_argument("--only-c3", action="store_true", help="BERT tiny + BASELINE config 3: BERT-base, S = 10 (about a minute of CPU)")
     ap.add_argument("--only-c4", action="store_true", help="BASELINE config 4: BERT-base, S = 64 (about 6 minutes of CPU)")
     ap.add_argument("--only-checkpoint", action="store_true")
     ap.add_argument("--only-bert-train", action="store_true")
@@ -456,6 +475,10 @@ def main():
     torch.set_num_threads(8)
     if args.only_linear768:
         np.savez_compressed(os.path.join(HERE, "linear768_c2.npz"), **linear768_cases())
+        return
+    if args.only_c3:
+        np.savez_compressed(os.path.join(HERE, "bert_tiny.npz"), **bert_case(True))
+        np.savez_compressed(os.path.join(HERE, "bert_c3.npz"), **bert_case(False))
         return
     if args.only_c4:
         np.savez_compressed(os.path.join(HERE, "bert_c4.npz"), **bert_case(False, samples=64))

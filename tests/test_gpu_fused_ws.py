@@ -10,14 +10,45 @@ import bayeformers_amd.nn as bnn
 from bayeformers_amd import ops
 from oracle import bayes_oracle as bo
 
-# developer-build entry point (csrc/bf_dev_api.h) since round 4: run with
-#   python -m bayeformers_amd.build --dev && BF_LIB_PATH=bayeformers_amd/lib/libbayeformers_amd_dev.so pytest tests/test_gpu_fused_ws.py -m gpu
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not hasattr(bf._C.lib(), "bf_linear_fwd_ws"),
-                                 reason="bf_linear_fwd_ws lives in the developer library only (BF_LIB_PATH=..._dev.so)")]
+# bf_linear_fwd_ws is a developer-build entry point (csrc/bf_dev_api.h): the product library carries only dispatched code.
+# The kernel cases below need the developer library loaded (BF_LIB_PATH=..._dev.so), which is a per-process choice — so
+# under the product library they are skipped and `test_fused_ws_cases_run_under_the_developer_library` runs them all in a
+# fresh CHILD python process that loads the developer library (built by __graft_entry__.build()), and counts the passes.
+pytestmark = pytest.mark.gpu
+_HAS_WS = hasattr(bf._C.lib(), "bf_linear_fwd_ws")
 SEED = 0x5EED
+N_DEV_CASES = 7   # 3 shapes x 2 priors + the refusal test
 
 
+def needs_dev(fn):
+    """Collected only in a process that loaded the developer library (no skipped placeholders in the product run)."""
+    fn.__test__ = _HAS_WS
+    return fn
+
+
+def test_fused_ws_cases_run_under_the_developer_library():
+    if _HAS_WS:
+        return  # this IS the developer-library process: the cases below run here
+    """NS-1's measured alternative (DESIGN.md 4.3) stays parity-checked: a child `python -m pytest` of this file with the
+    developer library selected.  A child process, never a re-exec: this process has initialised the GPU."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dev = os.path.join(root, "bayeformers_amd", "lib", "libbayeformers_amd_dev.so")
+    assert os.path.exists(dev), f"{dev} is missing: __graft_entry__.build() / `python -m bayeformers_amd.build --dev` builds it"
+    env = dict(os.environ, BF_LIB_PATH=dev)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) == N_DEV_CASES + 1 and "skipped" not in r.stdout, tail   # + this function, a no-op there
+
+
+@needs_dev
 @pytest.mark.parametrize("prior", ["mixture", "moped"])
 @pytest.mark.parametrize("S,M,N,K,shares", [(3, 300, 128, 256, 1), (2, 1024, 64, 768, 2), (4, 513, 192, 64, 0)])
 def test_fused_ws_matches_two_launch_path_and_oracle(prior, S, M, N, K, shares):
@@ -56,6 +87,7 @@ def test_fused_ws_matches_two_launch_path_and_oracle(prior, S, M, N, K, shares):
     assert err <= 2.0 ** -7 * float(x[:M].float().norm(dim=1).max()) * float((mu_w.abs() + 1).norm(dim=1).max())
 
 
+@needs_dev
 def test_fused_ws_refuses_what_it_cannot_take():
     layer = bnn.Linear(1024, 128).cuda()   # K > 768: the strip does not fit beside the x stages in LDS
     x = torch.randn(256, 1024, device="cuda").to(torch.bfloat16)

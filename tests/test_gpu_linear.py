@@ -162,6 +162,61 @@ def test_gemm_forms_are_repeatable(S, L, M, N, K, act):
             assert torch.equal(ops.gemm_nn(a, w1), r)
 
 
+# The launches of the benchmarked steps (BASELINE configs[2] and configs[4]), EVERY output row against an fp64 einsum of the
+# same 16-bit operands: (S, L, M, N, K, act, dtype).  These shapes have more tiles than workgroups (480 ... 1920 tiles on 256
+# persistent workgroups), so the ring's tile-to-tile hand-over (the next tile's W(0) / X(0) / W(1) issued in a tile's last
+# two k-steps, csrc/bf_gemm256_r5.hip) is exercised on every row — F.linear of /root/reference/bayeformers/nn/layers/linear.py:104.
+BENCH_NT_SHAPES = [
+    (10, 1, 4096, 768, 768, 0, torch.bfloat16),     # BERT-base attention-out
+    (10, 1, 4096, 768, 3072, 0, torch.bfloat16),    # BERT-base FFN-down
+    (10, 1, 4096, 3072, 768, 1, torch.bfloat16),    # BERT-base FFN-up + GELU
+    (10, 3, 4096, 768, 768, 0, torch.bfloat16),     # BERT-base query / key / value, one stacked launch
+    (10, 1, 6144, 1024, 1024, 0, torch.float16),    # BERT-large attention-out (configs[4], fp16)
+    (10, 1, 6144, 4096, 1024, 1, torch.float16),    # BERT-large FFN-up + GELU
+    (10, 1, 6144, 1024, 4096, 0, torch.float16),    # BERT-large FFN-down
+    (10, 3, 6144, 1024, 1024, 0, torch.float16),    # BERT-large query / key / value
+]
+
+
+@pytest.mark.parametrize("S,L,M,N,K,act,dt", BENCH_NT_SHAPES)
+def test_gemm_nt_benchmarked_shapes_all_rows_against_fp64(S, L, M, N, K, act, dt):
+    g = torch.Generator(device="cuda").manual_seed(S * 7919 + L * 131 + M * 31 + N * 7 + K)
+    x = torch.randn(S, M, K, device="cuda", generator=g).to(dt)
+    w = (torch.randn(L, S, N, K, device="cuda", generator=g) * 0.1).to(dt)
+    b = torch.randn(L, S, N, device="cuda", generator=g)
+    y = ops.gemm_nt_layers(x, w, b, L, S, M, N, K, M * K, dt, act)
+    assert y.shape == (L, S, M, N) and y.dtype == dt
+    tol = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    xd = x.double()
+    worst = 0.0
+    for l in range(L):  # one layer at a time: the fp64 reference of a whole launch is 1-3 GB
+        ref = torch.einsum("smk,snk->smn", xd, w[l].double()) + b[l][:, None, :].double()
+        if act:
+            ref = torch.nn.functional.gelu(ref)
+        bound = tol * ref.abs().max().item() + 1e-5 * np.sqrt(K)
+        err = (y[l].double() - ref).abs().max().item()
+        worst = max(worst, err / bound)
+        assert err <= bound, (l, err, bound)
+        del ref
+    if L == 1:  # the single-layer entry point runs the same schedule: same bits
+        assert torch.equal(ops.gemm_nt(x, w[0], b[0], S, M, N, K, M * K, dt, act), y[0])
+    print(f"[gemm_nt all rows] S={S} L={L} M={M} N={N} K={K} act={act} {str(dt)[6:]}: max err / bound = {worst:.3f}")
+
+
+def test_gemm_fuzz_all_forms_against_fp64():
+    """tools/gemm_fuzz.py as a test: 65 random ragged shapes (M 130..3000, N = 8..1112, K = 64..512, bf16 / fp16, with
+    and without GELU) through every form of the 256-wide GEMM — NT, NT with the pre-activation output, TN, NN — against
+    fp64 einsums over all outputs."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gemm_fuzz.py")
+    spec = importlib.util.spec_from_file_location("gemm_fuzz", path)
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    assert fuzz.run(65, 0) == 0
+
+
 def test_gemm_detects_transposes():
     """Asymmetric operands: a swapped row/col mapping in the MFMA epilogue cannot pass."""
     M, N, K = 48, 80, 64
@@ -337,6 +392,86 @@ def test_moped_alias_path_equals_general_path_and_tracks_edits(golden_dir):
                                         ("gaussian", t(layer.bias_prior.mu), t(layer.bias_prior.rho)))
     assert float(lp_edit[0, 0]) == pytest.approx(lp64, rel=LOGPROB_RTOL) and float(lp_edit[0, 0]) != float(lp_alias[0, 0])
     assert float(lp_edit[0, 1]) == pytest.approx(lq64, rel=LOGPROB_RTOL)
+
+
+def _logprob_oracle(layer, prior_w, prior_b, sample):
+    t = lambda p: p.detach().cpu()
+    N, K = layer.weight.mu.shape
+    eps_w, eps_b = bo.eps_tensor((N, K), SEED, sample, 0, 0), bo.eps_tensor((N,), SEED, sample, 0, 1)
+    return bo.linear_logprobs_f64(t(layer.weight.mu), t(layer.weight.rho), t(layer.bias.mu), t(layer.bias.rho), eps_w, eps_b,
+                                  prior_w, prior_b)
+
+
+@pytest.mark.parametrize("M", [32, 300])   # the single fused kernel and the sampling launch + tiled GEMM
+def test_prior_edited_through_data_is_never_silently_stale(M):
+    """The reference's own idiom for touching a prior is an in-place edit through `.data`
+    (/root/reference/bayeformers/nn/layers/linear.py:140-150), which moves no version counter — the MOPED-alias verdict
+    and the mixture constants cached on the host cannot see it.  The kernels re-check what they were told against the
+    tensors (bf_prior_t): the forward after such an edit has a NaN log_prior (never a wrong finite one), the next one
+    warns, drops the caches and is right; `bayeformers_amd.invalidate_caches` right after the edit skips the NaN step."""
+    import warnings
+
+    from util import linear768_layer
+
+    x = torch.randn(M, 768, device="cuda")
+    t = lambda p: p.detach().cpu()
+
+    def gauss_priors(layer):
+        return (("gaussian", t(layer.weight_prior.mu), t(layer.weight_prior.rho)),
+                ("gaussian", t(layer.bias_prior.mu), t(layer.bias_prior.rho)))
+
+    # --- MOPED prior of a frozen mean (aliased: the kernel reads neither prior.mu nor prior.rho)
+    layer = linear768_layer("moped").cuda()
+    layer.layer_id = 0
+    _, lp = run_layer(layer, x, 2, 50)
+    lp64, _ = _logprob_oracle(layer, *gauss_priors(layer), 50)
+    assert float(lp[0, 0]) == pytest.approx(lp64, rel=LOGPROB_RTOL)
+    layer.weight_prior.rho.data.fill_(0.5)
+    if M > ops.fused_small_rows(768, 768):
+        _, lp = run_layer(layer, x, 2, 50)
+        assert bool(torch.isnan(lp[:, 0]).all()) and bool(torch.isfinite(lp[:, 1]).all())     # loud, not wrong
+        torch.cuda.synchronize()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            _, lp = run_layer(layer, x, 2, 50)
+        assert any("edited in place" in str(i.message) for i in w)
+    else:  # the single fused kernel reads a Gaussian prior's tensors themselves: nothing cached, right at once
+        _, lp = run_layer(layer, x, 2, 50)
+    lp64, lq64 = _logprob_oracle(layer, *gauss_priors(layer), 50)
+    assert float(lp[0, 0]) == pytest.approx(lp64, rel=LOGPROB_RTOL) and float(lp[0, 1]) == pytest.approx(lq64, rel=LOGPROB_RTOL)
+    # the public way: say so after the edit — no NaN step (a scaled prior mean: no longer the posterior's)
+    layer.weight_prior.mu.data.mul_(1.5)
+    layer.bias_prior.rho.data.fill_(-1.0)
+    bf.invalidate_caches(layer)
+    _, lp = run_layer(layer, x, 2, 50)
+    lp64, _ = _logprob_oracle(layer, *gauss_priors(layer), 50)
+    assert float(lp[0, 0]) == pytest.approx(lp64, rel=LOGPROB_RTOL)
+
+    # --- scale-mixture prior: its three constants live in 0-d device tensors and are cached on the host
+    torch.manual_seed(5)
+    prior = bnn.ScaledGaussianMixture(0.5, 1.0, float(np.exp(-6)))
+    layer = bnn.Linear(768, 768, prior=prior).cuda()
+    layer.layer_id = 0
+    mix = lambda: ("mixture", float(prior.pi), float(prior.sigma1), float(prior.sigma2))
+    _, lp = run_layer(layer, x, 2, 60)
+    lp64, _ = _logprob_oracle(layer, mix(), mix(), 60)
+    assert float(lp[0, 0]) == pytest.approx(lp64, rel=LOGPROB_RTOL)
+    prior.sigma1.data.fill_(2.0)
+    prior.pi.data.fill_(0.25)
+    _, lp = run_layer(layer, x, 2, 60)
+    assert bool(torch.isnan(lp[:, 0]).all())
+    torch.cuda.synchronize()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        _, lp = run_layer(layer, x, 2, 60)
+    assert any("edited in place" in str(i.message) for i in w)
+    lp64, _ = _logprob_oracle(layer, mix(), mix(), 60)
+    assert float(lp[0, 0]) == pytest.approx(lp64, rel=LOGPROB_RTOL)
+    prior.sigma2.data.fill_(0.01)
+    bf.invalidate_caches(layer)
+    _, lp = run_layer(layer, x, 2, 60)
+    lp64, _ = _logprob_oracle(layer, mix(), mix(), 60)
+    assert float(lp[0, 0]) == pytest.approx(lp64, rel=LOGPROB_RTOL)
 
 
 @pytest.mark.parametrize("S,M,N,K", [(2, 300, 200, 128), (1, 40, 24, 72), (2, 513, 259, 192)])

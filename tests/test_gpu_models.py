@@ -60,6 +60,23 @@ def test_mlp_c1(golden_dir, dtype, tol):
     assert float(bmodel.log_variational_posterior()) == pytest.approx(g["lvp"].mean(), rel=1e-6)
 
 
+def _logits_and_last_hidden(out):
+    return out.logits, out.hidden_states[-1]
+
+
+def _hidden_rows_error(hidden, g):
+    """max |hidden[s, b, t, :] - reference| over the fixture's (sequence, token) positions; hidden: [S, B, L, hidden]."""
+    h = hidden.float().cpu().numpy()
+    return max(float(np.abs(h[:, b, t] - g["hidden"][:, i]).max()) for i, (b, t) in enumerate(g["hidden_at"]))
+
+
+# Tolerances = 2x what the tests measured on MI355X in round 5 (their own printout, profiles/r5a_pytest_new_parity.txt).
+# The benchmarked configuration (bf16, every fusion on): max |logit - ref| = 4.83e-3 with logits up to 1.97 and a
+# sample-to-sample spread of 0.82; max |last-layer hidden - ref| = 2.05e-2 on unit-variance rows whose samples spread by 0.90.
+C3_LOGIT_TOL = 1.0e-2
+C3_HIDDEN_TOL = 4.5e-2
+
+
 def _bert(tiny):
     from transformers import BertConfig, BertForSequenceClassification
 
@@ -72,9 +89,13 @@ def _bert(tiny):
     return cfg, BertForSequenceClassification(cfg).eval()
 
 
-@pytest.mark.parametrize("fixture,tiny,dtype,tol", [("bert_tiny", True, "fp32", 2e-4), ("bert_tiny", True, "bf16", 5e-2),
-                                                    ("bert_c3", False, "bf16", 5e-2), ("bert_c3", False, "fp32", 5e-4)])
-def test_bert(golden_dir, fixture, tiny, dtype, tol):
+# (fixture, tiny, dtype, nll tolerance, max |logit - ref|, max |hidden - ref|): the last two are absolute and about 2x the
+# measured values — tiny fp32 8.9e-8 / 7.7e-7, tiny bf16 2.1e-3 / 2.0e-2, BERT-base bf16 5.2e-3 / 3.3e-2, fp32 1.1e-6 / 6.0e-6
+# (the fp32 bounds leave room for the ulp-level differences of the host's libm in the MOPED rho, see the checksum check)
+@pytest.mark.parametrize("fixture,tiny,dtype,tol,tol_logit,tol_hidden", [
+    ("bert_tiny", True, "fp32", 2e-4, 1e-6, 5e-6), ("bert_tiny", True, "bf16", 5e-2, 5e-3, 4.5e-2),
+    ("bert_c3", False, "bf16", 5e-2, 1.1e-2, 7e-2), ("bert_c3", False, "fp32", 5e-4, 5e-6, 2e-5)])
+def test_bert(golden_dir, fixture, tiny, dtype, tol, tol_logit, tol_hidden):
     g = np.load(f"{golden_dir}/{fixture}.npz")
     S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
     cfg, model = _bert(tiny)
@@ -93,8 +114,8 @@ def test_bert(golden_dir, fixture, tiny, dtype, tol):
     bf.set_compute_dtype(dtype)
     try:
         with torch.no_grad():
-            inputs = {"input_ids": ids.cuda(), "attention_mask": mask.cuda()}
-            raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S)
+            inputs = {"input_ids": ids.cuda(), "attention_mask": mask.cuda(), "output_hidden_states": True}
+            raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S, select=_logits_and_last_hidden)
             nll = torch.nn.functional.cross_entropy(mean[0].float(), labels.cuda())
     finally:
         bf.set_compute_dtype("bf16")
@@ -102,7 +123,11 @@ def test_bert(golden_dir, fixture, tiny, dtype, tol):
     np.testing.assert_allclose(lps[:, 0], g["log_prior"], rtol=2e-6)
     np.testing.assert_allclose(lps[:, 1], g["lvp"], rtol=2e-6)
     logits = raw[0].float().cpu().numpy()
-    assert np.abs(logits - g["logits"]).max() < tol * max(1.0, np.abs(g["logits"]).max())
+    # rows other than [CLS]: the reference's last-layer hidden states at positions spread over the batch (unit-variance
+    # LayerNorm outputs, so the bound is absolute)
+    err_l, err_h = float(np.abs(logits - g["logits"]).max()), _hidden_rows_error(raw[1], g)
+    print(f"[{fixture} {dtype}] max |logit - ref| = {err_l:.3e}, max |hidden - ref| = {err_h:.3e}")
+    assert err_l < tol_logit and err_h < tol_hidden
     assert float(nll) == pytest.approx(float(g["nll"]), rel=max(tol, 1e-3), abs=tol)
     n_batches = 2105  # SST-2 train set / batch 32
     ref_loss = (g["lvp"].mean() - g["log_prior"].mean()) / n_batches + float(g["nll"])
@@ -125,15 +150,19 @@ def test_benchmarked_configuration_matches_reference_c3(golden_dir):
     assert len(bmodel.fused_children()) == int(g["n_layers"])
     bf.manual_seed(SEED)
     with torch.no_grad():
-        raw, mean, lp, lq = sample_bayesian(bmodel, inputs, S)
+        raw, mean, lp, lq = sample_bayesian(bmodel, dict(inputs, output_hidden_states=True), S, select=_logits_and_last_hidden)
         nll = torch.nn.functional.cross_entropy(mean[0].float(), labels.cuda())
     lps = bmodel.log_prob_samples().cpu().numpy()
     np.testing.assert_allclose(lps[:, 0], g["log_prior"], rtol=2e-6)
     np.testing.assert_allclose(lps[:, 1], g["lvp"], rtol=2e-6)
     logits = raw[0].float().cpu().numpy()
-    tol = 5e-2
-    assert np.abs(logits - g["logits"]).max() < tol * max(1.0, np.abs(g["logits"]).max())
-    assert float(nll) == pytest.approx(float(g["nll"]), rel=tol, abs=tol)
+    err_l = float(np.abs(logits - g["logits"]).max())
+    err_h = _hidden_rows_error(raw[1], g)   # 8 rows of the LAST layer spread over the 16 row bands: not only [CLS]
+    print(f"[c3 benchmarked configuration] max |logit - ref| = {err_l:.3e} (max |logit| {np.abs(g['logits']).max():.3f}), "
+          f"max |hidden - ref| = {err_h:.3e}, |nll - ref| = {abs(float(nll) - float(g['nll'])):.3e}")
+    assert err_l < C3_LOGIT_TOL      # 2x the measured error; the samples of one logit spread by 0.82
+    assert err_h < C3_HIDDEN_TOL
+    assert float(nll) == pytest.approx(float(g["nll"]), abs=1e-3)   # measured 3.7e-5
     n_batches = 2105
     ref_loss = (g["lvp"].mean() - g["log_prior"].mean()) / n_batches + float(g["nll"])
     assert float(elbo(lp, lq, nll.double(), n_batches)) == pytest.approx(ref_loss, rel=1e-3)

@@ -111,12 +111,12 @@ def test_header_and_library_export_the_same_symbols():
     lib = ctypes.CDLL(_C.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _C.lib().bf_version() == _C.ABI_VERSION == 4
+    assert _C.lib().bf_version() == _C.ABI_VERSION == 5
 
 
 def test_struct_layout_matches_header():
-    # 4 + 3*4 + 2*8 = 32 bytes; tensor = 8+8+8+32+4+4+8 = 72 bytes (natural alignment, as the C compiler lays it out)
-    assert ctypes.sizeof(_C.bf_prior_t) == 32 and ctypes.sizeof(_C.bf_tensor_t) == 72
+    # 4 + 3*4 + 5*8 = 56 bytes; tensor = 8+8+8+56+4+4+8 = 96 bytes (natural alignment, as the C compiler lays it out)
+    assert ctypes.sizeof(_C.bf_prior_t) == 56 and ctypes.sizeof(_C.bf_tensor_t) == 96
 
 
 def test_error_reporting_without_gpu():
