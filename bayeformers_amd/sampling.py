@@ -214,20 +214,53 @@ def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callabl
 
 
 _GRAPHED_KEEP = 2  # GraphedSamplers kept per model by sample_bayesian(graph=True): the last two batch signatures
+# model -> [(key, sampler)], most recent last.  Kept OUTSIDE the module (weakly keyed): a model with captured graphs in its
+# __dict__ could be neither deep-copied nor pickled; when the model goes away its samplers are closed (the sample counter
+# returns to the host).
+_GRAPHED: "weakref.WeakKeyDictionary" = None
+
+
+def _select_key(select):
+    """Cache identity of a `select` callable: a lambda written at the call site is a new object on every call but the same
+    code with the same captured values."""
+    code = getattr(select, "__code__", None)
+    if code is None:
+        return select
+    cells = tuple(id(c.cell_contents) for c in (select.__closure__ or ()))
+    return code, select.__defaults__, cells, getattr(select, "__self__", None)
+
+
+def _close_all(entries):
+    for _, sampler in entries:
+        sampler.close()
 
 
 def _graphed(model: Model, inputs, samples: int, select, group):
-    cache = model.__dict__.setdefault("_bf_graphed", [])  # [(key, sampler)], most recent last
-    key = (GraphedSampler._sig(inputs), int(samples), select, group)
-    for i, (k, sampler) in enumerate(cache):
-        if k == key and sampler.graph is not None:
+    import weakref
+
+    global _GRAPHED
+    if _GRAPHED is None:
+        _GRAPHED = weakref.WeakKeyDictionary()
+    cache = _GRAPHED.get(model)
+    if cache is None:
+        cache = _GRAPHED[model] = []
+        weakref.finalize(model, _close_all, cache)
+    key = (GraphedSampler._sig(inputs), int(samples), _select_key(select), group)
+    sampler = None
+    for i, (k, sm) in enumerate(cache):
+        if k == key and sm.graph is not None:
             cache.append(cache.pop(i))
-            return sampler(inputs)
-    while len(cache) >= _GRAPHED_KEEP:
-        cache.pop(0)[1].close()
-    sampler = GraphedSampler(model, inputs, samples, select=select, group=group)
-    cache.append((key, sampler))
-    return sampler()
+            sampler = sm
+            break
+    if sampler is None:
+        while len(cache) >= _GRAPHED_KEEP:
+            cache.pop(0)[1].close()
+        sampler = GraphedSampler(model, inputs, samples, select=select, group=group)
+        cache.append((key, sampler))
+    raw, means, log_prior, lvp = sampler(inputs)
+    # the convenience path hands out COPIES of the small results (an evaluation loop that collects `mean[0]` per batch
+    # must not end up with the last batch in every entry); `raw` stays the graph's buffer, valid until the next call
+    return raw, tuple(m.clone() for m in means), log_prior.clone(), lvp.clone()
 
 
 def elbo(log_prior: Tensor, log_variational_posterior: Tensor, nll: Tensor, n_batches: int) -> Tensor:
@@ -255,7 +288,13 @@ class GraphedSampler:
 
     The returned tensors are the graph's own buffers (`mean`, the log-probs: fresh tensors when a group reduces them): the
     next call overwrites them — clone what must outlive it.  Gradients are not recorded (training steps are not
-    replayable: their dropout masks and autograd graphs are per step) and the model must be in eval mode."""
+    replayable: their dropout masks and autograd graphs are per step) and the model must be in eval mode.
+
+    What a capture bakes in besides the shapes: the Philox SEED (a kernel argument), the compute dtype and the sampling
+    plan (which priors are aliases of their frozen means, where the sampled weights live).  `__call__` compares them with
+    the current state and captures again when one changed (`bf.manual_seed(other)`, `set_compute_dtype`, an edited prior),
+    so a replay never draws from a stale key or dtype.  The capture's warm-up steps give their sample indices back:
+    `manual_seed(s); GraphedSampler(...)()` equals the eager call from the same state, and replay k the k-th eager step."""
 
     def __init__(self, model: Model, inputs, samples: int, select: Optional[Callable] = None,
                  group: Optional["dist.ProcessGroup"] = None, warmup: int = 2) -> None:
@@ -281,18 +320,43 @@ class GraphedSampler:
         self._open = True
         bfr.use_device_counter(True, device=self.device)
         self.graph = self._static = None
+        self._warmup = max(1, int(warmup))
+        self.captures = 0
         try:
-            with torch.no_grad(), torch.cuda.device(self.device):
-                for _ in range(max(1, int(warmup))):  # plans, workspaces and tile schedules are built outside the capture
-                    self._step()
-                torch.cuda.synchronize(self.device)
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    self._static = self._step()
-                self.graph = graph
+            self._capture()
         except BaseException:
             self.close()  # a failed capture leaves nothing behind (the counter goes back where it was)
             raise
+
+    def _baked(self):
+        """The host state a capture bakes into its launches."""
+        from . import random as bfr
+
+        plan = getattr(self.model, "_plan", None)
+        return bfr.STATE.seed, bfr.get_compute_dtype(), plan, (plan.key if plan is not None else None)
+
+    def _capture(self) -> None:
+        from . import random as bfr
+
+        self.graph = self._static = None
+        with torch.no_grad(), torch.cuda.device(self.device):
+            for _ in range(self._warmup):  # plans, workspaces and tile schedules are built outside the capture
+                self._step()
+            # the warm-up steps consumed sample indices the caller never saw: hand them back, so that the first replay
+            # draws what the eager step from the caller's state would have drawn
+            bfr.STATE.device_counter.sub_(self._warmup * self.samples)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._static = self._step()
+            self.graph = graph
+        self._baked_state = self._baked()
+        self.captures += 1
+
+    def _still_valid(self) -> bool:
+        seed, cdt, plan, key = self._baked_state
+        now = self._baked()
+        return now[0] == seed and now[1] == cdt and now[2] is plan and now[3] == key and (plan is None or plan.alias_valid())
 
     # ------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -337,6 +401,8 @@ class GraphedSampler:
         if self.model.training:
             raise RuntimeError("GraphedSampler: the model was switched to training mode after the capture; the captured "
                                "forward is the evaluation one — call model.eval(), or build a new sampler")
+        if not self._still_valid():  # another seed / compute dtype / plan than the captured launches carry
+            self._capture()
         if inputs is not None:
             self.load(inputs)
         self.graph.replay()

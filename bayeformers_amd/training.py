@@ -22,6 +22,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
+from . import random as bfr
 from .nn.model import Model
 from .sampling import elbo, sample_bayesian
 
@@ -121,8 +122,11 @@ class GradientBuckets:
             p.grad = None
 
     def slot(self, p):
-        """The standing destination of p's gradient while a step is open (None otherwise): ops.linear_backward writes it."""
-        return self._views.get(p) if self.active else None
+        """The standing destination of p's gradient while a step is open (None otherwise): ops.linear_backward writes it.
+        Not with the opt-in KL gradient (set_kl_gradient): then a mu / rho receives TWO gradients per backward — the layer's
+        and the KL term's — which autograd must sum before anything is sent, so the producer takes the ordinary path and
+        the hook below copies the sum."""
+        return self._views.get(p) if self.active and not bfr.STATE.kl_gradient else None
 
     def arrived(self, p) -> None:
         """p's gradient is in its slot (written there by the kernel that produced it, or copied by the hook)."""
@@ -137,8 +141,14 @@ class GradientBuckets:
 
     def _make_hook(self, p):
         def hook(grad):
-            if grad is None or not self.active or p in self._arrived:
+            if grad is None or not self.active:
                 return None  # (a gradient its kernel wrote in place reaches autograd as None)
+            if p in self._arrived:
+                # its slot is complete — possibly on the wire already: a further defined gradient can be neither added
+                # nor dropped
+                raise RuntimeError("GradientBuckets: a parameter whose gradient was already in its bucket slot received "
+                                   "another one in the same backward(); every gradient of a parameter must reach it "
+                                   "through one path per step")
             view = self._views.get(p)
             if view is None:
                 raise RuntimeError("GradientBuckets: a parameter that had no gradient in the first step received one now; "

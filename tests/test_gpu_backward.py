@@ -222,6 +222,52 @@ def test_training_loop_reduces_the_elbo():
     assert losses[-1] < 0.85 * losses[0], (losses[0], losses[-1])
 
 
+def test_kl_gradient_with_gradient_buckets_keeps_both_gradients():
+    """with set_kl_gradient(True) every mu / rho receives the layer's gradient AND the KL term's.  Under
+    GradientBuckets (what training_step builds on sharded ranks) the layer's backward used to write its part into the bucket
+    slot and the KL part was dropped.  The bucketed step must leave the gradients of the plain step."""
+    from bayeformers_amd.sampling import elbo, sample_bayesian
+    from bayeformers_amd.training import GradientBuckets
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.ReLU(), torch.nn.Linear(128, 4), torch.nn.LogSoftmax(dim=1))
+    bmodel = bf.to_bayesian(net, delta=0.05).cuda()
+    x = torch.randn(128, 64, device="cuda")
+    labels = torch.randint(0, 4, (128,), device="cuda")
+    params = [p for p in bmodel.parameters() if p.requires_grad]
+
+    def step(buckets):
+        bf.manual_seed(SEED)
+        if buckets is not None:
+            buckets.zero()
+        else:
+            for p in params:
+                p.grad = None
+        _, mean, lp, lq = sample_bayesian(bmodel, x, 3)
+        loss = elbo(lp, lq, torch.nn.functional.nll_loss(mean[0], labels, reduction="sum").double(), 10)
+        loss.backward()
+        if buckets is not None:
+            buckets.finish()
+        return {i: p.grad.clone() for i, p in enumerate(params) if p.grad is not None}
+
+    bf.set_kl_gradient(True)
+    try:
+        ref = step(None)
+        buckets = GradientBuckets(params, bucket_bytes=1 << 16)
+        for _ in range(2):  # the second step runs on the settled layout
+            got = step(buckets)
+            assert set(got) == set(ref) and len(ref) >= 8
+            for i in ref:
+                assert torch.allclose(got[i], ref[i], rtol=1e-5, atol=1e-6 * float(ref[i].abs().max())), i
+        buckets.remove()
+        # and the KL part is really there: without it the gradients differ
+        bf.set_kl_gradient(False)
+        nll_only = step(None)
+        assert any(not torch.allclose(nll_only[i], ref[i], rtol=1e-3) for i in ref)
+    finally:
+        bf.set_kl_gradient(False)
+
+
 def test_backward_after_a_later_forward_regenerates_the_samples():
     """The backward reads the forward's sampled weights while the sampling plan still holds them; if another forward
     has overwritten them in between (fwd 1, fwd 2, bwd 1) it regenerates them from the Philox counter — same grads."""

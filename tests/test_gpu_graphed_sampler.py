@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 SEED = 0xBEEF
 
 
-def _build():
+def _build(half=True):
     import bayeformers_amd as bf
     from transformers import BertConfig, BertForSequenceClassification
 
@@ -17,7 +17,9 @@ def _build():
                      max_position_embeddings=64)
     torch.manual_seed(0)
     model = BertForSequenceClassification(cfg).eval()
-    bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().cuda().to(torch.bfloat16)
+    bmodel = bf.to_bayesian(model, delta=0.05, freeze=True).eval().cuda()
+    if half:
+        bmodel = bmodel.to(torch.bfloat16)
     bf.fuse_activations(bmodel), bf.fuse_residual_layernorm(bmodel), bf.fuse_shared_inputs(bmodel)
     bf.fuse_attention(bmodel), bf.fuse_embeddings(bmodel)
     g = torch.Generator().manual_seed(7)
@@ -113,12 +115,15 @@ def test_sample_bayesian_graph_flag_caches_two_signatures():
     bf.set_compute_dtype("bf16")
     with pytest.raises(RuntimeError, match="no_grad"):
         sample_bayesian(bmodel, batches[0], 2, graph=True)
+    from bayeformers_amd import sampling
+
     with torch.no_grad():
         sample_bayesian(bmodel, batches[0], 2, graph=True)  # captures
-        first = bmodel._bf_graphed[0][1]
+        cache = sampling._GRAPHED[bmodel]
+        first = cache[0][1]
         bf.manual_seed(SEED)
         got = _host(sample_bayesian(bmodel, batches[1], 2, graph=True))  # same signature: the cached sampler, new batch
-        assert len(bmodel._bf_graphed) == 1 and bmodel._bf_graphed[0][1] is first
+        assert len(cache) == 1 and cache[0][1] is first
         bf.manual_seed(SEED)
         want = _host(sample_bayesian(bmodel, batches[1], 2))
         assert np.array_equal(got[0], want[0]) and got[2] == want[2] and got[3] == want[3]
@@ -126,8 +131,52 @@ def test_sample_bayesian_graph_flag_caches_two_signatures():
         tiny = {k: v[:1].clone() for k, v in batches[0].items()}
         sample_bayesian(bmodel, small, 2, graph=True)
         sample_bayesian(bmodel, tiny, 2, graph=True)
-        assert len(bmodel._bf_graphed) == 2 and first.graph is None  # the oldest signature was closed
-        for _, s in bmodel._bf_graphed:
+        assert len(cache) == 2 and first.graph is None  # the oldest signature was closed
+        for _, s in cache:
             s.close()
-        bmodel._bf_graphed.clear()
+        cache.clear()
+    assert bfr.STATE.device_counter is None
+
+
+def test_graph_follows_seed_dtype_and_starts_at_the_callers_sample_index():
+    """the seed is a kernel argument, the compute dtype and the sampling plan are fixed at capture — a replay after
+    `manual_seed(other)` / `set_compute_dtype` must not keep drawing from the old key or dtype; and the capture's warm-up
+    steps must not eat sample indices: `manual_seed(s); sample_bayesian(graph=True)` IS the eager call from that state."""
+    import copy
+
+    import bayeformers_amd as bf
+    from bayeformers_amd import random as bfr
+    from bayeformers_amd import sampling
+    from bayeformers_amd.sampling import sample_bayesian
+
+    bmodel, batches = _build(half=False)   # fp32 activations go with every compute dtype
+    bf.set_compute_dtype("bf16")
+    S = 2
+    pick = lambda: (lambda out: (out.logits,))   # a select written at the call site: a new object per call
+    try:
+        with torch.no_grad():
+            for step, (seed, dtype) in enumerate([(SEED, "bf16"), (SEED + 1, "bf16"), (SEED + 1, "fp16"), (SEED, "bf16")]):
+                bf.set_compute_dtype(dtype)
+                bf.manual_seed(seed)
+                want = [_host(sample_bayesian(bmodel, batches[0], S)), _host(sample_bayesian(bmodel, batches[1], S))]
+                bf.manual_seed(seed)   # NO extra rewind after the capture: the first graphed call starts here
+                got0 = sample_bayesian(bmodel, batches[0], S, select=pick(), graph=True)
+                mean0 = got0[1][0]
+                got0 = _host(got0)
+                got1 = _host(sample_bayesian(bmodel, batches[1], S, select=pick(), graph=True))
+                for got, w in zip((got0, got1), want):
+                    assert np.array_equal(got[0], w[0]) and np.array_equal(got[1], w[1]), (step, seed, dtype)
+                    assert got[2] == w[2] and got[3] == w[3], (step, seed, dtype)
+                # the convenience path returns copies of the means: the second call did not overwrite the first's
+                assert np.array_equal(mean0.float().cpu().numpy(), want[0][1])
+                cache = sampling._GRAPHED[bmodel]
+                assert len(cache) == 1 and cache[0][1].captures == step + 1   # one sampler, captured again per change
+        # the model carries no graph: it can be copied while samplers exist
+        assert "_bf_graphed" not in bmodel.__dict__
+        clone = copy.deepcopy(bmodel)
+        assert sum(p.numel() for p in clone.parameters()) == sum(p.numel() for p in bmodel.parameters())
+    finally:
+        bf.set_compute_dtype("bf16")
+        for _, sm in sampling._GRAPHED.get(bmodel, []):
+            sm.close()
     assert bfr.STATE.device_counter is None

@@ -238,6 +238,54 @@ def test_gradient_written_in_place_by_its_producer_needs_no_copy():
     assert not hasattr(w, "_bf_grad_sink")
 
 
+def test_second_gradient_for_a_sunk_parameter_is_never_dropped():
+    """with the opt-in KL gradient a mu / rho gets two gradients per backward.  A producer that has written the
+    first one into the bucket slot (and closed the bucket) must not see the second one silently ignored: with
+    set_kl_gradient(True) the slot is not offered at all (autograd sums, the hook copies the sum); a second defined
+    gradient for an arrived parameter raises."""
+    import bayeformers_amd as bf
+
+    class InPlace(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            ctx.w = w
+            return x @ w
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            sink = getattr(ctx.w, "_bf_grad_sink", None)
+            slot = sink.slot(ctx.w) if sink is not None else None
+            if slot is not None:
+                torch.matmul(x.t(), g, out=slot)
+                sink.arrived(ctx.w)
+                return g @ w.t(), None
+            return g @ w.t(), x.t() @ g
+
+    torch.manual_seed(7)
+    w = torch.nn.Parameter(torch.randn(4, 3))
+    x = torch.randn(6, 4)
+    loss = lambda: InPlace.apply(x, w).sum() + (w * w).sum()   # the second term plays the KL gradient
+    loss().backward()
+    ref = w.grad.clone()
+    buckets = GradientBuckets([w], bucket_bytes=1 << 20)
+    buckets.zero()
+    with pytest.raises(RuntimeError, match="received\\s+another one|already in its bucket slot"):
+        loss().backward()
+    buckets.finish()
+    bf.set_kl_gradient(True)
+    try:
+        buckets.zero()
+        assert buckets.slot(w) is None
+        loss().backward()
+        buckets.finish()
+        np.testing.assert_allclose(w.grad.numpy(), ref.numpy(), rtol=1e-6)
+    finally:
+        bf.set_kl_gradient(False)
+        buckets.remove()
+
+
 def test_buckets_settle_on_the_parameters_that_receive_gradients():
     """requires_grad says too much: the Gaussian priors of a converted model are Parameters no gradient ever reaches (the
     reference's optimizer skips them because .grad stays None).  After the first step the buckets cover only what backward
