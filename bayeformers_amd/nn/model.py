@@ -41,14 +41,17 @@ class _ForwardContext:
     """What the Bayesian layers of one Model.forward share: the reserved sample indices, their log-prob slots and
     (when every layer is plannable) the cross-layer sampling plan."""
 
-    def __init__(self, sample_base: int, S: int, slots: dict, plan=None, lp_buf=None):
+    def __init__(self, sample_base: int, S: int, slots: dict, plan=None, lp_buf=None, shard_start: int = 0):
         self.sample_base, self.S, self._slots = sample_base, S, slots
         self.plan, self.lp_buf = plan, lp_buf
         self.token = next(_TOKENS)
         self.shared_out = {}  # id(first layer of a stacked run) -> (input identity, [L, S, M, N] outputs)
         self.counter = bfr.counter_snapshot()  # device-counter mode: the counter value this forward's kernels added
         self.graph_tasks = set()  # ids of the backward passes that reached this forward's outputs (bfr.remember_context)
-        self.drop_call = bfr.reserve_dropout_call()  # the `call` of every dropout applied inside this forward
+        # the `call` of every dropout applied inside this forward.  On S-sharded ranks the same step's forwards must not
+        # apply the same masks to their (different) samples: the shard's first global sample is folded in (rank 0 / one
+        # process: unchanged), so the dropout noise is independent across the ranks' samples as it is across one rank's.
+        self.drop_call = (bfr.reserve_dropout_call() + (int(shard_start) * 0x9E3779B1)) & 0xFFFFFFFF
 
     @contextlib.contextmanager
     def replay(self):
@@ -161,7 +164,7 @@ class Model(Module):
         base = bfr.reserve_samples(total) + start
         self._last_base, self._last_seed, self._last_S = base, bfr.STATE.seed, S
         self._last_counter = bfr.counter_snapshot() if bfr.STATE.kl_gradient else None
-        ctx = bfr.STATE.ctx = _ForwardContext(base, S, slots, plan, self._lp_buf)
+        ctx = bfr.STATE.ctx = _ForwardContext(base, S, slots, plan, self._lp_buf, shard_start=start)
         out = None
         try:
             out = super(Model, self).__call__(*args, **kwargs)

@@ -121,11 +121,16 @@ def remember_context(ctx, output) -> None:
     def tensors(o, depth=0):
         if isinstance(o, torch.Tensor):
             yield o
-        elif depth < 3 and isinstance(o, dict):
+        elif depth >= 6:
+            return
+        elif isinstance(o, dict):
             for v in o.values():
                 yield from tensors(v, depth + 1)
-        elif depth < 3 and isinstance(o, (tuple, list)):
+        elif isinstance(o, (tuple, list)):
             for v in o:
+                yield from tensors(v, depth + 1)
+        elif hasattr(o, "__dict__") and not isinstance(o, (type, torch.nn.Module)):  # dataclasses, plain result objects
+            for v in vars(o).values():
                 yield from tensors(v, depth + 1)
 
     def stamp(*_):
@@ -155,8 +160,15 @@ def recompute_context():
     hit = [c for c in STATE.live_ctxs if tid in c.graph_tasks]
     if len(hit) == 1:
         return hit[0]
-    if not hit and len(STATE.live_ctxs) == 1:
-        return STATE.live_ctxs[0]  # the loss was built on something other than the model's outputs: the only candidate
+    if not hit:
+        # the loss was built on something the output walk did not reach (an output type it does not know): a forward no
+        # backward pass has claimed yet can still own this one — finished ones (claimed by EARLIER backward passes) cannot.
+        # One such candidate is the answer (the usual forward / backward / forward / backward loop, from its second step
+        # on too); several are ambiguous.
+        free = [c for c in STATE.live_ctxs if not c.graph_tasks]
+        if len(free) == 1:
+            free[0].graph_tasks.add(tid)  # claimed: the rest of this backward finds it at once, later ones pass it over
+            return free[0]
     raise RuntimeError(
         "bayeformers_amd: a Bayesian layer is being recomputed during backward (a checkpointed block) and "
         f"{len(hit) or len(STATE.live_ctxs)} finished bnn.Model forwards could own it; run backward() after each "

@@ -90,7 +90,34 @@ def honoured_env():
     """Every BF_* variable set in this process's environment: they are developer switches that change what is built or
     timed (BF_BENCH_NO_*_FUSION, BF_BENCH_TRAIN_*, BF_BENCH_SHARE_GPU, BF_PLAN_ARENA_BYTES, BF_LIB_PATH, ...), so a line
     produced under any of them says so in its `config` (an empty dict = the defaults the driver measures)."""
-    return {k: os.environ[k] for k in sorted(os.environ) if k.startswith("BF_")}
+    env = {k: os.environ[k] for k in sorted(os.environ) if k.startswith("BF_")}
+    # the one runtime setting multi-process GPU work depends on here (dmabuf IPC; RCCL and CUDA-tensor sharing fail without
+    # it on this driver): always echoed, with where its value came from
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = ipc_mode_setting()
+    return env
+
+
+_IPC_VAR = "HSA_ENABLE_IPC_MODE_LEGACY"
+
+
+def ipc_mode_setting():
+    v = os.environ.get(_IPC_VAR)
+    if v is None:
+        return "(unset)"
+    return v + (" (bench.py default)" if os.environ.get("BF_BENCH_IPC_DEFAULTED") == "1" else " (environment)")
+
+
+def default_ipc_mode(env) -> None:
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 unless the caller's environment says otherwise (any value it holds is kept): the host
+    driver of this pool supports dmabuf IPC only — without it RCCL's hipIpcGetMemHandle fails with `invalid argument`.
+    Must happen before the process (or its children) initialises the HIP runtime.  Logged on stderr."""
+    if _IPC_VAR in env:
+        if env.get("BF_BENCH_IPC_DEFAULTED") != "1":
+            print(f"bench.py: {_IPC_VAR}={env[_IPC_VAR]} (from the environment)", file=sys.stderr)
+        return
+    env[_IPC_VAR] = "0"
+    env["BF_BENCH_IPC_DEFAULTED"] = "1"
+    print(f"bench.py: {_IPC_VAR} was unset, defaulting to 0 (dmabuf IPC; export it to override)", file=sys.stderr)
 
 
 def timed_cpu(fn, n):
@@ -616,7 +643,7 @@ def launch_ranks(args) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    default_ipc_mode(env)
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for line in proc.stdout:
         sys.stdout.write(line)
@@ -624,16 +651,23 @@ def launch_ranks(args) -> int:
     return proc.wait()
 
 
-def dry_run(args, world, rank, device):
-    """Process-group preflight: the SAME group the real run builds (RCCL through init_process_group("nccl", device_id=...)
-    on GPUs) carries the real run's two kinds of message once — the packed fp64 ELBO buffer (66 values, latency-bound)
-    and one 128 MiB gradient bucket (bandwidth-bound, asynchronous like training.GradientBuckets sends it) — and rank 0
-    prints who took part, so an environment problem shows up in seconds, before any model is built."""
+def preflight(args, world, rank, device, samples=None):
+    """Process-group preflight on the group the run has just built (RCCL through init_process_group("nccl", device_id=...)
+    on GPUs): the real run's two kinds of message once — the packed fp64 ELBO buffer (66 values, latency-bound) and one
+    128 MiB gradient bucket (bandwidth-bound, asynchronous like training.GradientBuckets sends it) — and who took part, with
+    the Monte-Carlo samples each rank will run.  Returns the report; report["ok"] is False when an all-reduce of ones did
+    not count exactly `world` ranks."""
+    from bayeformers_amd.sampling import shard_span
+
     line = {"metric": "dry-run", "value": None, "n_gpus": world, "steps": 0, "warmup": 0,
             "backend": dist.get_backend() if world > 1 else None}
     packed = torch.ones(66, dtype=torch.float64, device=device)
     bucket = torch.ones((128 << 20) // 4, dtype=torch.float32, device=device)
     times = {}
+    if samples is not None:
+        start, count = shard_span(samples, rank, world) if args.strong else (rank * samples, samples)
+    else:
+        start = count = None
     if world > 1:
         for name, t in (("packed_fp64_66", packed), ("bucket_128MiB", bucket)):
             dist.all_reduce(t)  # first call: communicator / ring set-up
@@ -649,9 +683,11 @@ def dry_run(args, world, rank, device):
         names = [None] * world
         me = {"rank": rank, "device": str(device),
               "gpu": torch.cuda.get_device_name(device) if device.type == "cuda" else "cpu",
-              "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+              "ipc_mode_legacy": ipc_mode_setting(), "first_sample": start, "samples": count}
         dist.all_gather_object(names, me)
         line["ranks"] = names
+    line["scaling"] = "strong" if args.strong else "weak"
+    line["samples_per_step"] = None if samples is None else (samples if args.strong else samples * world)
     line["ranks_counted"] = int(packed[0].item())
     line["bucket_ranks_counted"] = int(bucket[-1].item())
     line["allreduce_ms"] = times or None
@@ -660,14 +696,24 @@ def dry_run(args, world, rank, device):
             line["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:  # pragma: no cover
             line["rccl_version"] = None
-    ok = line["ranks_counted"] == world and line["bucket_ranks_counted"] == world
-    line["ok"] = ok
+    line["ok"] = line["ranks_counted"] == world and line["bucket_ranks_counted"] == world
+    del packed, bucket
+    return line
+
+
+def dry_run(args, world, rank, device, samples):
+    """--dry-run: the preflight alone, so an environment problem shows up in seconds, before any model is built."""
+    line = preflight(args, world, rank, device, samples)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
-    if not ok:
+    if not line["ok"]:
         sys.exit(3)
+
+
+DEFAULTS = {"bert_base": (10, "bf16"), "bert_base_train": (10, "bf16"), "bert_large_qa": (10, "fp16"),
+            "bert_large_qa_train": (10, "bf16"), "linear768": (10, "bf16"), "linear768_m32": (10, "bf16"), "mlp": (5, "bf16")}
 
 
 def main():
@@ -676,6 +722,8 @@ def main():
     _STRONG = bool(args.strong)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
+    default_ipc_mode(os.environ)  # (ranks started by torch.distributed.run directly: before anything touches the GPU)
+    S = args.samples or DEFAULTS[args.workload][0]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -690,7 +738,7 @@ def main():
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo")
-        return dry_run(args, world, rank, torch.device("cpu"))
+        return dry_run(args, world, rank, torch.device("cpu"), S)
     # developer switches for exercising the N-rank path on a ONE-GPU box (never set by the driver): all ranks on cuda:0 and
     # gloo collectives on the CUDA tensors (RCCL refuses two ranks on one device); the numbers of such a run mean nothing
     share_gpu = os.environ.get("BF_BENCH_SHARE_GPU") is not None
@@ -709,7 +757,18 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     if args.dry_run:
-        return dry_run(args, world, rank, device)
+        return dry_run(args, world, rank, device, S)
+    pre = None
+    if world > 1:
+        # the same preflight inside the real run, before any model is built: a group that does not count N ranks ends the
+        # run with a JSON error line instead of a number measured on fewer GPUs than claimed
+        pre = preflight(args, world, rank, device, S)
+        if not pre["ok"]:
+            if rank == 0:
+                print(json.dumps({"error": "process-group preflight failed: an all-reduce of ones did not count "
+                                           f"{world} ranks", "n_gpus": args.gpus, "preflight": pre}), flush=True)
+            dist.destroy_process_group()
+            sys.exit(3)
 
     import bayeformers_amd as bf
     from bayeformers_amd import _C
@@ -717,9 +776,7 @@ def main():
     if args.calibrate_traffic:
         cal_shapes, cal_m, cal_dt = bert_gemm_shapes(args.workload)
         calibration_probes(device, cal_shapes, S=args.samples or 10, M=cal_m or 4096, dtype=cal_dt or torch.bfloat16)
-    defaults = {"bert_base": (10, "bf16"), "bert_base_train": (10, "bf16"), "bert_large_qa": (10, "fp16"), "bert_large_qa_train": (10, "bf16"), "linear768": (10, "bf16"), "linear768_m32": (10, "bf16"), "mlp": (5, "bf16")}
-    S = args.samples or defaults[args.workload][0]
-    dtype = args.dtype or defaults[args.workload][1]
+    dtype = args.dtype or DEFAULTS[args.workload][1]
     bf.set_compute_dtype(dtype)
     bf.manual_seed(0x5EED)
     if args.workload == "bert_base":
@@ -923,6 +980,9 @@ def main():
             cfgd["samples_per_gpu"] = [shard_span(S, r, n_ranks)[1] for r in range(n_ranks)]
         if by_rank is not None:
             roofline["by_rank"] = by_rank
+        if pre is not None:  # the N-rank run's own preflight: who took part, what the two message kinds cost
+            cfgd["preflight"] = {k: pre[k] for k in ("backend", "ranks", "ranks_counted", "bucket_ranks_counted",
+                                                     "allreduce_ms", "rccl_version") if k in pre}
         cfgd.update({"env": honoured_env(), "parallelism": f"mc-sample-shard x{n_ranks}", "last_elbo": last, "hip_graph": graph_note if harness is not None and graph_note else bool(use_graph),
                      "samples_total": total_samples, "samples_per_step": per_step,
                      "allreduce_ms_per_step": round(allreduce_ms, 4) if allreduce_ms is not None else None})

@@ -46,3 +46,36 @@ def test_world_size_mismatch_is_an_error():
     r = run(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_strong_scaling_of_ten_samples_over_eight_ranks_through_the_launcher():
+    """BASELINE configs[4]'s 8-GPU leg as the driver will launch it (`--strong --samples 10 --gpus 8`): eight rank processes
+    come up, the preflight counts all of them over both message kinds, and the ranks report the uneven shards
+    2, 2, 1, 1, 1, 1, 1, 1 of the step's ten global sample indices."""
+    r = run(["--gpus", "8", "--strong", "--samples", "10", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = last_json(r.stdout)
+    assert out["ok"] and out["n_gpus"] == 8 and out["ranks_counted"] == 8 and out["bucket_ranks_counted"] == 8
+    assert out["scaling"] == "strong" and out["samples_per_step"] == 10
+    ranks = out["ranks"]
+    assert [q["rank"] for q in ranks] == list(range(8))
+    assert [q["samples"] for q in ranks] == [2, 2, 1, 1, 1, 1, 1, 1]
+    assert [q["first_sample"] for q in ranks] == [0, 2, 4, 5, 6, 7, 8, 9]
+    # the IPC setting multi-process GPU work depends on is logged and echoed by every rank, with where it came from
+    assert all(q["ipc_mode_legacy"] is not None for q in ranks)
+
+
+def test_ipc_mode_is_defaulted_logged_and_overridable():
+    r = run(["--gpus", "2", "--dry-run"], {"HSA_ENABLE_IPC_MODE_LEGACY": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert all(q["ipc_mode_legacy"] == "1 (environment)" for q in last_json(r.stdout)["ranks"])
+    assert "HSA_ENABLE_IPC_MODE_LEGACY=1 (from the environment)" in r.stderr
+    env = dict(os.environ)
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                        env={k: v for k, v in dict(env, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="").items()
+                             if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")},
+                        capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert all(q["ipc_mode_legacy"] == "0 (bench.py default)" for q in last_json(r2.stdout)["ranks"])
+    assert "defaulting to 0" in r2.stderr

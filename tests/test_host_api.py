@@ -212,6 +212,58 @@ def test_recompute_context_is_bound_to_the_graph_that_runs_backward():
     assert all(c.shared_out == {} for c in bfr.STATE.live_ctxs) and len(bfr.STATE.live_ctxs) <= bfr.LIVE_CONTEXTS
 
 
+def test_recompute_context_with_outputs_the_walk_does_not_know():
+    """a checkpointed model whose output is a dataclass (walked) or an opaque object (not walkable: no stamped
+    hook) must still find its forward in EVERY training step, not only while one finished forward is remembered."""
+    import dataclasses
+
+    import torch.utils.checkpoint as cp
+
+    from bayeformers_amd import random as bfr
+    from bayeformers_amd.nn.model import Model
+
+    seen = []
+
+    class Probe(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(3))
+
+        def forward(self, x):
+            ctx = bfr.STATE.ctx if bfr.STATE.ctx is not None else bfr.recompute_context()
+            seen.append(None if ctx is None else ctx.sample_base)
+            return x * self.w
+
+    @dataclasses.dataclass
+    class Out:
+        logits: torch.Tensor
+        extra: dict
+
+    class Opaque:
+        __slots__ = ("t",)
+
+        def __init__(self, t):
+            self.t = t
+
+    class Net(Model):
+        def __init__(self, wrap):
+            super().__init__()
+            self.p, self.wrap = Probe(), wrap
+
+        def forward(self, x):
+            return self.wrap(cp.checkpoint(self.p, x, use_reentrant=False))
+
+    x = torch.randn(2, 3, requires_grad=True)
+    for wrap, get in ((lambda t: Out(t, {"k": [t]}), lambda o: o.logits), (Opaque, lambda o: o.t)):
+        bfr.manual_seed(11)
+        net = Net(wrap)
+        for step in range(4):   # more steps than one: finished forwards pile up in live_ctxs
+            out = net(x)
+            del seen[:]
+            get(out).sum().backward()
+            assert seen == [step], (wrap, step, seen)
+
+
 def test_moped_prior_alias_is_decided_on_contents_and_tracks_edits():
     """ops.prior_alias: the sampling kernel may skip the prior's mu / rho (8 instead of 16 bytes per scalar) exactly when
     the prior is N(the posterior's frozen mean, one constant sigma) — what to_bayesian(delta, freeze=True) builds
