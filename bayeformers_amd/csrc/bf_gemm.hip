@@ -307,9 +307,12 @@ int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, con
     }
     if (layers > 1) {
         // L layers sharing x: one launch of the 256x256 kernel when it applies, else one launch per layer
-        const bool fast = gemm_variant() != 0 && w_dtype != BF_DT_F32 && (long long)M * N >= 128 * 128 &&
+        const bool fast = gemm_variant() != 0 && (long long)M * N >= 128 * 128 &&
                           ((uintptr_t)d_bias & 15) == 0 && (long long)layers * S <= 65535 &&
-                          bf_gemm256_supported(x_dtype, w_dtype, y_dtype, layers * S, M, N, K, d_x, d_w, x_sample_stride);
+                          (w_dtype == BF_DT_F32
+                               ? x_dtype == BF_DT_F32 && y_dtype == BF_DT_F32 && getenv("BF_F32_GENERIC") == nullptr &&
+                                     bf_gemm256_f32_supported(layers * S, M, N, K, d_x, d_w, d_y, d_bias, x_sample_stride)
+                               : bf_gemm256_supported(x_dtype, w_dtype, y_dtype, layers * S, M, N, K, d_x, d_w, x_sample_stride));
         if (!fast) {
             const size_t ws = bf_dtype_size(w_dtype), ys = bf_dtype_size(y_dtype);
             for (int l = 0; l < layers; ++l) {
@@ -340,6 +343,12 @@ int bf_launch_gemm_nt(const void* d_x, int x_dtype, int64_t x_sample_stride, con
     p.layers = layers;
     if (w_dtype == BF_DT_F32) {
         if (x_dtype != BF_DT_F32 || y_dtype != BF_DT_F32) BF_FAIL("bf_gemm_nt: fp32 weights need fp32 x and y");
+        // large aligned problems: the 256-wide ring kernel on v_mfma_f32_16x16x4_f32 (BF_F32_GENERIC: developer A/B)
+        static const bool generic_only = getenv("BF_F32_GENERIC") != nullptr;
+        if (!generic_only && (long long)M * N >= 128 * 128 && (long long)layers * S <= 65535 &&
+            bf_gemm256_f32_supported(layers * S, M, N, K, d_x, d_w, d_y, d_bias, x_sample_stride) &&
+            (!d_pre || ((uintptr_t)d_pre & 15) == 0))
+            return bf_launch_gemm256_f32(p, stream);
         p.tiles_m = (M + FM - 1) / FM;
         p.tiles_n = (N + FN - 1) / FN;
         hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3((uint32_t)(p.tiles_m * p.tiles_n), (uint32_t)S), dim3(256), 0,

@@ -46,10 +46,26 @@ constexpr int NSLOT = 5;
 // per block) — about what the LDS round trip costs.  Not pursued.  The W units then use their own 16-byte-chunk swizzle,
 // chunk ^= ((row >> 1) & 1) | (((row >> 4) & 3) << 1): a fragment read touches rows {16 a + b + 4 i} (a, b = 0..3), whose
 // swizzle under the x units' (row >> 1) & 7 would take two values only.
+// T = float (round 5): the reference-precision form.  A unit is still 256 rows x 128 B — 32 fp32 values of k per row and
+// k-step instead of 64 16-bit ones — so the ring, the DMA pieces, the swizzle and the fragment reads (16 bytes = 4
+// consecutive k of a lane's row) are the 16-bit kernel's, byte for byte; a fragment feeds FOUR v_mfma_f32_16x16x4_f32
+// (component c of both operands' vectors = k 4 (lane >> 4) + c of the 16-deep half: the same k in both operands, in a
+// fixed order).  That MFMA runs 1/16 of the 16-bit rate (32 cycles per 2048 flop): an M slot is 4096 cycles beside an L
+// slot of a few hundred, so the k-loop is bound by the matrix pipe alone.  fp32 outputs: the wave-private epilogue moves a
+// 16-row block through ONE 4 KiB slice per wave (eight of them = the one consumed slot).
+template <typename T>
+struct FragOf { using type = typename Mfma16<T>::frag; };
+template <>
+struct FragOf<float> { using type = f32x4_t; };
+
 template <typename T, typename YT, bool TRW = false, bool SEG = false, bool DPPE = false>
 __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams p) {
     static_assert(!DPPE || (!TRW && sizeof(YT) == 2), "the register epilogue belongs to the forward form");
-    using frag = typename Mfma16<T>::frag;
+    static_assert(sizeof(T) == 2 || (!TRW && !SEG && !DPPE && sizeof(YT) == 4), "fp32 operands: forward form, fp32 outputs");
+    using frag = typename FragOf<T>::type;
+    constexpr unsigned ES = sizeof(T);            // bytes per operand element
+    constexpr int TKE = ROW_BYTES / (int)ES;      // k-values per k-step: 64 (16-bit) or 32 (fp32)
+    constexpr int CE = 16 / (int)ES;              // elements per 16-byte chunk
 
     __shared__ __attribute__((aligned(1024))) char smem[NSLOT * SLOT_BYTES];
 
@@ -65,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         int ln = lane;
         asm volatile("" : "+v"(ln));
         prow = ln >> 3;
-        kc8 = ((ln & 7) ^ ((((wid & 1) << 2) + (ln >> 4)) & 7)) * 8;
+        kc8 = ((ln & 7) ^ ((((wid & 1) << 2) + (ln >> 4)) & 7)) * CE;
     };
 
     // DMA sources of the units still to be issued: wave-uniform operand bases + four per-lane BYTE offsets per operand.  Only ONE such set exists: the W half is switched to the workgroup's next tile before the k-step
@@ -73,7 +89,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     const T* xb;
     const T* wb;
     unsigned xo, wo;  // per-lane byte offset of piece 0 (rows 8 wid .. 8 wid + 7); piece i lies 64 rows = `rowblk` bytes further
-    const unsigned rowblk = 64u * (unsigned)K * 2u;
+    const unsigned rowblk = 64u * (unsigned)K * ES;
     // An operand is fetched through a buffer descriptor that ends with the sample's operand: rows past M (N) of a partial
     // tile are out of range and arrive as zeros (their products land in rows / columns the epilogue masks) — no per-row
     // clamp, so ONE offset register per operand instead of four.
@@ -99,8 +115,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                 asm volatile("" : "+v"(ln));
                 kc8 = ((ln & 7) ^ (((ln >> 4) & 1) | ((wid >> 1) << 1))) * 8;
             }
-            wo = ((unsigned)(n0 + wid * 8 + prow) * (unsigned)K + kc8) * 2u;
-            w_bytes = (unsigned)N * (unsigned)K * 2u;
+            wo = ((unsigned)(n0 + wid * 8 + prow) * (unsigned)K + kc8) * ES;
+            w_bytes = (unsigned)N * (unsigned)K * ES;
         }
     };
     auto setup_x = [&](const int4 d) {
@@ -108,8 +124,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         xb = reinterpret_cast<const T*>(p.x) + (long long)__builtin_amdgcn_readfirstlane(d.y) * p.x_sstride;
         int prow, kc8;
         piece_lane(prow, kc8);
-        xo = ((unsigned)(m0 + wid * 8 + prow) * (unsigned)K + kc8) * 2u;
-        x_bytes = (unsigned)M * (unsigned)K * 2u;
+        xo = ((unsigned)(m0 + wid * 8 + prow) * (unsigned)K + kc8) * ES;
+        x_bytes = (unsigned)M * (unsigned)K * ES;
     };
     // one 1 KiB piece: `base` (a buffer of `bytes`) + per-lane byte offset `off` + wave-uniform byte offset `soff` -> LDS `dst`
 #ifndef BF_R5_AUX_X
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         return __builtin_bit_cast(frag, v);
     };
 
-    const int nk = SEG ? p.segs * (K / TK) : K / TK;
+    const int nk = SEG ? p.segs * (K / TK) : K / TKE;
     // the schedule is read through the scalar cache (it was written before the launch): entries arrive in SGPRs
     typedef int sched_i32x4 __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) sched_i32x4 sched_entry;
@@ -280,10 +296,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                 else
 #endif
                 __builtin_amdgcn_s_setprio(1);
+                if constexpr (sizeof(T) == 4) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int c = 0; c < 4; ++c)  // 32 independent MFMAs between two on the same accumulator
 #pragma unroll
-                    for (int j = 0; j < H; ++j) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int j = 0; j < H; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][c], xf[j][c], acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < H; ++j) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
+                }
                 __builtin_amdgcn_s_setprio(0);
             };
             // MODE 0: kt + 2 < nk, every unit issued is this tile's own; 1: kt = nk - 2 (L1 issues the next tile's W(0));
@@ -368,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
             // group 1's last LDS slot, group 1 comes from its last MFMA slot.  The next unit that lands there is W(2) of
             // the next tile, issued behind that tile's second barrier, which every wave reaches after its epilogue; the
             // slot of W of the last k-step takes the next tile's X(1) at once (no wave reads it any more).
-            static_assert(sizeof(YT) == 2, "the one-slot epilogue scratch holds 16-bit outputs");
+            static_assert(sizeof(YT) == 2 || sizeof(T) == 4, "the one-slot epilogue scratch: 16-bit outputs, or fp32 through one slice");
             int sc = a + 4;
             if (sc >= NSLOT) sc -= NSLOT;
             YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
@@ -380,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
             if (p.flags & 8) return;      // ablation: no epilogue
 #endif
             if constexpr (DPPE) epilogue_dpp<YT, H>(acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act);
-            else epilogue_wave<YT, H>(scratch, acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act);
+            else epilogue_wave<YT, H, sizeof(YT) == 2 ? 2 : 1>(scratch, acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act);
         };
         switch (h) {
             case 8: body(std::integral_constant<int, 8>{}); break;
@@ -433,6 +459,34 @@ int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, i
 #endif
     if (w_dtype == BF_DT_BF16) return launch_r5<__bf16, __bf16, false, false>(p, stream, grid);
     return launch_r5<_Float16, _Float16, false, false>(p, stream, grid);
+}
+
+// fp32 operands and outputs (the reference's own precision, /root/reference/bayeformers/nn/parameters/base.py:32,
+// layers/linear.py:104): same schedule, same ring, v_mfma_f32_16x16x4_f32.
+bool bf_gemm256_f32_supported(int S, int M, int N, int K, const void* d_x, const void* d_w, const void* d_y,
+                              const float* d_bias, int64_t x_sample_stride) {
+    if (K % 32 != 0 || K < 64) return false;   // whole 128-byte k-steps, two of them at least
+    if (N % 4 != 0) return false;              // 16-byte bias rows / output chunks
+    if (((uintptr_t)d_x | (uintptr_t)d_w | (uintptr_t)d_y | (uintptr_t)d_bias) & 15) return false;
+    if (((size_t)x_sample_stride * 4) % 16 != 0) return false;
+    // an operand of one sample is addressed by 32-bit byte offsets inside a buffer descriptor of < 2^31 bytes (+ one tile)
+    if ((long long)(M + 256) * K >= (1ll << 28) || (long long)(N + 256) * K >= (1ll << 28) || (long long)M * N >= (1ll << 31)) return false;
+    if (M >= (1 << 24) || (N + TN - 1) / TN >= (1 << 24)) return false;  // schedule entry packing
+    const long long tiles = (long long)((M + UNIT * HMIN - 1) / (UNIT * HMIN)) * ((N + TN - 1) / TN) * S;
+    return tiles <= 0x3FFFFFll;
+}
+
+int bf_launch_gemm256_f32(const GemmParams& p0, hipStream_t stream) {
+    GemmParams p = p0;
+    p.flags = 0;
+    if (p.layers < 1) p.layers = 1;
+    p.tiles_m = (p.M + TM - 1) / TM;
+    p.tiles_n = (p.N + TN - 1) / TN;
+    Gemm256Sched sc;
+    if (bf_gemm256_get_schedule(p.S, p.layers, p.tiles_n, p.M, BF_SCHED_POLICY, stream, sc)) return 1;
+    p.sched = sc.d_table;
+    p.sched_rounds = sc.rounds;
+    return launch_r5<float, float, false, false>(p, stream, sc.grid);
 }
 
 // NN form (x K-contiguous, W contraction-major as sampled, 16-bit out): y[s][m][k] = sum_n x[s][m][n] w[s][n][k]

@@ -33,6 +33,10 @@ struct GemmParams {
 bool bf_gemm256_supported(int x_dtype, int w_dtype, int y_dtype, int S, int M, int N, int K, const void* d_x,
                           const void* d_w, int64_t x_sample_stride);
 int bf_launch_gemm256(const GemmParams& p, int w_dtype, int y_dtype, hipStream_t stream);
+// the same tile, schedule and ring on fp32 operands and outputs, v_mfma_f32_16x16x4_f32 (bf_gemm256_r5.hip)
+bool bf_gemm256_f32_supported(int S, int M, int N, int K, const void* d_x, const void* d_w, const void* d_y,
+                              const float* d_bias, int64_t x_sample_stride);
+int bf_launch_gemm256_f32(const GemmParams& p, hipStream_t stream);
 // TN form (contraction-major operands, fp32 out): out[b][n][k] = sum_m a[b][m][n] * b[b][m][k]
 bool bf_gemm256_tn_supported(int dtype, int batch, int Mc, int Nl, int Kl, const void* d_a, const void* d_b,
                              const void* d_out);

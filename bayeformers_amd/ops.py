@@ -285,7 +285,14 @@ def gemm_nn_layers(x: Tensor, w: Tensor) -> Tensor:
 
 
 class LinearPlan:
-    """Cached ctypes descriptors of one bnn.Linear (pointers are refreshed per call; structs are reused)."""
+    """Cached ctypes descriptors of one bnn.Linear (pointers are refreshed per call; structs are reused).  A cache only:
+    copying or pickling the layer starts it afresh (ctypes structs holding pointers can be neither)."""
+
+    def __deepcopy__(self, memo):
+        return LinearPlan()
+
+    def __reduce__(self):
+        return (LinearPlan, ())
 
     def __init__(self):
         self.w = _C.bf_tensor_t()

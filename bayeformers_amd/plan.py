@@ -35,7 +35,19 @@ GROUP_BYTES = 96 << 20
 ARENA_BYTES = int(os.environ.get("BF_PLAN_ARENA_BYTES", str(16 << 30)))
 
 
+def _no_plan():
+    return None
+
+
 class SamplePlan:
+    # a cache of a bnn.Model (arenas of sampled weights, a device table of raw pointers): a copied or pickled model gets
+    # none and builds its own at its first forward
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_no_plan, ())
+
     def __init__(self, layers, S: int, cdt: torch.dtype, device: torch.device, index=None, shared=()):
         """layers: the planned bnn.Linear modules; index[i] = row of layers[i] in the model's [L, S, 2] log-prob
         buffer (layers that take the single-kernel small-M path are left out, so rows may have gaps).

@@ -175,6 +175,10 @@ BENCH_NT_SHAPES = [
     (10, 1, 6144, 4096, 1024, 1, torch.float16),    # BERT-large FFN-up + GELU
     (10, 1, 6144, 1024, 4096, 0, torch.float16),    # BERT-large FFN-down
     (10, 3, 6144, 1024, 1024, 0, torch.float16),    # BERT-large query / key / value
+    # the reference's own precision (--dtype fp32): the same ring on v_mfma_f32_16x16x4_f32, fp32 operands and outputs
+    (10, 1, 4096, 768, 768, 0, torch.float32), (10, 1, 4096, 768, 3072, 0, torch.float32),
+    (10, 1, 4096, 3072, 768, 1, torch.float32), (10, 3, 4096, 768, 768, 0, torch.float32),
+    (3, 1, 1000, 520, 96, 1, torch.float32),        # ragged M and N, three k-steps
 ]
 
 
@@ -186,7 +190,7 @@ def test_gemm_nt_benchmarked_shapes_all_rows_against_fp64(S, L, M, N, K, act, dt
     b = torch.randn(L, S, N, device="cuda", generator=g)
     y = ops.gemm_nt_layers(x, w, b, L, S, M, N, K, M * K, dt, act)
     assert y.shape == (L, S, M, N) and y.dtype == dt
-    tol = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    tol = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11, torch.float32: 1e-5}[dt]
     xd = x.double()
     worst = 0.0
     for l in range(L):  # one layer at a time: the fp64 reference of a whole launch is 1-3 GB
