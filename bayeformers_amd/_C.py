@@ -70,7 +70,7 @@ SYMBOLS = {
     "bf_linear_fwd": (_i, [_vp, _i, _i64, _tp, _tp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u32, _vp, _vp, _sz, _vp]),
     "bf_linear_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "bf_linear_bwd": (_i, [_vp, _i64, _vp, _i, _tp, _tp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u64, _u32, _i, _vp,
-                           _vp, _sz, _vp]),
+                           _vp, _vp, _sz, _vp]),
     "bf_kl_grad": (_i, [_tp, _i, _u64, _u32, _vp, _vp, _vp, _vp]),
     "bf_embedding_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i64, _i, _u64, _u32, _u32, _vp]),
     "bf_embedding_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i64, _i64, _i, _u64, _u32, _u32, _vp]),
@@ -92,6 +92,10 @@ SYMBOLS = {
                                           ctypes.c_float, _u64, _u32, _u32, _vp]),
     "bf_add_layernorm_bwd_sum": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i64, _i, ctypes.c_float,
                                       ctypes.c_float, _u64, _u32, _u32, _vp]),
+    "bf_attention_bwd_colsum": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64,
+                                     ctypes.c_float, ctypes.c_float, _vp, _i, _vp, _vp, _vp]),
+    "bf_add_layernorm_bwd_colsum": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i64, _i,
+                                         ctypes.c_float, ctypes.c_float, _u64, _u32, _u32, _i, _vp, _vp]),
     "bf_profile_enable": (_i, [_i]),
     "bf_profile_reset": (_i, []),
     "bf_probe_stream_read": (_i, [_vp, _sz, _vp, _vp]),

@@ -500,6 +500,20 @@ int bf_attention_bwd_dropout(const void* d_q, const void* d_k, const void* d_v, 
                                    d.thresh ? d_keep_bits : nullptr, d.inv_keep);
 }
 
+int bf_attention_bwd_colsum(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
+                            const void* d_out, const void* d_dout, const float* d_lse, float* d_delta, void* d_dq, void* d_dk,
+                            void* d_dv, int dtype, int B, int T, int H, int head_dim, int64_t token_stride, float scaling,
+                            float p_drop, const uint32_t* d_keep_bits, int samples, float* d_partial, float* d_colsum,
+                            void* stream) {
+    if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_attention_bwd_colsum: p must be in [0, 1) (got %g)", p_drop);
+    if (!d_partial || !d_colsum) BF_FAIL("bf_attention_bwd_colsum: needs d_partial ([B][H][3][64] fp32) and d_colsum ([3][samples][H*64] fp32)");
+    const bf_dropout_t d = make_dropout(p_drop, 0, 0, 0);
+    if (d.thresh && !d_keep_bits) BF_FAIL("bf_attention_bwd_colsum: the forward's keep bits are needed");
+    return bf_launch_attention_bwd(d_q, d_k, d_v, d_mask, d_mask_off, d_out, d_dout, d_lse, d_delta, d_dq, d_dk, d_dv, dtype,
+                                   B, T, H, head_dim, token_stride, scaling, (hipStream_t)stream,
+                                   d.thresh ? d_keep_bits : nullptr, d.inv_keep, samples, d_partial, d_colsum);
+}
+
 int bf_add_layernorm_dropout(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, int param_dtype,
                              void* d_out, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed, uint32_t call,
                              uint32_t site, void* stream) {
@@ -528,6 +542,18 @@ int bf_add_layernorm_bwd_sum(const void* d_x, const void* d_residual, const void
     return bf_launch_add_layernorm_bwd(d_x, d_residual, d_gamma, param_dtype, d_dy, d_dz, d_dgamma, d_dbeta, d_workspace,
                                        workspace_bytes, dtype, rows, N, eps, (hipStream_t)stream, d.thresh ? &d : nullptr, d_dx,
                                        d_dy2);
+}
+
+int bf_add_layernorm_bwd_colsum(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,
+                                const void* d_dy2, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
+                                size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
+                                uint32_t call, uint32_t site, int samples, float* d_colsum, void* stream) {
+    if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_add_layernorm_bwd_colsum: p must be in [0, 1) (got %g)", p_drop);
+    if (!d_colsum || samples < 1) BF_FAIL("bf_add_layernorm_bwd_colsum: needs d_colsum and samples >= 1");
+    const bf_dropout_t d = make_dropout(p_drop, seed, call, site);
+    return bf_launch_add_layernorm_bwd(d_x, d_residual, d_gamma, param_dtype, d_dy, d_dz, d_dgamma, d_dbeta, d_workspace,
+                                       workspace_bytes, dtype, rows, N, eps, (hipStream_t)stream, d.thresh ? &d : nullptr, d_dx,
+                                       d_dy2, samples, d_colsum);
 }
 
 size_t bf_add_layernorm_bwd_workspace_bytes(int64_t rows, int N) { return bf_add_layernorm_bwd_ws_bytes(rows, N); }
@@ -625,7 +651,7 @@ size_t bf_linear_bwd_workspace_bytes(int S, int M, int N, int K, int has_bias, i
 int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, int dtype, const bf_tensor_t* weight,
                   const bf_tensor_t* bias, void* d_dx, float* d_dmu_w, float* d_drho_w, float* d_dmu_b,
                   float* d_drho_b, int S, int M, int N, int K, uint64_t seed, uint32_t sample_base, int act,
-                  const void* d_act_pre, void* d_workspace, size_t workspace_bytes, void* stream_) {
+                  const void* d_act_pre, const float* d_dy_colsum, void* d_workspace, size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d_x || !d_dy || !weight || !d_drho_w) BF_FAIL("bf_linear_bwd: NULL argument");
     if (act != BF_ACT_NONE && act != BF_ACT_GELU) BF_FAIL("bf_linear_bwd: unknown activation %d", act);
@@ -714,10 +740,14 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
                                    sample_base, weight->stream_id, d_dmu_w, d_drho_w, stream)))
         return rc;
     if (bias) {
-        if (!fused_colsum && (rc = bf_launch_colsum(d_dy, dtype, reinterpret_cast<float*>(ws + L.db), S, M, N,
-                                                    reinterpret_cast<float*>(ws + L.dbp), stream)))
+        // the column sums of dy: from the pass that formed dy (fused activation / transpose), from the kernel that produced
+        // d_dy (d_dy_colsum), or a pass of their own
+        const float* colsum = reinterpret_cast<const float*>(ws + L.db);
+        if (!fused_colsum && d_dy_colsum && act == BF_ACT_NONE) colsum = d_dy_colsum;
+        else if (!fused_colsum && (rc = bf_launch_colsum(d_dy, dtype, reinterpret_cast<float*>(ws + L.db), S, M, N,
+                                                         reinterpret_cast<float*>(ws + L.dbp), stream)))
             return rc;
-        if ((rc = bf_launch_param_grad(reinterpret_cast<const float*>(ws + L.db), bias->d_rho, bias->n, S, 1, seed,
+        if ((rc = bf_launch_param_grad(colsum, bias->d_rho, bias->n, S, 1, seed,
                                        sample_base, bias->stream_id, d_dmu_b, d_drho_b, stream)))
             return rc;
     }

@@ -22,6 +22,22 @@
 
 namespace {
 
+// BF_ATTN_OUT_STORES: how the attention output rows (the x of the attention-out GEMM that runs next) are written — 0 plain
+// (product), 1 nontemporal, 2 sc1, 3 sc0 sc1 (write-through).  Measured in the BERT-base step, one box, interleaved runs
+// (profiles/r5e_attention_store_policy_ab.txt): no policy beats plain stores.
+#ifndef BF_ATTN_OUT_STORES
+#define BF_ATTN_OUT_STORES 0
+#endif
+template <typename V>
+__device__ __forceinline__ void attn_st8(V* p, V v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    if (BF_ATTN_OUT_STORES == 1) __builtin_nontemporal_store(v, p);
+    else if (BF_ATTN_OUT_STORES == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u32x2, v)) : "memory");
+    else if (BF_ATTN_OUT_STORES == 3) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u32x2, v)) : "memory");
+    else *p = v;
+}
+
+
 constexpr int HD = 64;          // head size
 constexpr int TQ = 128;         // queries per workgroup
 constexpr int TKEY = 128;       // keys per tile
@@ -236,7 +252,7 @@ __global__ __launch_bounds__(256, DROP ? BF_ATTN_DROP_WGS : 3) void attention_fw
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             const f32x4_t r = o[qi][db] * inv;
-            *reinterpret_cast<half4*>(orow + db * 16 + lg * 4) = __builtin_convertvector(r, half4);
+            attn_st8(reinterpret_cast<half4*>(orow + db * 16 + lg * 4), __builtin_convertvector(r, half4));
         }
     }
 }

@@ -17,6 +17,7 @@
 //     the transpose read.
 // Algorithmic HBM bytes: dq kernel 5 reads (Q, K, V, O, dO) + 1 write; dk/dv kernel 4 reads + 2 writes, x B*T*H*64*2 B.
 #include "bf_common.h"
+#include "bf_device.h"
 
 namespace {
 
@@ -71,6 +72,10 @@ struct BwdParams {
     // 1 / (1 - p) factor.  NULL: no dropout.  With P~ = P o keep / (1 - p):  dV = P~^T dO,  dS = P o (keep / (1 - p) o dP~ - delta).
     const uint32_t* keep_bits;
     float inv_keep;
+    // one-tile kernel only (round 5): per (sequence, head) the sums over the 128 tokens of dq, dk, dv AS STORED —
+    // [B][H][3][64] fp32 — from which attention_colsum_finish_kernel makes the per-sample column sums that the Bayesian
+    // query / key / value layers take as their bias gradient (bf_linear_bwd: d_dy_colsum).  NULL: not wanted.
+    float* cs_partial;
 };
 
 // stage a [128][64] tile (rows `row0`.. of a [tokens][stride] tensor) into the swizzled and / or the padded image
@@ -457,10 +462,31 @@ __global__ __launch_bounds__(512, 4) void attention_bwd_tile_kernel(const BwdPar
     }
     T* dkb = reinterpret_cast<T*>(p.dk) + (long long)b * p.T * ostride + hoff;
     T* dvb = reinterpret_cast<T*>(p.dv) + (long long)b * p.T * ostride + hoff;
+    // column sums of this tile's dq / dk / dv: [8 waves][3][64] floats in the 12 KiB between the K image (kp, 20 KiB over
+    // qs | dos) and the padded images — dead since S and dP were formed
+    float* const cs = reinterpret_cast<float*>(smem + P_BYTES);
+    auto colsum_rows = [&](const half4 (&v)[4], int t) {  // the wave's 16 rows of one tensor, as stored
 #pragma unroll
-    for (int db = 0; db < 4; ++db) {
-        *reinterpret_cast<half4*>(dkb + row * ostride + db * 16 + lg * 4) = __builtin_convertvector(dk[db] * p.scale, half4);
-        *reinterpret_cast<half4*>(dvb + row * ostride + db * 16 + lg * 4) = __builtin_convertvector(dv[db], half4);
+        for (int db = 0; db < 4; ++db) {
+            f32x4_t r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = row_sum((float)v[db][j]);
+            if (li == 15) *reinterpret_cast<f32x4_t*>(cs + (wid * 3 + t) * HD + db * 16 + lg * 4) = r;
+        }
+    };
+    {
+        half4 hk[4], hv[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            hk[db] = __builtin_convertvector(dk[db] * p.scale, half4);
+            hv[db] = __builtin_convertvector(dv[db], half4);
+            *reinterpret_cast<half4*>(dkb + row * ostride + db * 16 + lg * 4) = hk[db];
+            *reinterpret_cast<half4*>(dvb + row * ostride + db * 16 + lg * 4) = hv[db];
+        }
+        if (p.cs_partial) {
+            colsum_rows(hk, 1);
+            colsum_rows(hv, 2);
+        }
     }
 
     __syncthreads();  // every wave has read the last of Q, dO and their transposes
@@ -482,9 +508,32 @@ __global__ __launch_bounds__(512, 4) void attention_bwd_tile_kernel(const BwdPar
         for (int db = 0; db < 4; ++db) dq[db] = Mfma<T>::run(tr_frag<T>(kp, c, db, li, lg), dsf, dq[db]);
     }
     T* dqb = reinterpret_cast<T*>(p.dq) + (long long)b * p.T * ostride + hoff;
+    half4 hq[4];
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
-        *reinterpret_cast<half4*>(dqb + row * ostride + db * 16 + lg * 4) = __builtin_convertvector(dq[db] * p.scale, half4);
+    for (int db = 0; db < 4; ++db) {
+        hq[db] = __builtin_convertvector(dq[db] * p.scale, half4);
+        *reinterpret_cast<half4*>(dqb + row * ostride + db * 16 + lg * 4) = hq[db];
+    }
+    if (p.cs_partial) {
+        colsum_rows(hq, 0);
+        __syncthreads();
+        if (tid < 3 * HD) {  // fixed order over the 8 waves: deterministic
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) acc += cs[w * 3 * HD + tid];
+            p.cs_partial[((long long)b * p.H + h) * 3 * HD + tid] = acc;
+        }
+    }
+}
+
+// out[t][s][h * 64 + d] = sum over the sequences of sample s of partial[b][h][t][d]; grid = (3 H, S), 64 threads
+__global__ __launch_bounds__(64) void attention_colsum_finish_kernel(const float* __restrict__ partial, int seq_per_sample, int H,
+                                                                     int S, float* __restrict__ out) {
+    const int t = blockIdx.x / H, h = blockIdx.x % H, s = blockIdx.y, d = threadIdx.x;
+    float acc = 0.f;
+    for (int i = 0; i < seq_per_sample; ++i)
+        acc += partial[(((long long)s * seq_per_sample + i) * H + h) * 3 * HD + t * HD + d];
+    out[((long long)t * S + s) * H * HD + h * HD + d] = acc;
 }
 
 }  // namespace
@@ -493,9 +542,11 @@ int bf_launch_attention_bwd(const void* d_q, const void* d_k, const void* d_v, c
                             const unsigned char* d_mask_off, const void* d_out, const void* d_dout, const float* d_lse,
                             float* d_delta, void* d_dq, void* d_dk, void* d_dv, int dtype, int B, int T, int H,
                             int head_dim, long long token_stride, float scaling, hipStream_t stream,
-                            const uint32_t* d_keep_bits, float inv_keep) {
+                            const uint32_t* d_keep_bits, float inv_keep, int samples, float* d_cs_partial, float* d_colsum) {
     if (!d_q || !d_k || !d_v || !d_out || !d_dout || !d_lse || !d_delta || !d_dq || !d_dk || !d_dv)
         BF_FAIL("bf_attention_bwd: NULL argument");
+    if (d_colsum && (T != TT || !d_cs_partial || samples < 1 || B % samples || samples > 65535))
+        BF_FAIL("bf_attention_bwd: column sums need one-tile sequences (T = %d), a partial buffer and B %% samples == 0", TT);
     if (dtype != BF_DT_BF16 && dtype != BF_DT_F16) BF_FAIL("bf_attention_bwd: dtype must be bf16 or fp16");
     if (head_dim != HD) BF_FAIL("bf_attention_bwd: head size %d (only %d)", head_dim, HD);
     if (B < 1 || H < 1 || T < TT || T % TT) BF_FAIL("bf_attention_bwd: T=%d must be a positive multiple of %d", T, TT);
@@ -526,7 +577,15 @@ int bf_launch_attention_bwd(const void* d_q, const void* d_k, const void* d_v, c
     p.scale_log2e = scaling * 1.4426950408889634f;
     p.keep_bits = d_keep_bits;
     p.inv_keep = inv_keep;
+    p.cs_partial = d_colsum ? d_cs_partial : nullptr;
     const dim3 grid(T / TT, H, B);
+    auto finish = [&]() -> int {
+        if (d_colsum)
+            hipLaunchKernelGGL(attention_colsum_finish_kernel, dim3(3 * H, samples), dim3(64), 0, stream, d_cs_partial, B / samples,
+                               H, samples, d_colsum);
+        BF_HIP_CHECK(hipGetLastError());
+        return 0;
+    };
     if (d_keep_bits) {
         if ((uintptr_t)d_keep_bits & 3) BF_FAIL("bf_attention_bwd: keep bits must be 4-byte aligned");
         if (T == TT) {
@@ -539,14 +598,12 @@ int bf_launch_attention_bwd(const void* d_q, const void* d_k, const void* d_v, c
             hipLaunchKernelGGL((attention_bwd_dq_kernel<_Float16, true>), grid, dim3(256), 0, stream, p);
             hipLaunchKernelGGL((attention_bwd_dkv_kernel<_Float16, true>), grid, dim3(512), 0, stream, p);
         }
-        BF_HIP_CHECK(hipGetLastError());
-        return 0;
+        return finish();
     }
     if (T == TT) {  // one tile: dQ, dK, dV in one launch
         if (dtype == BF_DT_BF16) hipLaunchKernelGGL(attention_bwd_tile_kernel<__bf16>, grid, dim3(512), 0, stream, p);
         else hipLaunchKernelGGL(attention_bwd_tile_kernel<_Float16>, grid, dim3(512), 0, stream, p);
-        BF_HIP_CHECK(hipGetLastError());
-        return 0;
+        return finish();
     }
     if (dtype == BF_DT_BF16) {
         hipLaunchKernelGGL(attention_bwd_dq_kernel<__bf16>, grid, dim3(256), 0, stream, p);

@@ -212,9 +212,11 @@ int bf_launch_attention_bwd(const void* d_q, const void* d_k, const void* d_v, c
                             const unsigned char* d_mask_off, const void* d_out, const void* d_dout, const float* d_lse,
                             float* d_delta, void* d_dq, void* d_dk, void* d_dv, int dtype, int B, int T, int H,
                             int head_dim, long long token_stride, float scaling, hipStream_t stream,
-                            const uint32_t* d_keep_bits = nullptr, float inv_keep = 1.0f);
+                            const uint32_t* d_keep_bits = nullptr, float inv_keep = 1.0f, int samples = 0,
+                            float* d_cs_partial = nullptr, float* d_colsum = nullptr);
 size_t bf_add_layernorm_bwd_ws_bytes(long long rows, int N);
 int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
                                 const void* d_dy, void* d_dz, float* d_dgamma, float* d_dbeta, void* d_workspace,
                                 size_t workspace_bytes, int dtype, long long rows, int N, float eps, hipStream_t stream,
-                                const bf_dropout_t* drop = nullptr, void* d_dx = nullptr, const void* d_dy2 = nullptr);
+                                const bf_dropout_t* drop = nullptr, void* d_dx = nullptr, const void* d_dy2 = nullptr,
+                                int samples = 0, float* d_colsum = nullptr);

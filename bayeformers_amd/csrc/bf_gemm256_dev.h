@@ -55,6 +55,16 @@ struct Mfma16<_Float16> {
     }
 };
 
+template <>
+struct Mfma16<float> {  // a 16-byte fragment = 4 consecutive k of fp32: four 16x16x4 MFMAs (bf_gemm256_r5.hip orders them itself)
+    using frag = f32x4_t;
+    static __device__ __forceinline__ f32x4_t run(frag a, frag b, f32x4_t c) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[k], c, 0, 0, 0);
+        return c;
+    }
+};
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
@@ -132,7 +142,8 @@ __device__ __forceinline__ f32x4_t act_chunk(f32x4_t c, int act) {
 // when a wave gets here, see the kernel).
 template <typename YT, int H, int SLICES = 2>
 __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc)[4][H], YT* y, YT* y2, int m0,
-                                              int m_end, int n0, int N, int wm, int wn, int lane, int act) {
+                                              int m_end, int n0, int N, int wm, int wn, int lane, int act,
+                                              int act_done = 0) {  // act_done: blocks 0 .. act_done - 1 are activated already
     constexpr int ROWB = 64 * (int)sizeof(YT);   // 128 or 256
     constexpr int BLK = 16 * ROWB;               // 2 or 4 KiB
     constexpr int CH = ROWB / 16;                // 16-byte chunks per row: 8 or 16
@@ -158,7 +169,7 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
         char* R = scratch + (SLICES == 2 ? (mb & 1) * BLK : 0);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            const f32x4_t v = y2 ? acc[nb][mb] : bf_apply_act<sizeof(YT) == 2>(acc[nb][mb], act);
+            const f32x4_t v = (y2 || mb < act_done) ? acc[nb][mb] : bf_apply_act<sizeof(YT) == 2>(acc[nb][mb], act);
             char* dst = R + wr_off[nb];
             if constexpr (sizeof(YT) == 4)
                 *reinterpret_cast<f32x4_t*>(dst) = v;

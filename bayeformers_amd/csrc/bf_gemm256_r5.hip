@@ -26,6 +26,9 @@
 
 namespace {
 
+#ifndef BF_R5_EARLY_ACT
+#define BF_R5_EARLY_ACT 0  // experiment, see `mfmas` below: an extra instantiation (EA) for launches with a fused activation
+#endif
 constexpr int SLOT_BYTES = 32768;  // one unit: 256 rows x 128 B (= X_BYTES)
 constexpr int NSLOT = 5;
 
@@ -58,7 +61,7 @@ struct FragOf { using type = typename Mfma16<T>::frag; };
 template <>
 struct FragOf<float> { using type = f32x4_t; };
 
-template <typename T, typename YT, bool TRW = false, bool SEG = false, bool DPPE = false>
+template <typename T, typename YT, bool TRW = false, bool SEG = false, bool DPPE = false, bool EA = false>
 __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams p) {
     static_assert(!DPPE || (!TRW && sizeof(YT) == 2), "the register epilogue belongs to the forward form");
     static_assert(sizeof(T) == 2 || (!TRW && !SEG && !DPPE && sizeof(YT) == 4), "fp32 operands: forward form, fp32 outputs");
@@ -290,7 +293,36 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
 #endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
-            auto mfmas = [&] {
+#if 0
+#define BF_R5_EARLY_ACT_DOC 0  // experiment: the tile's LAST MFMA slot runs row block by row block and the
+// fused activation of block j - 2 is applied in place between the MFMAs of block j, so that the GELU's VALU time of the
+// first H - 2 blocks lies under matrix-pipe time instead of in the epilogue.  Bit-identical outputs.  Measured in the
+// BERT-base step (profiles/r5e_ring_early_act_ab.txt): see DESIGN.md / LABBOOK.md — not adopted.
+#endif
+#ifndef BF_R5_EARLY_LAG
+#define BF_R5_EARLY_LAG 2   // the activation trails the MFMAs by this many row blocks (more = fewer live fragments beside it)
+#endif
+            constexpr int LAG = BF_R5_EARLY_LAG;
+            int act_done = 0;  // row blocks whose activation is already applied when the epilogue starts
+            auto mfmas = [&](auto lastc) {
+                if constexpr (EA && decltype(lastc)::value && sizeof(T) == 2 && !TRW && (H > LAG)) {
+                    {  // (EA instantiation: launched for act != NONE without a pre-activation output)
+                        __builtin_amdgcn_s_setprio(1);
+                        static_for<0, H>([&](auto jc) {
+                            constexpr int j = decltype(jc)::value;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
+                            if constexpr (j >= LAG) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) acc[i][j - LAG] = bf_apply_act<true>(acc[i][j - LAG], p.act);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        });
+                        __builtin_amdgcn_s_setprio(0);
+                        act_done = H - LAG;
+                        return;
+                    }
+                }
 #ifdef BF_DEV
                 if (p.flags & 8192) __builtin_amdgcn_s_setprio(0);  // experiment: no priority for the MFMA slot
                 else
@@ -354,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                 read_frags(a, ax, std::integral_constant<int, 0>{});
                 __builtin_amdgcn_sched_barrier(0);
                 if (lock) __builtin_amdgcn_s_barrier();
-                mfmas();
+                mfmas(std::false_type{});
                 if (BF_R5_SPLIT) dma0(2, 4);
                 __builtin_amdgcn_sched_barrier(0);
                 if (lock) __builtin_amdgcn_s_barrier();
@@ -363,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                 if (wm == 1) wait_all_but_newest();
                 __builtin_amdgcn_sched_barrier(0);
                 if (lock || wm == 1) __builtin_amdgcn_s_barrier();
-                mfmas();
+                mfmas(std::integral_constant<bool, MODE == 2>{});
                 if (BF_R5_SPLIT) dma1(2, 4);
                 if (wm == 0) wait_all_but_newest();
                 __builtin_amdgcn_sched_barrier(0);
@@ -406,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
             if (p.flags & 8) return;      // ablation: no epilogue
 #endif
             if constexpr (DPPE) epilogue_dpp<YT, H>(acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act);
-            else epilogue_wave<YT, H, sizeof(YT) == 2 ? 2 : 1>(scratch, acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act);
+            else epilogue_wave<YT, H, sizeof(YT) == 2 ? 2 : 1>(scratch, acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act, act_done);
         };
         switch (h) {
             case 8: body(std::integral_constant<int, 8>{}); break;
@@ -426,9 +458,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     }
 }
 
-template <typename T, typename YT, bool TRW, bool SEG, bool DPPE = false>
+template <typename T, typename YT, bool TRW, bool SEG, bool DPPE = false, bool EA = false>
 int launch_r5(const GemmParams& p, hipStream_t stream, int grid) {
-    hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, TRW, SEG, DPPE>), dim3(grid), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, TRW, SEG, DPPE, EA>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -456,6 +488,12 @@ int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, i
     }
 #else
     (void)reg_epilogue;
+#endif
+#if BF_R5_EARLY_ACT
+    if (p.act != BF_ACT_NONE && !p.y2) {
+        if (w_dtype == BF_DT_BF16) return launch_r5<__bf16, __bf16, false, false, false, true>(p, stream, grid);
+        return launch_r5<_Float16, _Float16, false, false, false, true>(p, stream, grid);
+    }
 #endif
     if (w_dtype == BF_DT_BF16) return launch_r5<__bf16, __bf16, false, false>(p, stream, grid);
     return launch_r5<_Float16, _Float16, false, false>(p, stream, grid);

@@ -139,8 +139,14 @@ struct BodyArgs {
 // block = 256 threads; a thread owns kGPT groups of 4 consecutive scalars (group j of thread t = group j*256 + t of the
 // block: 16-byte loads stay contiguous across the wave) x the samples of chunk blockIdx.y.  Several groups per thread
 // amortise the two wave reductions a sample needs (about a quarter of the per-sample instructions at one group).
-template <int PRIOR, int OUT_DT>
-__device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][kMaxSChunk][2], float (*cst)[2]) {
+// raw mu / rho of a block's full groups, loaded ahead of the block that runs before it (bf_sample_table_pair_kernel)
+struct PreLoaded {
+    f32x4_t mu[kGPT], rho[kGPT];
+};
+
+template <int PRIOR, int OUT_DT, bool PRE = false>
+__device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][kMaxSChunk][2], float (*cst)[2],
+                                            const PreLoaded* pre = nullptr) {
     constexpr int G = kGPT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,8 +169,13 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][k
         for (int i = 0; i < 4; ++i) mu[j][i] = sigma[j][i] = pmu[j][i] = pinv[j][i] = 0.f;
         if (nvalid[j] > 0) {
             float rho[4];
-            load4(a.mu, e0[j], nvalid[j], a.vec_in, mu[j]);
-            load4(a.rho, e0[j], nvalid[j], a.vec_in, rho);
+            if constexpr (PRE) {  // (the caller checked: every group of this block is full and 16-byte aligned)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mu[j][i] = pre->mu[j][i], rho[i] = pre->rho[j][i];
+            } else {
+                load4(a.mu, e0[j], nvalid[j], a.vec_in, mu[j]);
+                load4(a.rho, e0[j], nvalid[j], a.vec_in, rho);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 sigma[j][i] = softplus_fast(rho[i]);
@@ -419,6 +430,60 @@ __global__ __launch_bounds__(kThreads, ONLY >= 0 ? BF_SAMPLE_ONLY_WAVES : 1) voi
     else sample_body<BF_PRIOR_NONE, OUT_RUNTIME>(a, red, cst);
 }
 
+#ifndef BF_SAMPLE_PAIR
+#define BF_SAMPLE_PAIR 0  // experiment: at S <= BF_SAMPLE_PAIR samples per launch a workgroup takes TWO
+// consecutive table blocks and has the mu / rho loads of the second in flight while it works on the first (the memory-bound
+// regime of the strong-scaling shards: S_local = 1, 2).  Measured: profiles/r5e_sampling_pair_ab.txt — not adopted.
+#endif
+#if BF_SAMPLE_PAIR
+template <int ONLY>
+__global__ __launch_bounds__(kThreads) void bf_sample_table_pair_kernel(const TableEntry* __restrict__ table,
+                                                                        const uint32_t* __restrict__ entry_of_block,
+                                                                        uint32_t block0, uint32_t block_end, int S, int ny,
+                                                                        uint32_t k0, uint32_t k1, uint32_t sample_base,
+                                                                        const uint32_t* __restrict__ counter,
+                                                                        double* __restrict__ partials, uint32_t* stale) {
+    __shared__ float red[4][4][kMaxSChunk][2];
+    __shared__ float cst[4][2];
+    const int tid = threadIdx.x;
+    const uint32_t base = sample_base + (counter ? *counter : 0u);
+    auto args_of = [&](uint32_t gb) {
+        const TableEntry& e = table[entry_of_block[gb]];
+        BodyArgs a;
+        a.mu = e.mu; a.rho = e.rho; a.mu_p = e.mu_p; a.rho_p = e.rho_p; a.out = e.out; a.n = e.n;
+        a.a1 = e.a1; a.b1 = e.b1; a.a2 = e.a2; a.b2 = e.b2;
+        a.stream = e.stream; a.rel_block = gb - e.block_begin;
+        a.vec_in = e.vec_in; a.vec_out = e.vec_out; a.out_dt = e.out_dt;
+        a.S = S; a.ny = ny; a.k0 = k0; a.k1 = k1; a.sample_base = base;
+        a.partial_row = partials + (size_t)gb * S * 2;
+        a.chk = e.chk; a.rho_alias = e.rho_alias; a.stale = stale;
+        return a;
+    };
+    const uint32_t gb0 = block0 + 2 * blockIdx.x, gb1 = gb0 + 1;
+    const BodyArgs a0 = args_of(gb0);
+    if (gb1 >= block_end) {
+        sample_body<ONLY, OUT_RUNTIME>(a0, red, cst);
+        return;
+    }
+    const BodyArgs a1 = args_of(gb1);
+    // the second block's parameters first (they return first: loads complete in order), when all of its groups are full
+    const bool full = a1.vec_in && ((unsigned long long)(a1.rel_block + 1) * kThreads * kEPT <= a1.n);
+    PreLoaded pre;
+    if (full) {
+#pragma unroll
+        for (int j = 0; j < kGPT; ++j) {
+            const unsigned long long e = (((unsigned long long)a1.rel_block * kGPT + j) * kThreads + tid) * 4;
+            pre.mu[j] = *reinterpret_cast<const f32x4_t*>(a1.mu + e);
+            pre.rho[j] = *reinterpret_cast<const f32x4_t*>(a1.rho + e);
+        }
+    }
+    sample_body<ONLY, OUT_RUNTIME>(a0, red, cst);
+    __syncthreads();  // the first block's final LDS reads before the second block's writes
+    if (full) sample_body<ONLY, OUT_RUNTIME, true>(a1, red, cst, &pre);
+    else sample_body<ONLY, OUT_RUNTIME>(a1, red, cst);
+}
+#endif
+
 // out[g][s][j] = sum of partial rows [rows[g], rows[g+1]) in a fixed order.  grid = (2*S, G).
 __global__ __launch_bounds__(256) void bf_reduce_groups_kernel(const double* __restrict__ partials,
                                                                const uint32_t* __restrict__ rows, int S,
@@ -672,6 +737,15 @@ int bf_launch_sample_table(const void* d_blob, int n_tensors, uint32_t block_beg
                                                             bf_align_up((size_t)n_tensors * sizeof(TableEntry), 256));
     const uint32_t blk = block_end - block_begin;
     const int ny = pick_ny(blk, S);
+#if BF_SAMPLE_PAIR
+    if (S <= BF_SAMPLE_PAIR && ny == 1 && prior_kinds == (1 << PRIOR_GAUSS_ALIAS)) {
+        hipLaunchKernelGGL(bf_sample_table_pair_kernel<PRIOR_GAUSS_ALIAS>, dim3((blk + 1) / 2, 1), dim3(kThreads), 0, stream, ent,
+                           map, block_begin, block_end, S, ny, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base,
+                           bf_sample_counter(), d_partials, bf_stale_counter_dev());
+        BF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+#endif
 #define BF_TABLE_LAUNCH(ONLY)                                                                                          \
     hipLaunchKernelGGL(bf_sample_table_kernel<ONLY>, dim3(blk, (uint32_t)ny), dim3(kThreads), 0, stream, ent, map,      \
                        block_begin, S, ny, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, bf_sample_counter(), d_partials, \

@@ -137,6 +137,7 @@ class Model(Module):
             warnings.warn("bayeformers_amd: a prior's tensors were edited in place through `.data` after a forward had "
                           "cached their state; the log_prior of the forward(s) since the edit is NaN — the caches are "
                           "dropped now (call bayeformers_amd.invalidate_caches(model) after such an edit)")
+        ops._COLSUM_OFFERS.clear()  # (column sums a backward pass offered and nobody took)
         slots = {}
         if layers:
             dev = layers[0].weight.mu.device

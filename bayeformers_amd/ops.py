@@ -409,9 +409,45 @@ def planned_linear_forward(x: Tensor, w_s: Tensor, b_s: Optional[Tensor], S: int
     return gemm_nt(x, w_s, b_s, S, M, N, K, M * K, x.dtype, act).view(S * M, N)
 
 
+COLSUMS_FOLDED = [0]  # bias gradients whose column sums came with the output gradient (tests, diagnostics)
+
+# Column sums a gradient's PRODUCER left for its consumer (add_layernorm_backward, attention_backward -> linear_backward).
+# Between the two the gradient passes through autograd — as the same tensor object or as views of it (HF's head split /
+# merge) — so the hand-over is keyed by where the gradient lives: (storage address, byte offset, elements), valid while that
+# very storage is alive AND unmodified: autograd's engine may add a second gradient into the producer's tensor IN PLACE
+# (an output with two consumers); that moves the version counter every view of the storage shares, and the offer is void.
+# An offer is taken once; a new bnn.Model forward drops what nobody took.
+_COLSUM_OFFERS = {}
+
+
+def _offer_key(t: Tensor):
+    return (t.untyped_storage().data_ptr(), t.storage_offset() * t.element_size(), t.numel(), t.dtype)
+
+
+def offer_colsum(grad: Tensor, colsum: Tensor) -> None:
+    """`colsum` [S, N] fp32 = per-sample column sums of the contiguous gradient `grad` ([S*M, N] rows), as stored."""
+    from torch.multiprocessing.reductions import StorageWeakRef
+
+    if len(_COLSUM_OFFERS) > 64:
+        _COLSUM_OFFERS.clear()
+    _COLSUM_OFFERS[_offer_key(grad)] = (StorageWeakRef(grad.untyped_storage()), colsum, grad._version)
+
+
+def take_colsum(grad: Tensor, S: int, N: int) -> Optional[Tensor]:
+    if not _COLSUM_OFFERS or not grad.is_contiguous():
+        return None
+    hit = _COLSUM_OFFERS.pop(_offer_key(grad), None)
+    if hit is None:
+        return None
+    ref, colsum, version = hit
+    if ref.expired() or grad._version != version or tuple(colsum.shape) != (S, N) or colsum.device != grad.device:
+        return None  # the storage the offer described is gone (its address may have been reused) or shapes do not match
+    return colsum
+
+
 def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_base: int, cdt: torch.dtype,
                     need_x: bool, need_mu_w: bool, need_mu_b: bool, w_samples: Optional[Tensor] = None,
-                    act: int = 0, act_pre: Optional[Tensor] = None):
+                    act: int = 0, act_pre: Optional[Tensor] = None, dy_colsum: Optional[Tensor] = None):
     """Gradients of the sampled-weight linear layer (bf_linear_bwd).  Returns (dx, dmu_w, drho_w, dmu_b, drho_b);
     entries that are not needed are None.  x: [S*M, K] as saved by the forward; grad_y: [S*M, N].
     act / act_pre: the forward fused act() into its GEMM and kept the pre-activation [S*M, N]: grad_y is the gradient
@@ -421,6 +457,13 @@ def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_
     K, N = layer.in_features, layer.out_features
     M = x.shape[0] // S
     has_bias = not isinstance(layer.bias, NoneParameter)
+    if dy_colsum is None and has_bias and not act:
+        # the kernel that produced grad_y may have left its per-sample column sums with it (add_layernorm_backward,
+        # attention_backward): valid for exactly this tensor, as it is (same dtype: no rounding in between)
+        cs = take_colsum(grad_y, S, N) if (grad_y.dtype == cdt and grad_y.numel() == S * M * N) else None
+        if cs is not None:
+            dy_colsum = cs
+            COLSUMS_FOLDED[0] += 1
     xg = (x if x.dtype == cdt else x.to(cdt)).contiguous()
     dy = grad_y.reshape(S * M, N)
     dy = (dy if dy.dtype == cdt else dy.to(cdt)).contiguous()
@@ -464,7 +507,7 @@ def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_
     _C.check(lib.bf_linear_bwd(xg.data_ptr(), M * K, dy.data_ptr(), _TORCH2BF[cdt], ctypes.byref(w),
                                ctypes.byref(b) if has_bias else None, ptr(dx), ptr(dmu_w), ptr(drho_w), ptr(dmu_b),
                                ptr(drho_b), S, M, N, K, seed, sample_base & 0xFFFFFFFF, act, ptr(act_pre) if act else None,
-                               ws.data_ptr(), ws.numel(), _stream_ptr()), "bf_linear_bwd")
+                               ptr(dy_colsum), ws.data_ptr(), ws.numel(), _stream_ptr()), "bf_linear_bwd")
     if dx is not None and dx.dtype != x.dtype:
         dx = dx.to(x.dtype)
     if sunk:
@@ -650,14 +693,31 @@ def attention_forward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tensor
 
 def attention_backward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tensor], mask_off: Optional[Tensor],
                        out: Tensor, grad_out: Tensor, lse: Tensor, scaling: float, drop_p: float = 0.0,
-                       keep: Optional[Tensor] = None):
-    """Gradients of attention_forward (bf_attention_bwd).  Returns (dq, dk, dv), each [B, T, H, 64] contiguous."""
+                       keep: Optional[Tensor] = None, colsum_samples: int = 0):
+    """Gradients of attention_forward (bf_attention_bwd).  Returns (dq, dk, dv), each [B, T, H, 64] contiguous.
+    colsum_samples = S (one-tile sequences, B % S == 0): the per-sample column sums of dq / dk / dv come out of the same
+    launch (bf_attention_bwd_colsum) and are offered to the backward of the layers that produced q, k, v (offer_colsum)."""
     B, H, T, D = q.shape
     go = grad_out if (grad_out.dtype == q.dtype and grad_out.is_contiguous()) else grad_out.to(q.dtype).contiguous()
     # one buffer, three slabs: the gradients of a stacked query / key / value launch arrive as one [3, ...] tensor
     dqkv = torch.empty((3, B, T, H, D), dtype=q.dtype, device=q.device)
     dq, dk, dv = dqkv[0], dqkv[1], dqkv[2]
     delta = torch.empty((B, H, T), dtype=torch.float32, device=q.device)
+    if colsum_samples > 0 and T == 128 and B % colsum_samples == 0 and not _NO_COLSUM_FOLD:
+        S = int(colsum_samples)
+        partial = workspace(q.device, B * H * 3 * D * 4)
+        colsum = torch.empty((3, S, H * D), dtype=torch.float32, device=q.device)
+        _C.check(_C.lib().bf_attention_bwd_colsum(q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                                  key_mask.data_ptr() if key_mask is not None else None,
+                                                  mask_off.data_ptr() if mask_off is not None else None, out.data_ptr(),
+                                                  go.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(),
+                                                  dk.data_ptr(), dv.data_ptr(), _TORCH2BF[q.dtype], B, T, H, D, H * D,
+                                                  float(scaling), float(drop_p), keep.data_ptr() if drop_p > 0.0 else None,
+                                                  S, partial.data_ptr(), colsum.data_ptr(), _stream_ptr()),
+                 "bf_attention_bwd_colsum")
+        for t, g in enumerate((dq, dk, dv)):
+            offer_colsum(g, colsum[t])
+        return dq, dk, dv
     if drop_p > 0.0:
         _C.check(_C.lib().bf_attention_bwd_dropout(q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                                    key_mask.data_ptr() if key_mask is not None else None,
@@ -683,6 +743,8 @@ class AttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, key_mask, mask_off, scaling, drop=None):
         ctx.drop_p = drop.p if drop is not None else 0.0
+        fwd = bfr.STATE.ctx   # inside an S-sample forward: the backward also leaves dq / dk / dv's per-sample column sums
+        ctx.cs_samples = fwd.S if fwd is not None else 0
         if ctx.drop_p > 0.0:  # training mode: probabilities dropped in the kernel, one keep bit each kept for the backward
             out, lse, keep = attention_forward(q, k, v, key_mask, scaling, mask_off, want_lse=True, drop=drop, want_keep=True)
             ctx.save_for_backward(q, k, v, out, lse, keep)
@@ -696,13 +758,14 @@ class AttentionFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         q, k, v, out, lse = ctx.saved_tensors[:5]
         keep = ctx.saved_tensors[5] if ctx.drop_p > 0.0 else None
-        dq, dk, dv = attention_backward(q, k, v, ctx.key_mask, ctx.mask_off, out, grad_out, lse, ctx.scaling, ctx.drop_p, keep)
+        dq, dk, dv = attention_backward(q, k, v, ctx.key_mask, ctx.mask_off, out, grad_out, lse, ctx.scaling, ctx.drop_p, keep,
+                                        colsum_samples=ctx.cs_samples)
         # q, k, v came in as [B, H, T, 64] views of [B, T, H*64] projections: hand the gradients back in that view
         return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2), None, None, None, None
 
 
 def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor, grad_out: Tensor, eps: float,
-                           drop: Optional[Dropout] = None, grad_out2: Optional[Tensor] = None):
+                           drop: Optional[Dropout] = None, grad_out2: Optional[Tensor] = None, colsum_samples: int = 0):
     """Gradients of add_layernorm (bf_add_layernorm_bwd): returns (dz, dgamma, dbeta); dz is the gradient of both x
     and residual, dgamma / dbeta are fp32.  With `drop` (bf_add_layernorm_dropout_bwd) returns (dz, dgamma, dbeta, dx):
     dz is the residual's gradient, dx = dz o keep / (1 - p) the dropped input's.  grad_out2: the gradient of the
@@ -722,6 +785,26 @@ def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor,
     lib = _C.lib()
     need = lib.bf_add_layernorm_bwd_workspace_bytes(x2.shape[0], N)
     ws = workspace(x.device, need)
+    if colsum_samples > 0 and x2.shape[0] % colsum_samples == 0:
+        # the per-sample column sums of the gradient handed to x ride along (bf_add_layernorm_bwd_colsum): attached to that
+        # gradient as `_bf_colsum`, where the backward of the dense layer in front finds its bias gradient ready
+        h2 = None
+        if grad_out2 is not None:
+            h2 = grad_out2.reshape(-1, N)
+            h2 = (h2 if h2.dtype == x.dtype else h2.to(x.dtype)).contiguous()
+        dropping = drop is not None and drop.p > 0.0
+        dx = torch.empty_like(x2) if dropping else None
+        colsum = torch.empty((colsum_samples, N), dtype=torch.float32, device=x.device)
+        _C.check(lib.bf_add_layernorm_bwd_colsum(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
+                                                 _TORCH2BF[gamma.dtype], g2.data_ptr(), h2.data_ptr() if h2 is not None else None,
+                                                 dz.data_ptr(), dx.data_ptr() if dropping else None, dgamma.data_ptr(),
+                                                 dbeta.data_ptr(), ws.data_ptr(), ws.numel(), _TORCH2BF[x.dtype], x2.shape[0], N,
+                                                 float(eps), drop.p if dropping else 0.0, drop.seed if dropping else 0,
+                                                 drop.call if dropping else 0, drop.site if dropping else 0, colsum_samples,
+                                                 colsum.data_ptr(), _stream_ptr()), "bf_add_layernorm_bwd_colsum")
+        gx = dx.view(x.shape) if dropping else dz.view(x.shape)
+        offer_colsum(gx, colsum)
+        return (dz.view(x.shape), dgamma, dbeta, gx) if dropping else (gx, dgamma, dbeta)
     if grad_out2 is not None:
         h2 = grad_out2.reshape(-1, N)
         h2 = (h2 if h2.dtype == x.dtype else h2.to(x.dtype)).contiguous()
@@ -750,6 +833,7 @@ def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor,
     return dz.view(x.shape), dgamma, dbeta
 
 
+_NO_COLSUM_FOLD = os.environ.get("BF_NO_COLSUM_FOLD") is not None  # developer A/B: every bias gradient's column sums by a pass of its own
 _NO_TWIN = os.environ.get("BF_NO_LN_TWIN") is not None  # developer A/B: let autograd add the two consumers' gradients
 
 
@@ -764,8 +848,11 @@ class AddLayerNormFn(torch.autograd.Function):
     are summed by autograd as always."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, drop=None, twin=False):
+    def forward(ctx, x, residual, gamma, beta, eps, drop=None, twin=False, cs_samples=0):
         ctx.eps, ctx.has_res = eps, residual is not None
+        # cs_samples = S when x is the output of a Bayesian dense layer with a bias inside an S-sample forward: the backward
+        # then also leaves the per-sample column sums of x's gradient — that layer's bias gradient (add_layernorm_backward)
+        ctx.cs_samples = 0 if _NO_COLSUM_FOLD else int(cs_samples)
         ctx.drop = drop if (drop is not None and drop.p > 0.0) else None
         ctx.save_for_backward(x, residual if residual is not None else x, gamma)
         y = add_layernorm(x, residual, gamma, beta, eps, ctx.drop)
@@ -780,21 +867,21 @@ class AddLayerNormFn(torch.autograd.Function):
         if grad_out is None:
             grad_out, grad_twin = grad_twin, None
         if grad_out is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         dx = None
         if ctx.drop is not None:  # the mask is regenerated from (seed, call, site): nothing was stored
             dz, dgamma, dbeta, dx = add_layernorm_backward(x, residual if ctx.has_res else None, gamma, grad_out, ctx.eps, ctx.drop,
-                                                           grad_out2=grad_twin)
+                                                           grad_out2=grad_twin, colsum_samples=ctx.cs_samples)
         else:
             dz, dgamma, dbeta = add_layernorm_backward(x, residual if ctx.has_res else None, gamma, grad_out, ctx.eps,
-                                                       grad_out2=grad_twin)
+                                                       grad_out2=grad_twin, colsum_samples=ctx.cs_samples)
         need = ctx.needs_input_grad
         if gamma.dtype != torch.float32 and (need[2] or need[3]):
             # dgamma and dbeta are the two rows of one fp32 buffer: cast them with one launch
             both = dgamma._base.to(gamma.dtype) if dgamma._base is not None else torch.stack((dgamma, dbeta)).to(gamma.dtype)
             dgamma, dbeta = both[0], both[1]
         return ((dx if dx is not None else dz) if need[0] else None, dz if (ctx.has_res and need[1]) else None,
-                dgamma if need[2] else None, dbeta if need[3] else None, None, None, None)
+                dgamma if need[2] else None, dbeta if need[3] else None, None, None, None, None)
 
 
 def layernorm_supported(x: Tensor, residual: Optional[Tensor], ln) -> bool:

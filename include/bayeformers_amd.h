@@ -231,12 +231,14 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
  * (not needed); d_drho_b/d_dmu_b are ignored when bias is NULL.  Gradients are written, not accumulated.
  * act / d_act_pre: when the forward fused an activation into its GEMM (bf_gemm_nt_act_pre), d_dy is the gradient of
  * act(y) and d_act_pre the forward's pre-activation y ([S][M][N] of `dtype`, 16-bit, N % 8 == 0): dy = d_dy * act'(y)
- * is formed first, in one pass that also yields the bias gradient's column sums.  act = BF_ACT_NONE: d_act_pre unused. */
+ * is formed first, in one pass that also yields the bias gradient's column sums.  act = BF_ACT_NONE: d_act_pre unused.
+ * d_dy_colsum (nullable): [S][N] fp32 column sums of d_dy per sample, when the kernel that PRODUCED d_dy left them
+ * (bf_add_layernorm_bwd_colsum, bf_attention_bwd_colsum): the bias gradient then needs no pass over d_dy of its own. */
 size_t bf_linear_bwd_workspace_bytes(int S, int M, int N, int K, int has_bias, int dtype, int act);
 int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, int dtype, const bf_tensor_t* weight,
                   const bf_tensor_t* bias, void* d_dx, float* d_dmu_w, float* d_drho_w, float* d_dmu_b,
                   float* d_drho_b, int S, int M, int N, int K, uint64_t seed, uint32_t sample_base, int act,
-                  const void* d_act_pre, void* d_workspace, size_t workspace_bytes, void* stream);
+                  const void* d_act_pre, const float* d_dy_colsum, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Opt-in Bayes-by-Backprop gradient of the KL terms.  The reference detaches its log-probs (layers/linear.py:99-102
  * store them with `.data =`), so `loss = (lvp - log_prior)/n_batches + nll` (bert_glue.py:235) trains the likelihood
@@ -343,6 +345,18 @@ int bf_attention_bwd_dropout(const void* d_q, const void* d_k, const void* d_v, 
                              const void* d_out, const void* d_dout, const float* d_lse, float* d_delta, void* d_dq, void* d_dk,
                              void* d_dv, int dtype, int B, int T, int H, int head_dim, int64_t token_stride, float scaling,
                              float p_drop, const uint32_t* d_keep_bits, void* stream);
+
+/* bf_attention_bwd_dropout (p_drop = 0: no dropout) for sequences of ONE 128-token tile that also leaves the per-sample
+ * COLUMN SUMS of dq, dk and dv as stored: d_colsum [3][samples][H * head_dim] fp32 (the B sequences being `samples` equal
+ * groups), through d_partial ([B][H][3][head_dim] fp32 of scratch).  dq / dk / dv are the output gradients of the Bayesian
+ * query / key / value layers: their column sums per Monte-Carlo sample are those layers' bias gradients
+ * (/root/reference/examples/bert_glue.py:239), handed to bf_linear_bwd as d_dy_colsum instead of three more passes over the
+ * activation-sized gradients. */
+int bf_attention_bwd_colsum(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
+                            const void* d_out, const void* d_dout, const float* d_lse, float* d_delta, void* d_dq, void* d_dk,
+                            void* d_dv, int dtype, int B, int T, int H, int head_dim, int64_t token_stride, float scaling,
+                            float p_drop, const uint32_t* d_keep_bits, int samples, float* d_partial, float* d_colsum,
+                            void* stream);
 int bf_add_layernorm_dropout(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, int param_dtype,
                              void* d_out, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed, uint32_t call,
                              uint32_t site, void* stream);
@@ -360,6 +374,16 @@ int bf_add_layernorm_bwd_sum(const void* d_x, const void* d_residual, const void
                              const void* d_dy2, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
                              size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
                              uint32_t call, uint32_t site, void* stream);
+
+/* bf_add_layernorm_bwd_sum that also leaves the per-sample COLUMN SUMS of the gradient it hands to the layer in front of
+ * it — d_dx with dropout, d_dz without: d_colsum [samples][N] fp32, the `rows` being `samples` equal slabs.  In
+ * LayerNorm(dropout(dense(h)) + input) that gradient is the dense layer's d_dy, and its column sums are the dense layer's
+ * bias gradient per Monte-Carlo sample (/root/reference/examples/bert_glue.py:239: loss.backward() through
+ * BertSelfOutput / BertOutput): bf_linear_bwd takes them as d_dy_colsum instead of reading d_dy once more. */
+int bf_add_layernorm_bwd_colsum(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,
+                                const void* d_dy2, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
+                                size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
+                                uint32_t call, uint32_t site, int samples, float* d_colsum, void* stream);
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * While enabled, every sampling launch (kind BF_PROF_SAMPLE) and every GEMM launch (BF_PROF_GEMM) made through

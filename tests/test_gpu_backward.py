@@ -609,3 +609,106 @@ def test_checkpointed_blocks_recompute_the_forwards_epsilon(device_counter):
     for n in g0:
         scale = g0[n].abs().max().item() + 1e-30
         assert (g0[n] - g1[n]).abs().max().item() <= 1e-6 * scale, n
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Round 5: the bias gradients' column sums ride in the kernels that PRODUCE the output gradient of a Bayesian layer
+# (the residual + LayerNorm backward, the one-tile attention backward) instead of a pass of their own over that gradient.
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("S,rows_per_sample,N", [(3, 96, 768), (10, 4096, 768), (2, 130, 1024), (1, 7, 8), (4, 64, 200)])
+@pytest.mark.parametrize("p,twin", [(0.0, False), (0.1, False), (0.1, True)])
+def test_layernorm_backward_leaves_the_column_sums_of_the_gradient_it_hands_on(dtype, S, rows_per_sample, N, p, twin):
+    """bf_add_layernorm_bwd_colsum: same dz / dx / dgamma / dbeta as the plain backward, plus colsum[s] = the sum over sample s's
+    rows of the gradient handed to x (dx with dropout, dz without) — as that tensor is stored."""
+    from bayeformers_amd import ops
+
+    g = torch.Generator().manual_seed(S * 100 + N)
+    rows = S * rows_per_sample
+    x, res, go, go2 = (torch.randn(rows, N, generator=g).cuda().to(dtype) for _ in range(4))
+    gamma = torch.randn(N, generator=g).cuda()
+    drop = ops.Dropout(p, SEED, 3, 5) if p > 0 else None
+    plain = ops.add_layernorm_backward(x, res, gamma, go, 1e-12, drop, grad_out2=go2 if twin else None)
+    folded = ops.add_layernorm_backward(x, res, gamma, go, 1e-12, drop, grad_out2=go2 if twin else None, colsum_samples=S)
+    for i, (a, b) in enumerate(zip(plain, folded)):
+        if i in (1, 2):  # dgamma, dbeta: the per-sample walk regroups their fp32 partial sums
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * float(a.abs().max()))
+        else:
+            assert torch.equal(a, b)
+    handed = folded[3] if p > 0 else folded[0]
+    cs = ops.take_colsum(handed.view(rows, N), S, N)
+    assert cs is not None and ops.take_colsum(handed.view(rows, N), S, N) is None      # taken once
+    ref = handed.view(S, rows_per_sample, N).double().sum(1)
+    assert (cs.double() - ref).abs().max().item() <= 1e-5 * max(1.0, float(handed.float().abs().sum(0).max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("S,Bs,H,p", [(2, 3, 2, 0.0), (5, 4, 12, 0.0), (3, 2, 4, 0.1)])
+def test_attention_backward_leaves_the_column_sums_of_dq_dk_dv(dtype, S, Bs, H, p):
+    """bf_attention_bwd_colsum (one-tile sequences): dq / dk / dv bit-identical to bf_attention_bwd's, plus the per-sample
+    column sums of each — what the Bayesian query / key / value layers take as their bias gradients."""
+    from bayeformers_amd import ops
+
+    B, T = S * Bs, 128
+    g = torch.Generator().manual_seed(B * 31 + H)
+    q, k, v = (torch.randn(B, T, H * 64, generator=g).cuda().to(dtype).view(B, T, H, 64).transpose(1, 2) for _ in range(3))
+    go = torch.randn(B, T, H, 64, generator=g).cuda().to(dtype)
+    drop = ops.Dropout(p, SEED, 1, 2) if p > 0 else None
+    if drop is not None:
+        out, lse, keep = ops.attention_forward(q, k, v, None, 0.125, None, want_lse=True, drop=drop, want_keep=True)
+    else:
+        (out, lse), keep = ops.attention_forward(q, k, v, None, 0.125, None, want_lse=True), None
+    plain = ops.attention_backward(q, k, v, None, None, out, go, lse, 0.125, p, keep)
+    folded = ops.attention_backward(q, k, v, None, None, out, go, lse, 0.125, p, keep, colsum_samples=S)
+    for t, (a, b) in enumerate(zip(plain, folded)):
+        assert torch.equal(a, b)
+        flat = b.reshape(B * T, H * 64)          # the [S M, N] rows the projection's backward sees: a view, same storage
+        cs = ops.take_colsum(flat, S, H * 64)
+        assert cs is not None, t
+        ref = flat.view(S, Bs * T, H * 64).double().sum(1)
+        assert (cs.double() - ref).abs().max().item() <= 1e-5 * max(1.0, float(flat.float().abs().sum(0).max())), t
+
+
+def test_folded_column_sums_give_the_bias_gradients_of_the_plain_path():
+    """End to end on a 2-layer BERT with 128-token sequences in training mode: every Bayesian layer's bias gradient with the
+    column sums folded into the producing kernels (residual + LayerNorm backward: attention-out and FFN-down; attention
+    backward: query / key / value; GELU backward: FFN-up) equals the gradient with a column-sum pass per layer."""
+    from transformers import BertConfig, BertForSequenceClassification
+
+    from bayeformers_amd import ops
+    from bayeformers_amd.sampling import elbo, sample_bayesian
+
+    cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=500,
+                     max_position_embeddings=128)
+    torch.manual_seed(0)
+    bmodel = bf.to_bayesian(BertForSequenceClassification(cfg), delta=0.05, freeze=True).cuda().to(torch.bfloat16)
+    bf.fuse_activations(bmodel), bf.fuse_residual_layernorm(bmodel), bf.fuse_shared_inputs(bmodel)
+    bf.fuse_attention(bmodel), bf.fuse_embeddings(bmodel)
+    bmodel.train()
+    ids = torch.randint(0, 500, (4, 128), generator=torch.Generator().manual_seed(1)).cuda()
+    inputs = {"input_ids": ids, "attention_mask": torch.ones_like(ids)}
+    labels = torch.randint(0, 2, (4,), generator=torch.Generator().manual_seed(2)).cuda()
+    params = {n: p_ for n, p_ in bmodel.named_parameters() if p_.requires_grad}
+
+    def grads(fold):
+        ops._NO_COLSUM_FOLD = not fold
+        ops.COLSUMS_FOLDED[0] = 0
+        try:
+            for p_ in params.values():
+                p_.grad = None
+            bf.manual_seed(SEED)
+            _, mean, lp, lq = sample_bayesian(bmodel, inputs, 3)
+            loss = elbo(lp, lq, torch.nn.functional.cross_entropy(mean[0].float(), labels).double(), 10)
+            loss.backward()
+            return {n: p_.grad.float().clone() for n, p_ in params.items() if p_.grad is not None}, ops.COLSUMS_FOLDED[0]
+        finally:
+            ops._NO_COLSUM_FOLD = False
+
+    plain, n_plain = grads(False)
+    folded, n_folded = grads(True)
+    assert n_plain == 0 and n_folded == 2 * (3 + 2), n_folded      # per layer: q, k, v + attention-out + FFN-down
+    assert set(plain) == set(folded)
+    for n in plain:
+        scale = float(plain[n].abs().max())
+        # fp32 sums in another order for the biases and the LayerNorm parameters; everything else: the same bits
+        tol = 1e-5 * max(scale, 1e-6) if ("bias" in n or "LayerNorm" in n) else 0.0
+        assert (plain[n] - folded[n]).abs().max().item() <= tol, n
