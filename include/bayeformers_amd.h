@@ -28,7 +28,8 @@ extern "C" {
 #define BF_VERSION_MINOR 5  /* 2: bf_embed_layernorm takes the table row counts; 3: bf_sample_table_build reports the
                                tensors' effective prior kinds, bf_sample_logprob_table takes the launch's set of them;
                                4: bf_add_layernorm_bwd_sum; 5: bf_prior_t carries the device addresses its constants were
-                               read from (re-checked by the kernels), bf_stale_counter */
+                               read from (re-checked by the kernels), bf_stale_counter; bf_linear_bwd takes d_dy_colsum,
+                               bf_add_layernorm_bwd_colsum, bf_attention_bwd_colsum */
 
 /* element types of activations / sampled weights */
 enum { BF_DT_F32 = 0, BF_DT_BF16 = 1, BF_DT_F16 = 2 };
