@@ -18,7 +18,7 @@ LIB = os.path.join(LIBDIR, "libbayeformers_amd.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 # The product library carries only code something dispatches to.  bf_fused_ws.hip — the weight-stationary single-kernel
-# variant of NS-1, measured slower than both alternatives at every M (profiles/r4b_mid_m_crossover.txt)
+# variant of NS-1, measured slower than both alternatives at every M (LABBOOK.md section 4.3, profiles/r4b_mid_m_crossover.txt)
 # — and the round-1 GEMM kernel are DEV_SOURCES: built into libbayeformers_amd_dev.so only (tests/test_gpu_fused_ws.py and
 # the tools/ micro-benchmarks select it with BF_LIB_PATH).
 SOURCES = ["bf_api.hip", "bf_sample.hip", "bf_gemm.hip", "bf_gemm256.hip", "bf_gemm256_r5.hip", "bf_backward.hip", "bf_fused_small.hip", "bf_norm.hip", "bf_attention.hip", "bf_attention_bwd.hip"]

@@ -13,7 +13,7 @@ extern "C" {
  * exist in HBM — accumulates the log-probs exactly once (row share 0), and streams its rows of x against the resident
  * strip (csrc/bf_fused_ws.hip).  Needs 16-bit x / y of the compute dtype, N % 64 == 0, K % 64 == 0, K <= 768.
  * row_shares: workgroups per (sample, strip) along M (each regenerates the strip); 0 = enough to fill the chip.
- * This is the measured alternative to sampling launch + 256-wide GEMM: it is NOT what
+ * This is the measured alternative to sampling launch + 256-wide GEMM (LABBOOK.md §4.3): it is NOT what
  * bnn.Linear dispatches to, because it is slower — four times the LDS-DMA bytes per flop of the 256 x 256 tile. */
 size_t bf_linear_fwd_ws_workspace_bytes(int S, int N);
 int bf_linear_fwd_ws(const void* d_x, int x_dtype, int64_t x_sample_stride, const bf_tensor_t* weight,

@@ -773,7 +773,7 @@ int launch256_tn(const GemmParams& p, hipStream_t stream, int grid) {
 
 template <typename T>
 int launch256_nn(const GemmParams& p, hipStream_t stream, int grid) {
-#ifdef BF_RING_ROWMAJOR  // measured slower than the burst form for row-major operands: developer builds only
+#ifdef BF_RING_ROWMAJOR  // measured slower than the burst form for row-major operands (LABBOOK.md §4.2): developer builds only
     if (p.segs > 1)
         hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, true, true, true>), dim3(grid), dim3(512), 0, stream, p);
     else if (p.K >= 2 * TK)

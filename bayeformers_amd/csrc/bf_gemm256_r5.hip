@@ -132,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     };
     // one 1 KiB piece: `base` (a buffer of `bytes`) + per-lane byte offset `off` + wave-uniform byte offset `soff` -> LDS `dst`
 #ifndef BF_R5_AUX_X
-#define BF_R5_AUX_X 0  // cache policy bits of the x / W pieces (1 = sc0, 2 = nt, 16 = sc1): experiment, see DESIGN.md 4.2b
+#define BF_R5_AUX_X 0  // cache policy bits of the x / W pieces (1 = sc0, 2 = nt, 16 = sc1): experiment, see LABBOOK.md 4.2b
 #endif
 #ifndef BF_R5_AUX_W
 #define BF_R5_AUX_W 0
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
 #define BF_R5_EARLY_ACT_DOC 0  // experiment: the tile's LAST MFMA slot runs row block by row block and the
 // fused activation of block j - 2 is applied in place between the MFMAs of block j, so that the GELU's VALU time of the
 // first H - 2 blocks lies under matrix-pipe time instead of in the epilogue.  Bit-identical outputs.  Measured in the
-// BERT-base step (profiles/r5e_ring_early_act_ab.txt): see DESIGN.md / LABBOOK.md — not adopted.
+// BERT-base step (profiles/r5e_gemm_variants_in_step_ab.txt): see LABBOOK.md (round 5) — not adopted.
 #endif
 #ifndef BF_R5_EARLY_LAG
 #define BF_R5_EARLY_LAG 2   // the activation trails the MFMAs by this many row blocks (more = fewer live fragments beside it)

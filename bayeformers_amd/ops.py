@@ -340,7 +340,7 @@ def linear_forward(layer, x: Tensor, S: int, seed: int, sample_base: int, lp_out
 
 def linear_forward_ws(layer, x: Tensor, S: int, seed: int, sample_base: int, lp_out: Tensor, row_shares: int = 0) -> Tensor:
     """Linear.forward for S samples in ONE launch, weight-stationary (bf_linear_fwd_ws): the measured alternative to
-    sampling launch + GEMM for large M.  Same arguments and results as linear_forward; 16-bit x only."""
+    sampling launch + GEMM for large M (LABBOOK.md 4.3).  Same arguments and results as linear_forward; 16-bit x only."""
     from .nn.parameters.base import NoneParameter
 
     if not hasattr(_C.lib(), "bf_linear_fwd_ws"):

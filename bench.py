@@ -935,7 +935,7 @@ def main():
             bound = "mfma"
         tflops = gflop / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
         # the north star asks for ONE fused reparameterise + GEMM kernel; here the weights are sampled by their own launch
-        # (DESIGN.md section 4.3), so the fraction a fused kernel would be held to is flop / (GEMM time + sampling time)
+        # (LABBOOK.md section 4.3), so the fraction a fused kernel would be held to is flop / (GEMM time + sampling time)
         tflops_ws = gflop / ((gms + sms) * 1e-3) / 1e12 if gms + sms > 0 else 0.0
         roofline = {"bound": bound, "kernel": kernel,
                     "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",

@@ -697,6 +697,7 @@ def test_folded_column_sums_give_the_bias_gradients_of_the_plain_path():
             for p_ in params.values():
                 p_.grad = None
             bf.manual_seed(SEED)
+            torch.manual_seed(1234)   # (the embedding block's dropout is the framework's: the same mask in both runs)
             _, mean, lp, lq = sample_bayesian(bmodel, inputs, 3)
             loss = elbo(lp, lq, torch.nn.functional.cross_entropy(mean[0].float(), labels).double(), 10)
             loss.backward()
@@ -712,4 +713,6 @@ def test_folded_column_sums_give_the_bias_gradients_of_the_plain_path():
         scale = float(plain[n].abs().max())
         # fp32 sums in another order for the biases and the LayerNorm parameters; everything else: the same bits
         tol = 1e-5 * max(scale, 1e-6) if ("bias" in n or "LayerNorm" in n) else 0.0
+        if "embeddings" in n and "LayerNorm" not in n:
+            tol = 5e-2 * scale   # the framework's embedding backward scatters with bf16 atomics: not run-to-run reproducible
         assert (plain[n] - folded[n]).abs().max().item() <= tol, n

@@ -1,4 +1,4 @@
-"""The weight-stationary fused kernel for large M (bf_linear_fwd_ws, NS-1 — the measured alternative of DESIGN.md 4.3)
+"""The weight-stationary fused kernel for large M (bf_linear_fwd_ws, NS-1 — the measured alternative of LABBOOK.md 4.3)
 against the shipped two-launch path and the oracle: same epsilon (same Philox counters), so the sampled weights are the
 same bits, the outputs agree to bf16 accumulation order, and the log-probs to fp32 summation order."""
 import numpy as np
@@ -29,7 +29,7 @@ def needs_dev(fn):
 def test_fused_ws_cases_run_under_the_developer_library():
     if _HAS_WS:
         return  # this IS the developer-library process: the cases below run here
-    """NS-1's measured alternative (DESIGN.md 4.3) stays parity-checked: a child `python -m pytest` of this file with the
+    """NS-1's measured alternative (LABBOOK.md 4.3) stays parity-checked: a child `python -m pytest` of this file with the
     developer library selected.  A child process, never a re-exec: this process has initialised the GPU."""
     import os
     import re
