@@ -104,7 +104,7 @@ def _dense_residual_norm_forward(self, hidden_states, input_tensor):
         return ln((self.dropout(hidden_states) if dropping else hidden_states) + input_tensor)
     # training mode (/root/reference/examples/bert_glue.py:221): the hidden dropout runs INSIDE the kernel, its Philox mask
     # regenerated in the backward pass — no mask tensor, no extra pass over the dense output
-    drop = ops.Dropout(self.dropout.p, bfr.STATE.seed, bfr.dropout_call(), bfr.dropout_site(self)) if dropping else None
+    drop = ops.Dropout(self.dropout.p, bfr.STATE.seed, bfr.dropout_call(), bfr.dropout_site(self), bfr.dropout_origin()) if dropping else None
     if torch.is_grad_enabled() and (hidden_states.requires_grad or input_tensor.requires_grad or ln.weight.requires_grad):
         # the backward of this block hands `hidden_states` its gradient: when the dense layer is a Bayesian one with a bias,
         # the per-sample column sums of that gradient (its bias gradient) come out of the same kernel
@@ -306,7 +306,7 @@ def _attention_interface(module, query, key, value, attention_mask, dropout: flo
             attention_mask = attention_mask.to(query.dtype)  # the framework's kernels want bool or the query's dtype
         return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
     scale = scaling if scaling is not None else query.shape[-1] ** -0.5
-    drop = ops.Dropout(dropout, bfr.STATE.seed, bfr.dropout_call(), bfr.dropout_site(module)) if dropout > 0.0 else None
+    drop = ops.Dropout(dropout, bfr.STATE.seed, bfr.dropout_call(), bfr.dropout_site(module), bfr.dropout_origin()) if dropout > 0.0 else None
     if need_grad:  # training: the same kernel, with bf_attention_bwd behind it
         return ops.AttentionFn.apply(query, key, value, key_mask, mask_off, scale, drop), None
     return ops.attention_forward(query, key, value, key_mask, scale, mask_off, drop=drop), None

@@ -454,12 +454,14 @@ int bf_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const fl
                                    dtype, B, T, H, head_dim, token_stride, scaling, (hipStream_t)stream);
 }
 
-static bf_dropout_t make_dropout(float p_drop, uint64_t seed, uint32_t call, uint32_t site) {
+static bf_dropout_t make_dropout(float p_drop, uint64_t seed, uint32_t call, uint32_t site, uint64_t first_group = 0) {
     bf_dropout_t d;
     d.k0 = (uint32_t)seed;
     d.k1 = (uint32_t)(seed >> 32);
     d.call = call;
     d.site = site;
+    d.g0_lo = (uint32_t)first_group;
+    d.g0_hi = (uint32_t)(first_group >> 32);
     d.thresh = bf_dropout_thresh(p_drop);
     d.inv_keep = 1.0f / (1.0f - (float)d.thresh / 65536.0f);
     return d;
@@ -480,10 +482,10 @@ int bf_dropout_keep_host(uint8_t* out, uint64_t first_group, uint64_t n_groups, 
 
 int bf_attention_fwd_dropout(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
                              void* d_out, float* d_lse, int dtype, int B, int T, int H, int head_dim, int64_t token_stride,
-                             float scaling, float p_drop, uint64_t seed, uint32_t call, uint32_t site, uint32_t* d_keep_bits,
+                             float scaling, float p_drop, uint64_t seed, uint32_t call, uint32_t site, uint64_t first_group, uint32_t* d_keep_bits,
                              void* stream) {
     if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_attention_fwd_dropout: p must be in [0, 1) (got %g)", p_drop);
-    const bf_dropout_t d = make_dropout(p_drop, seed, call, site);
+    const bf_dropout_t d = make_dropout(p_drop, seed, call, site, first_group);
     return bf_launch_attention_fwd(d_q, d_k, d_v, d_mask, d_mask_off, d_out, d_lse, dtype, B, T, H, head_dim, token_stride,
                                    scaling, (hipStream_t)stream, &d, d_keep_bits);
 }
@@ -516,9 +518,9 @@ int bf_attention_bwd_colsum(const void* d_q, const void* d_k, const void* d_v, c
 
 int bf_add_layernorm_dropout(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, int param_dtype,
                              void* d_out, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed, uint32_t call,
-                             uint32_t site, void* stream) {
+                             uint32_t site, uint64_t first_group, void* stream) {
     if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_add_layernorm_dropout: p must be in [0, 1) (got %g)", p_drop);
-    const bf_dropout_t d = make_dropout(p_drop, seed, call, site);
+    const bf_dropout_t d = make_dropout(p_drop, seed, call, site, first_group);
     return bf_launch_add_layernorm(d_x, d_residual, d_gamma, d_beta, param_dtype, d_out, dtype, rows, N, eps,
                                    (hipStream_t)stream, &d);
 }
@@ -526,9 +528,9 @@ int bf_add_layernorm_dropout(const void* d_x, const void* d_residual, const void
 int bf_add_layernorm_dropout_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
                                  const void* d_dy, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
                                  size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
-                                 uint32_t call, uint32_t site, void* stream) {
+                                 uint32_t call, uint32_t site, uint64_t first_group, void* stream) {
     if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_add_layernorm_dropout_bwd: p must be in [0, 1) (got %g)", p_drop);
-    const bf_dropout_t d = make_dropout(p_drop, seed, call, site);
+    const bf_dropout_t d = make_dropout(p_drop, seed, call, site, first_group);
     return bf_launch_add_layernorm_bwd(d_x, d_residual, d_gamma, param_dtype, d_dy, d_dz, d_dgamma, d_dbeta, d_workspace,
                                        workspace_bytes, dtype, rows, N, eps, (hipStream_t)stream, &d, d_dx);
 }
@@ -536,9 +538,9 @@ int bf_add_layernorm_dropout_bwd(const void* d_x, const void* d_residual, const 
 int bf_add_layernorm_bwd_sum(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,
                              const void* d_dy2, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
                              size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
-                             uint32_t call, uint32_t site, void* stream) {
+                             uint32_t call, uint32_t site, uint64_t first_group, void* stream) {
     if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_add_layernorm_bwd_sum: p must be in [0, 1) (got %g)", p_drop);
-    const bf_dropout_t d = make_dropout(p_drop, seed, call, site);
+    const bf_dropout_t d = make_dropout(p_drop, seed, call, site, first_group);
     return bf_launch_add_layernorm_bwd(d_x, d_residual, d_gamma, param_dtype, d_dy, d_dz, d_dgamma, d_dbeta, d_workspace,
                                        workspace_bytes, dtype, rows, N, eps, (hipStream_t)stream, d.thresh ? &d : nullptr, d_dx,
                                        d_dy2);
@@ -547,10 +549,10 @@ int bf_add_layernorm_bwd_sum(const void* d_x, const void* d_residual, const void
 int bf_add_layernorm_bwd_colsum(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,
                                 const void* d_dy2, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
                                 size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
-                                uint32_t call, uint32_t site, int samples, float* d_colsum, void* stream) {
+                                uint32_t call, uint32_t site, uint64_t first_group, int samples, float* d_colsum, void* stream) {
     if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_add_layernorm_bwd_colsum: p must be in [0, 1) (got %g)", p_drop);
     if (!d_colsum || samples < 1) BF_FAIL("bf_add_layernorm_bwd_colsum: needs d_colsum and samples >= 1");
-    const bf_dropout_t d = make_dropout(p_drop, seed, call, site);
+    const bf_dropout_t d = make_dropout(p_drop, seed, call, site, first_group);
     return bf_launch_add_layernorm_bwd(d_x, d_residual, d_gamma, param_dtype, d_dy, d_dz, d_dgamma, d_dbeta, d_workspace,
                                        workspace_bytes, dtype, rows, N, eps, (hipStream_t)stream, d.thresh ? &d : nullptr, d_dx,
                                        d_dy2, samples, d_colsum);

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256, DROP ? BF_ATTN_DROP_WGS : 3) void attention_fw
             if constexpr (DROP) {
                 // drop probabilities (the sum above saw all of them); the 1 / (1 - p) factor joins the final normalisation
                 const unsigned long long qrow = ((unsigned long long)b * p.H + h) * p.T + (q0 + qi * 16 + li);
-                const unsigned long long g0 = (qrow * (unsigned)(p.T >> 5) + (unsigned)(key0 >> 7) * 4u) * 4u + lg;
+                const unsigned long long g0 = (qrow * (unsigned)(p.T >> 5) + (unsigned)(key0 >> 7) * 4u) * 4u + lg +
+                                              (((unsigned long long)p.drop.g0_hi << 32) | p.drop.g0_lo);
                 uint32_t word = 0;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {

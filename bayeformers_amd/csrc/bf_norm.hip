@@ -65,7 +65,7 @@ constexpr int kRowsPerBlock = 4;  // one wave per row
 // hidden dropout of the dense output (HF BertSelfOutput / BertOutput: LayerNorm(dropout(dense(h)) + input), training mode):
 // the 8-element vector `vec` (= 8 consecutive features) of row `row` is dropout group row * (N / 8) + vec of bf_philox.h
 __device__ __forceinline__ void drop8(const bf_dropout_t& d, long long row, int nvec, int vec, float (&v)[8]) {
-    const unsigned long long g = (unsigned long long)row * (unsigned)nvec + (unsigned)vec;
+    const unsigned long long g = (unsigned long long)row * (unsigned)nvec + (unsigned)vec + (((unsigned long long)d.g0_hi << 32) | d.g0_lo);
     const uint32_t keep = bf_dropout_keep8((uint32_t)g, (uint32_t)(g >> 32), d.call, d.site, d.k0, d.k1, d.thresh);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = ((keep >> i) & 1u) ? v[i] * d.inv_keep : 0.f;
@@ -358,7 +358,7 @@ int launch_bwd_vpl(const void* x, const void* res, const void* gamma, const void
     const bool cs = rps > 0;
     const size_t lds = (size_t)kRowsPerBlock * (cs ? 3 : 2) * N * sizeof(float);
     const dim3 grid((unsigned)nblocks), block(64 * kRowsPerBlock);
-    const bf_dropout_t d = drop ? *drop : bf_dropout_t{0, 0, 0, 0, 0, 1.0f};
+    const bf_dropout_t d = drop ? *drop : bf_dropout_t{0, 0, 0, 0, 0, 1.0f, 0, 0};
 #define BF_LNB_LAUNCH1(VPL, DR, CSF)                                                                                        \
     hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, GT, VPL, DR, CSF>), grid, block, lds, stream, (const T*)x,              \
                        (const T*)res, (const GT*)gamma, (const T*)dy, (T*)dz, partial, rows, N, eps, d, (T*)dx,            \
@@ -384,7 +384,7 @@ template <typename T, typename GT>
 int launch_vpl(const void* x, const void* res, const void* gamma, const void* beta, void* out, long long rows, int N,
                float eps, hipStream_t stream, const bf_dropout_t* drop) {
     const int nvec = N >> 3;
-    const bf_dropout_t d = drop ? *drop : bf_dropout_t{0, 0, 0, 0, 0, 1.0f};
+    const bf_dropout_t d = drop ? *drop : bf_dropout_t{0, 0, 0, 0, 0, 1.0f, 0, 0};
     if (nvec % 32 == 0 && nvec <= 128) {  // N = 256, 512, 768, 1024: half a wave per row
         const dim3 hgrid((unsigned)((rows + 2 * kRowsPerBlock - 1) / (2 * kRowsPerBlock))), hblock(64 * kRowsPerBlock);
 #define BF_LNH_LAUNCH(V)                                                                                                \

@@ -92,7 +92,9 @@ static inline void bf_normal4_host(uint64_t group, uint32_t sample, uint32_t str
 //   element i is KEPT iff field_i >= thresh,  thresh = round(p * 65536)   (p exact to 1.5e-5), kept values scale by 1/(1-p')
 //   with p' = thresh / 65536.
 // Streams with the top bit set cannot collide with the weight streams 2 * layer_id + {0, 1}.  `call` identifies the
-// forward (one number per bnn.Model forward), `site` the module the dropout belongs to.
+// forward (one number per bnn.Model forward), `site` the module the dropout belongs to.  The group index is GLOBAL over the
+// step's Monte-Carlo samples: a kernel that sees the slabs of samples [s0, s0 + S_local) numbers its groups from
+// first_group = s0 * (groups per sample) — masks are a function of the global sample, like epsilon.
 #define BF_DROPOUT_STREAM 0x80000000u
 BF_HD uint32_t bf_dropout_thresh(float p) {
     const float t = p * 65536.0f + 0.5f;
@@ -117,6 +119,9 @@ struct bf_dropout_t {
     uint32_t call, site;
     uint32_t thresh;     // bf_dropout_thresh(p)
     float inv_keep;      // 1 / (1 - thresh / 65536)
+    // group index of the tensor's FIRST group in the step's GLOBAL numbering: an S-sharded rank passes (first global sample
+    // of its shard) x (groups per sample), so that sample s draws the same masks whichever rank — or how many — run it
+    uint32_t g0_lo, g0_hi;
 };
 
 #if defined(__HIPCC__) || defined(__HIP__)

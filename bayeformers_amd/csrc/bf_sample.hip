@@ -228,10 +228,24 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][k
             inv[j] = bf_philox_prepare((uint32_t)(e0[j] >> 2), (uint32_t)(e0[j] >> 34), a.stream, a.k0, a.k1);
         for (int s = s_begin; s < s_end; ++s) {
             f32x2_t q2 = {0.f, 0.f}, p2 = {0.f, 0.f};
+#ifdef BF_SAMPLE_HALF_PHILOX
+            bf_u32x4 xprev = {0u, 0u, 0u, 0u};
+#endif
 #pragma unroll
             for (int j = 0; j < G; ++j) {
                 float z[4];
+#ifdef BF_SAMPLE_HALF_PHILOX
+                // SPEED EXPERIMENT ONLY (wrong epsilon for the second group): one Philox block per TWO groups — twice the
+                // saving of "six normals per block"  — to bound what that contract change could gain
+                // (profiles/r5h_sampling_half_philox_bound.txt)
+                bf_u32x4 x;
+                if (j == 0) x = bf_philox_finish(inv[0], a.sample_base + (uint32_t)s, a.stream, a.k0, a.k1);
+                if (j == 0) { xprev = x; } else { x.x = xprev.x * 2654435761u; x.y = xprev.y ^ 0x9E3779B9u; x.z = xprev.z * 2246822519u; x.w = xprev.w ^ 0x85EBCA6Bu; }
+                bf_box_muller_dev(x.x, x.y, z[0], z[1]);
+                bf_box_muller_dev(x.z, x.w, z[2], z[3]);
+#else
                 bf_normal4_split_dev(inv[j], a.sample_base + (uint32_t)s, a.stream, a.k0, a.k1, z);
+#endif
                 const f32x2_t z01 = {z[0], z[1]}, z23 = {z[2], z[3]};
                 const f32x2_t w01 = __builtin_elementwise_fma(f32x2_t{sigma[j][0], sigma[j][1]}, z01, f32x2_t{mu[j][0], mu[j][1]});
                 const f32x2_t w23 = __builtin_elementwise_fma(f32x2_t{sigma[j][2], sigma[j][3]}, z23, f32x2_t{mu[j][2], mu[j][3]});

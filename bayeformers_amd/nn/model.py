@@ -48,10 +48,11 @@ class _ForwardContext:
         self.shared_out = {}  # id(first layer of a stacked run) -> (input identity, [L, S, M, N] outputs)
         self.counter = bfr.counter_snapshot()  # device-counter mode: the counter value this forward's kernels added
         self.graph_tasks = set()  # ids of the backward passes that reached this forward's outputs (bfr.remember_context)
-        # the `call` of every dropout applied inside this forward.  On S-sharded ranks the same step's forwards must not
-        # apply the same masks to their (different) samples: the shard's first global sample is folded in (rank 0 / one
-        # process: unchanged), so the dropout noise is independent across the ranks' samples as it is across one rank's.
-        self.drop_call = (bfr.reserve_dropout_call() + (int(shard_start) * 0x9E3779B1)) & 0xFFFFFFFF
+        # the `call` of every dropout applied inside this forward; `shard_start` (the first global sample of this process's
+        # shard within the step) is where the kernels start numbering their dropout groups (ops.Dropout.first_group): a
+        # sample's masks are a function of its GLOBAL index, so S-sharded training draws the single-process masks
+        self.drop_call = bfr.reserve_dropout_call()
+        self.shard_start = int(shard_start)
 
     @contextlib.contextmanager
     def replay(self):

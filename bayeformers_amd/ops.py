@@ -572,11 +572,22 @@ def embedding_backward(ids: Tensor, grad: Tensor, mu: Tensor, rho: Tensor, S: in
 class Dropout:
     """One dropout of the training-mode forward, as the kernels take it (the dropout contract of csrc/bf_philox.h):
     rate p, the Philox seed, `call` = the number of the forward it belongs to (reserved with the forward's sample indices, so
-    a backward pass and the recomputation of a checkpointed block find the same mask) and `site` = the module."""
-    __slots__ = ("p", "seed", "call", "site")
+    a backward pass and the recomputation of a checkpointed block find the same mask) and `site` = the module.
+    `origin` = (first global sample of this process's shard, samples in the shard): the kernels number their groups from
+    first_sample x (groups per sample), so a sample's masks do not depend on which rank runs it (random.dropout_origin)."""
+    __slots__ = ("p", "seed", "call", "site", "origin")
 
-    def __init__(self, p: float, seed: int, call: int, site: int):
+    def __init__(self, p: float, seed: int, call: int, site: int, origin=(0, 1)):
         self.p, self.seed, self.call, self.site = float(p), int(seed), int(call) & 0xFFFFFFFF, int(site) & 0x7FFFFFFF
+        self.origin = (int(origin[0]), max(1, int(origin[1])))
+
+    def first_group(self, units: int, groups_per_unit: int) -> int:
+        """Global index of the first group of a tensor made of `units` rows (or sequences) of `groups_per_unit` groups each,
+        the units being this shard's samples in equal slabs."""
+        start, s_local = self.origin
+        if start == 0 or units % s_local:
+            return 0
+        return start * (units // s_local) * int(groups_per_unit)
 
     @property
     def keep_scale(self) -> float:
@@ -613,7 +624,8 @@ def add_layernorm(x: Tensor, residual: Optional[Tensor], gamma: Tensor, beta: Te
         _C.check(_C.lib().bf_add_layernorm_dropout(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
                                                    beta.data_ptr(), _TORCH2BF[gamma.dtype], out.data_ptr(),
                                                    _TORCH2BF[x.dtype], x2.shape[0], N, float(eps), drop.p, drop.seed,
-                                                   drop.call, drop.site, _stream_ptr()), "bf_add_layernorm_dropout")
+                                                   drop.call, drop.site, drop.first_group(x2.shape[0], N // 8), _stream_ptr()),
+                 "bf_add_layernorm_dropout")
         return out.view(x.shape)
     _C.check(_C.lib().bf_add_layernorm(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
                                        beta.data_ptr(), _TORCH2BF[gamma.dtype], out.data_ptr(), _TORCH2BF[x.dtype],
@@ -678,6 +690,7 @@ def attention_forward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tensor
                                                    mask_off.data_ptr() if mask_off is not None else None, out.data_ptr(),
                                                    lse.data_ptr() if lse is not None else None, _TORCH2BF[q.dtype], B, T, H,
                                                    D, H * D, float(scaling), drop.p, drop.seed, drop.call, drop.site,
+                                                   drop.first_group(B, H * T * (T // 32) * 4),
                                                    keep.data_ptr() if keep is not None else None, _stream_ptr()),
                  "bf_attention_fwd_dropout")
         res = (out,) + ((lse,) if want_lse else ()) + ((keep,) if want_keep else ())
@@ -800,7 +813,8 @@ def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor,
                                                  dz.data_ptr(), dx.data_ptr() if dropping else None, dgamma.data_ptr(),
                                                  dbeta.data_ptr(), ws.data_ptr(), ws.numel(), _TORCH2BF[x.dtype], x2.shape[0], N,
                                                  float(eps), drop.p if dropping else 0.0, drop.seed if dropping else 0,
-                                                 drop.call if dropping else 0, drop.site if dropping else 0, colsum_samples,
+                                                 drop.call if dropping else 0, drop.site if dropping else 0,
+                                                 drop.first_group(x2.shape[0], N // 8) if dropping else 0, colsum_samples,
                                                  colsum.data_ptr(), _stream_ptr()), "bf_add_layernorm_bwd_colsum")
         gx = dx.view(x.shape) if dropping else dz.view(x.shape)
         offer_colsum(gx, colsum)
@@ -815,7 +829,8 @@ def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor,
                                               dx.data_ptr() if dropping else None, dgamma.data_ptr(), dbeta.data_ptr(),
                                               ws.data_ptr(), ws.numel(), _TORCH2BF[x.dtype], x2.shape[0], N, float(eps),
                                               drop.p if dropping else 0.0, drop.seed if dropping else 0,
-                                              drop.call if dropping else 0, drop.site if dropping else 0, _stream_ptr()),
+                                              drop.call if dropping else 0, drop.site if dropping else 0,
+                                              drop.first_group(x2.shape[0], N // 8) if dropping else 0, _stream_ptr()),
                  "bf_add_layernorm_bwd_sum")
         return (dz.view(x.shape), dgamma, dbeta, dx.view(x.shape)) if dropping else (dz.view(x.shape), dgamma, dbeta)
     if drop is not None and drop.p > 0.0:
@@ -824,7 +839,8 @@ def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor,
                                                   _TORCH2BF[gamma.dtype], g2.data_ptr(), dz.data_ptr(), dx.data_ptr(),
                                                   dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   _TORCH2BF[x.dtype], x2.shape[0], N, float(eps), drop.p, drop.seed, drop.call,
-                                                  drop.site, _stream_ptr()), "bf_add_layernorm_dropout_bwd")
+                                                  drop.site, drop.first_group(x2.shape[0], N // 8), _stream_ptr()),
+                 "bf_add_layernorm_dropout_bwd")
         return dz.view(x.shape), dgamma, dbeta, dx.view(x.shape)
     _C.check(lib.bf_add_layernorm_bwd(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
                                       _TORCH2BF[gamma.dtype], g2.data_ptr(), dz.data_ptr(), dgamma.data_ptr(),

@@ -190,6 +190,13 @@ def dropout_call() -> int:
     return ctx.drop_call if ctx is not None else reserve_dropout_call()
 
 
+def dropout_origin():
+    """(first global sample of this process's shard within the step, samples in the shard) of the running — or, in a
+    recomputed block, the original — bnn.Model forward: what makes a sample's dropout masks independent of the sharding."""
+    ctx = STATE.ctx if STATE.ctx is not None else recompute_context()
+    return (ctx.shard_start, ctx.S) if ctx is not None else (0, 1)
+
+
 def dropout_site(module) -> int:
     """The `site` number of a module (assigned at its first dropout, in execution order: stable for a given model)."""
     site = getattr(module, "_bf_drop_site", None)

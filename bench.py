@@ -929,8 +929,8 @@ def main():
             gn, gms, gflop = fn, fms, fflop
             kernel, bound, fused = fused["kernel"], "latency", None
         else:
-            kernel = ("gemm_f32_kernel (sampled-weight GEMM on the exact fp32-input MFMA; mean over the step's GEMM launches)"
-                      if dtype == "fp32" else
+            kernel = ("gemm256_ring5_kernel<float> (sampled-weight GEMM on v_mfma_f32_16x16x4_f32, five-slot LDS ring; mean over "
+                      "the step's tiled-GEMM launches)" if dtype == "fp32" else
                       "gemm256_ring5_kernel (sampled-weight GEMM, five-slot LDS ring; mean over the step's tiled-GEMM launches)")
             bound = "mfma"
         tflops = gflop / (gms * 1e-3) / 1e12 if gms > 0 else 0.0

@@ -328,6 +328,9 @@ int bf_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const fl
  *   call = one number per forward (the Python side reserves it with the forward's sample indices, so the recomputation
  *          of a checkpointed block finds the same masks), site = the module the dropout belongs to.
  * bf_dropout_keep_host: the host twin — keep flags (0 / 1), 8 per group, of groups first_group .. first_group + n_groups.
+ * first_group (the five device entries): the index of the tensor's first group in the step's GLOBAL numbering — 0 on one
+ *   process; an S-sharded rank passes (first global sample of its shard) x (groups per sample), so that sample s draws the
+ *   same masks whichever rank runs it.
  *
  * bf_attention_fwd_dropout: bf_attention_fwd with the probabilities dropped after the softmax normalisation.  Group of
  *   probability (b, h, q, key): g = (((b*H + h)*T + q) * (T/32) + (key/128)*4 + c) * 4 + lg, field e*4 + j, where
@@ -340,7 +343,7 @@ int bf_dropout_keep_host(uint8_t* out, uint64_t first_group, uint64_t n_groups, 
                          uint32_t site);
 int bf_attention_fwd_dropout(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
                              void* d_out, float* d_lse, int dtype, int B, int T, int H, int head_dim, int64_t token_stride,
-                             float scaling, float p_drop, uint64_t seed, uint32_t call, uint32_t site, uint32_t* d_keep_bits,
+                             float scaling, float p_drop, uint64_t seed, uint32_t call, uint32_t site, uint64_t first_group, uint32_t* d_keep_bits,
                              void* stream);
 int bf_attention_bwd_dropout(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
                              const void* d_out, const void* d_dout, const float* d_lse, float* d_delta, void* d_dq, void* d_dk,
@@ -360,11 +363,11 @@ int bf_attention_bwd_colsum(const void* d_q, const void* d_k, const void* d_v, c
                             void* stream);
 int bf_add_layernorm_dropout(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, int param_dtype,
                              void* d_out, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed, uint32_t call,
-                             uint32_t site, void* stream);
+                             uint32_t site, uint64_t first_group, void* stream);
 int bf_add_layernorm_dropout_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
                                  const void* d_dy, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
                                  size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
-                                 uint32_t call, uint32_t site, void* stream);
+                                 uint32_t call, uint32_t site, uint64_t first_group, void* stream);
 
 /* bf_add_layernorm_bwd / bf_add_layernorm_dropout_bwd (p_drop = 0: no dropout, d_dx unused) for an output that had TWO
  * consumers — in a transformer layer the normalised rows feed the next dense layer AND the next residual connection
@@ -374,7 +377,7 @@ int bf_add_layernorm_dropout_bwd(const void* d_x, const void* d_residual, const 
 int bf_add_layernorm_bwd_sum(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,
                              const void* d_dy2, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
                              size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
-                             uint32_t call, uint32_t site, void* stream);
+                             uint32_t call, uint32_t site, uint64_t first_group, void* stream);
 
 /* bf_add_layernorm_bwd_sum that also leaves the per-sample COLUMN SUMS of the gradient it hands to the layer in front of
  * it — d_dx with dropout, d_dz without: d_colsum [samples][N] fp32, the `rows` being `samples` equal slabs.  In
@@ -384,7 +387,7 @@ int bf_add_layernorm_bwd_sum(const void* d_x, const void* d_residual, const void
 int bf_add_layernorm_bwd_colsum(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,
                                 const void* d_dy2, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
                                 size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
-                                uint32_t call, uint32_t site, int samples, float* d_colsum, void* stream);
+                                uint32_t call, uint32_t site, uint64_t first_group, int samples, float* d_colsum, void* stream);
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * While enabled, every sampling launch (kind BF_PROF_SAMPLE) and every GEMM launch (BF_PROF_GEMM) made through

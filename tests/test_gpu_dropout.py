@@ -137,3 +137,63 @@ def test_train_mode_bert_takes_the_fused_paths_and_repeats_its_masks():
         assert grads and all(torch.isfinite(g).all() for g in grads)
     finally:
         ops.AttentionFn.forward, ops.AddLayerNormFn.forward = orig_attn, orig_ln
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_a_shard_draws_the_masks_of_its_global_samples(dtype):
+    """the in-kernel dropout masks are a function of the GLOBAL Monte-Carlo sample (like epsilon), not of where a
+    sample lies in the rank's batch: the slabs of samples [2, 4) run as a shard of their own — Dropout(origin=(2, 2)), what
+    bnn.Model.monte_carlo(span=(2, 4)) hands the kernels — come out bit for bit as in the unsharded run of all four, forward
+    and backward, for the residual + LayerNorm block and for the attention probabilities."""
+    S, rows_per_sample, N, p = 4, 96, 256, 0.2
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x, res, go = (torch.randn(S * rows_per_sample, N, device="cuda", generator=g).to(dtype) for _ in range(3))
+    gamma, beta = torch.randn(N, device="cuda", generator=g), torch.randn(N, device="cuda", generator=g)
+    full = ops.Dropout(p, SEED, 7, 3)
+    shard = ops.Dropout(p, SEED, 7, 3, origin=(2, 2))
+    lo = 2 * rows_per_sample
+    y_full = ops.add_layernorm(x, res, gamma, beta, 1e-12, full)
+    y_shard = ops.add_layernorm(x[lo:].contiguous(), res[lo:].contiguous(), gamma, beta, 1e-12, shard)
+    assert torch.equal(y_full[lo:], y_shard)
+    assert not torch.equal(y_full[:lo], y_shard)       # (and not the masks of samples 0, 1)
+    b_full = ops.add_layernorm_backward(x, res, gamma, go, 1e-12, full)
+    b_shard = ops.add_layernorm_backward(x[lo:].contiguous(), res[lo:].contiguous(), gamma, go[lo:].contiguous(), 1e-12, shard)
+    assert torch.equal(b_full[0][lo:], b_shard[0]) and torch.equal(b_full[3][lo:], b_shard[3])     # dz, dx
+    if dtype == torch.float32:
+        return
+    # attention probabilities: sequences of samples 2, 3 (Bs sequences per sample)
+    Bs, H, T, D = 3, 2, 128, 64
+    q, k, v = (torch.randn(S * Bs, T, H * D, device="cuda", generator=g).to(dtype).view(S * Bs, T, H, D).transpose(1, 2) for _ in range(3))
+    o_full = ops.attention_forward(q, k, v, None, 0.125, None, drop=full)
+    o_shard = ops.attention_forward(q[2 * Bs:], k[2 * Bs:], v[2 * Bs:], None, 0.125, None, drop=shard)
+    assert torch.equal(o_full[2 * Bs:], o_shard) and not torch.equal(o_full[:2 * Bs], o_shard)
+
+
+def test_sharded_train_mode_forward_equals_the_unsharded_one():
+    """The same through the model: a converted BERT in .train() (embedding dropout off: that one is the framework's RNG) run as
+    two shards of two samples gives, sample by sample, the logits of the unsharded four-sample forward."""
+    from transformers import BertConfig, BertForSequenceClassification
+
+    cfg = BertConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, vocab_size=300,
+                     max_position_embeddings=128)
+    torch.manual_seed(0)
+    bmodel = bf.to_bayesian(BertForSequenceClassification(cfg), delta=0.05, freeze=True).cuda().to(torch.bfloat16)
+    bf.fuse_activations(bmodel), bf.fuse_residual_layernorm(bmodel), bf.fuse_shared_inputs(bmodel)
+    bf.fuse_attention(bmodel), bf.fuse_embeddings(bmodel)
+    bmodel.train()
+    bmodel.model.bert.embeddings.dropout.p = 0.0
+    bmodel.model.dropout.p = 0.0                         # the pooled-output dropout is the framework's too
+    ids = torch.randint(0, 300, (3, 128), generator=torch.Generator().manual_seed(1)).cuda()
+    S = 4
+
+    def run(start, count):
+        bf.manual_seed(SEED)
+        with torch.no_grad(), bmodel.monte_carlo(count, span=(start, S)):
+            out = bmodel(input_ids=ids.repeat(count, 1), attention_mask=torch.ones_like(ids).repeat(count, 1))
+        return out.logits.float().view(count, 3, -1)
+
+    whole = run(0, S)
+    assert not torch.equal(whole[0], whole[2])
+    for start in (0, 2):
+        part = run(start, 2)
+        assert torch.equal(part, whole[start:start + 2]), start
