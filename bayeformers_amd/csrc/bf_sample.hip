@@ -281,8 +281,13 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][k
                 if (outp) {
                     const unsigned long long idx = (unsigned long long)s * a.n + e0[j];
                     const f32x4_t w4 = {w01[0], w01[1], w23[0], w23[1]};
-                    if (out_dt == BF_DT_BF16) *reinterpret_cast<bf16x4_t*>(outp + idx * 2) = __builtin_convertvector(w4, bf16x4_t);
-                    else if (out_dt == BF_DT_F16) *reinterpret_cast<f16x4_t*>(outp + idx * 2) = __builtin_convertvector(w4, f16x4_t);
+#ifndef BF_SAMPLE_NT_STORES
+#define BF_SAMPLE_NT_STORES 0  // 1: the sampled weights leave through nontemporal stores (experiment, profiles/r5i_*)
+#endif
+                    if (out_dt == BF_DT_BF16) {
+                        if (BF_SAMPLE_NT_STORES) __builtin_nontemporal_store(__builtin_convertvector(w4, bf16x4_t), reinterpret_cast<bf16x4_t*>(outp + idx * 2));
+                        else *reinterpret_cast<bf16x4_t*>(outp + idx * 2) = __builtin_convertvector(w4, bf16x4_t);
+                    } else if (out_dt == BF_DT_F16) *reinterpret_cast<f16x4_t*>(outp + idx * 2) = __builtin_convertvector(w4, f16x4_t);
                     else *reinterpret_cast<f32x4_t*>(outp + idx * 4) = w4;
                 }
             }
