@@ -26,6 +26,11 @@
 
 namespace {
 
+#ifndef BF_R5_ASYM
+#define BF_R5_ASYM 0  // experiment (round 5): ALL LDS-DMA pieces of a unit are issued by wave group 1 (8 per wave and L slot), group 0's
+// L slots carry fragment reads only — does a piece cost less when the partner group's slot is free of them?  Forward form only.
+// Measured: profiles/r5j_ring_asymmetric_dma_ab.txt.
+#endif
 #ifndef BF_R5_EARLY_ACT
 #define BF_R5_EARLY_ACT 0  // experiment, see `mfmas` below: an extra instantiation (EA) for launches with a fused activation
 #endif
@@ -92,7 +97,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     const T* xb;
     const T* wb;
     unsigned xo, wo;  // per-lane byte offset of piece 0 (rows 8 wid .. 8 wid + 7); piece i lies 64 rows = `rowblk` bytes further
-    const unsigned rowblk = 64u * (unsigned)K * ES;
+    constexpr bool ASYM = BF_R5_ASYM && !TRW && !SEG && !DPPE && sizeof(T) == 2;
+    const unsigned rowblk = (ASYM ? 32u : 64u) * (unsigned)K * ES;  // rows between a wave's consecutive pieces of a unit
     // An operand is fetched through a buffer descriptor that ends with the sample's operand: rows past M (N) of a partial
     // tile are out of range and arrive as zeros (their products land in rows / columns the epilogue masks) — no per-row
     // clamp, so ONE offset register per operand instead of four.
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                 asm volatile("" : "+v"(ln));
                 kc8 = ((ln & 7) ^ (((ln >> 4) & 1) | ((wid >> 1) << 1))) * 8;
             }
-            wo = ((unsigned)(n0 + wid * 8 + prow) * (unsigned)K + kc8) * ES;
+            wo = ((unsigned)(n0 + (ASYM ? (wid & 3) : wid) * 8 + prow) * (unsigned)K + kc8) * ES;
             w_bytes = (unsigned)N * (unsigned)K * ES;
         }
     };
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         xb = reinterpret_cast<const T*>(p.x) + (long long)__builtin_amdgcn_readfirstlane(d.y) * p.x_sstride;
         int prow, kc8;
         piece_lane(prow, kc8);
-        xo = ((unsigned)(m0 + wid * 8 + prow) * (unsigned)K + kc8) * ES;
+        xo = ((unsigned)(m0 + (ASYM ? (wid & 3) : wid) * 8 + prow) * (unsigned)K + kc8) * ES;
         x_bytes = (unsigned)M * (unsigned)K * ES;
     };
     // one 1 KiB piece: `base` (a buffer of `bytes`) + per-lane byte offset `off` + wave-uniform byte offset `soff` -> LDS `dst`
@@ -174,6 +180,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
 #ifdef BF_DEV
         if (p.flags & 64) kt = 0;  // ablation: every k-step re-reads k-step 0 (operands L2-hot)
 #endif
+        if constexpr (ASYM) {  // group 1 only: piece q = i * 4 + (wid & 3), i = 0 .. 7
+            if (wm == 0) return;
+            char* base = smem + slot * SLOT_BYTES + (wid & 3) * 1024;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i * 4 + 3 < h4 || i * 4 + (wid & 3) < h4) piece_x(xb, x_bytes, xo + i * rowblk, kt * ROW_BYTES, base + i * 4096);
+            return;
+        }
         char* base = smem + slot * SLOT_BYTES + wid * 1024;
         const int seg = segment(kt);
         const T* xs = SEG ? xb + (long long)seg * p.x_seg_stride : xb;
@@ -185,6 +199,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
 #ifdef BF_DEV
         if (p.flags & 64) kt = 0;
 #endif
+        if constexpr (ASYM) {
+            if (wm == 0) return;
+            char* base = smem + slot * SLOT_BYTES + (wid & 3) * 1024;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) piece_w(wb, w_bytes, wo + i * rowblk, kt * ROW_BYTES, base + i * 4096);
+            return;
+        }
         char* base = smem + slot * SLOT_BYTES + wid * 1024;
         const int seg = segment(kt);
         const T* ws = SEG ? wb + (long long)seg * p.w_seg_stride : wb;
@@ -258,7 +279,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     issue_w(0, 0);
     issue_x(0, 1, 4 * h);
     issue_w(1, 2);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (ASYM) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     int round = 0;
@@ -371,6 +393,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                     if (MODE == 0 || has_next) {
                         // (split issue: group 1 waits in its L1 with only the first two pieces of the newest unit out)
                         if (BF_R5_SPLIT && wm == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        else if (ASYM) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // a unit = 8 pieces of the issuing wave
                         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 };
