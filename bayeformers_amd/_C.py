@@ -94,8 +94,6 @@ SYMBOLS = {
                                       ctypes.c_float, _u64, _u32, _u32, _u64, _vp]),
     "bf_attention_bwd_colsum": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64,
                                      ctypes.c_float, ctypes.c_float, _vp, _i, _vp, _vp, _vp]),
-    "bf_add_layernorm_bwd_colsum": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i64, _i,
-                                         ctypes.c_float, ctypes.c_float, _u64, _u32, _u32, _u64, _i, _vp, _vp]),
     "bf_profile_enable": (_i, [_i]),
     "bf_profile_reset": (_i, []),
     "bf_probe_stream_read": (_i, [_vp, _sz, _vp, _vp]),

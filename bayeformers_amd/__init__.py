@@ -106,19 +106,15 @@ def _dense_residual_norm_forward(self, hidden_states, input_tensor):
     # regenerated in the backward pass — no mask tensor, no extra pass over the dense output
     drop = ops.Dropout(self.dropout.p, bfr.STATE.seed, bfr.dropout_call(), bfr.dropout_site(self), bfr.dropout_origin()) if dropping else None
     if torch.is_grad_enabled() and (hidden_states.requires_grad or input_tensor.requires_grad or ln.weight.requires_grad):
-        # the backward of this block hands `hidden_states` its gradient: when the dense layer is a Bayesian one with a bias,
-        # the per-sample column sums of that gradient (its bias gradient) come out of the same kernel
-        fwd = bfr.STATE.ctx
-        cs = fwd.S if (fwd is not None and isinstance(self.dense, nn.Linear) and not isinstance(self.dense.bias, nn.NoneParameter)) else 0
         if ops._NO_TWIN:
-            return ops.AddLayerNormFn.apply(hidden_states, input_tensor, ln.weight, ln.bias, ln.eps, drop, False, cs)
+            return ops.AddLayerNormFn.apply(hidden_states, input_tensor, ln.weight, ln.bias, ln.eps, drop)
         # The output of such a block has two consumers in a transformer layer — the next dense layer and the next block's
         # residual connection.  The block hands out `y` with its second alias attached; the next block of this kind takes
         # the alias as its residual input, so the two gradients reach this block's backward separately and are added
         # inside its kernel (AddLayerNormFn, twin).  A consumer that does not know about the alias just uses `y`.
         residual = getattr(input_tensor, "_bf_twin", None)
         y, y2 = ops.AddLayerNormFn.apply(hidden_states, residual if residual is not None else input_tensor, ln.weight, ln.bias,
-                                         ln.eps, drop, True, cs)
+                                         ln.eps, drop, True)
         y._bf_twin = y2
         return y
     return ops.add_layernorm(hidden_states, input_tensor, ln.weight, ln.bias, ln.eps, drop)

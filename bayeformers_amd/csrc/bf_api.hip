@@ -546,18 +546,6 @@ int bf_add_layernorm_bwd_sum(const void* d_x, const void* d_residual, const void
                                        d_dy2);
 }
 
-int bf_add_layernorm_bwd_colsum(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,
-                                const void* d_dy2, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
-                                size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
-                                uint32_t call, uint32_t site, uint64_t first_group, int samples, float* d_colsum, void* stream) {
-    if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_add_layernorm_bwd_colsum: p must be in [0, 1) (got %g)", p_drop);
-    if (!d_colsum || samples < 1) BF_FAIL("bf_add_layernorm_bwd_colsum: needs d_colsum and samples >= 1");
-    const bf_dropout_t d = make_dropout(p_drop, seed, call, site, first_group);
-    return bf_launch_add_layernorm_bwd(d_x, d_residual, d_gamma, param_dtype, d_dy, d_dz, d_dgamma, d_dbeta, d_workspace,
-                                       workspace_bytes, dtype, rows, N, eps, (hipStream_t)stream, d.thresh ? &d : nullptr, d_dx,
-                                       d_dy2, samples, d_colsum);
-}
-
 size_t bf_add_layernorm_bwd_workspace_bytes(int64_t rows, int N) { return bf_add_layernorm_bwd_ws_bytes(rows, N); }
 
 int bf_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,

@@ -218,5 +218,4 @@ size_t bf_add_layernorm_bwd_ws_bytes(long long rows, int N);
 int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
                                 const void* d_dy, void* d_dz, float* d_dgamma, float* d_dbeta, void* d_workspace,
                                 size_t workspace_bytes, int dtype, long long rows, int N, float eps, hipStream_t stream,
-                                const bf_dropout_t* drop = nullptr, void* d_dx = nullptr, const void* d_dy2 = nullptr,
-                                int samples = 0, float* d_colsum = nullptr);
+                                const bf_dropout_t* drop = nullptr, void* d_dx = nullptr, const void* d_dy2 = nullptr);

@@ -6,8 +6,6 @@
 // HBM-bound streaming kernel: one wave64 per row, the row lives in registers (fp32) between the load and the
 // store, statistics by the two-pass formula on those registers (mean, then sum of squared deviations), wave
 // reductions on the DPP network.  Algorithmic bytes per row: N * (2 reads + 1 write) * sizeof(T).
-#include <algorithm>
-
 #include "bf_common.h"
 #include "bf_device.h"
 #include "bf_philox.h"
@@ -64,11 +62,16 @@ constexpr int kRowsPerBlock = 4;  // one wave per row
 
 // hidden dropout of the dense output (HF BertSelfOutput / BertOutput: LayerNorm(dropout(dense(h)) + input), training mode):
 // the 8-element vector `vec` (= 8 consecutive features) of row `row` is dropout group row * (N / 8) + vec of bf_philox.h
-__device__ __forceinline__ void drop8(const bf_dropout_t& d, long long row, int nvec, int vec, float (&v)[8]) {
+__device__ __forceinline__ uint32_t drop8_bits(const bf_dropout_t& d, long long row, int nvec, int vec) {
     const unsigned long long g = (unsigned long long)row * (unsigned)nvec + (unsigned)vec + (((unsigned long long)d.g0_hi << 32) | d.g0_lo);
-    const uint32_t keep = bf_dropout_keep8((uint32_t)g, (uint32_t)(g >> 32), d.call, d.site, d.k0, d.k1, d.thresh);
+    return bf_dropout_keep8((uint32_t)g, (uint32_t)(g >> 32), d.call, d.site, d.k0, d.k1, d.thresh);
+}
+__device__ __forceinline__ void drop8_apply(const bf_dropout_t& d, uint32_t keep, float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = ((keep >> i) & 1u) ? v[i] * d.inv_keep : 0.f;
+}
+__device__ __forceinline__ void drop8(const bf_dropout_t& d, long long row, int nvec, int vec, float (&v)[8]) {
+    drop8_apply(d, drop8_bits(d, row, nvec, vec), v);
 }
 
 // VPL = 8-element vectors per lane: a row has N/8 <= 64*VPL of them
@@ -193,50 +196,43 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_half_kernel(
 // [2][N] fp32 row per workgroup, reduced in a fixed order by layernorm_param_grad_kernel (deterministic).
 // DROP: z = dropout(x) + residual with the forward's keep-mask regenerated (bf_philox.h); dz is the gradient of the
 // residual, and dx = dz o keep / (1 - p) goes to its own tensor.
-// CS (round 5): the COLUMN SUMS of the gradient this block hands to the dense layer in front of it (dx with dropout, dz
-// without) — the bias gradient of that layer, per Monte-Carlo sample — come out of the same pass instead of a launch that
-// reads the gradient again (bf_linear_bwd's column-sum pass: 24 launches of 16 us per BERT-base training step).  A
-// workgroup then walks a CONTIGUOUS range of `rows_per_block` rows that lies inside one sample (the host picks it so),
-// and leaves a third partial row; layernorm_param_grad_kernel adds the partial rows of a sample's workgroups.
-template <typename T, typename GT, int VPL, bool DROP = false, bool CS = false>
-__global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_bwd_kernel(
+// With dropout the kernel needs 132 VGPRs = 3 waves per SIMD; asked for 4 it fits in 128 (5 spilled dwords) and this
+// latency-bound pass runs 109 -> 79 us (two consumers: 129 -> 92 us) at the BERT-base training shape (tools/ln_bwd_bench.py, round 5).
+// (Folding the next dense layer's bias column sums into this kernel was built and measured in round 5: 16 more accumulators cost a
+// wave per SIMD again (+25-45 us), LDS ds_add_f32 accumulation 190-207 us — a column-sum pass of its own, 16 us, stays cheaper.)
+#ifndef BF_LN_BWD_DROP_WAVES
+#define BF_LN_BWD_DROP_WAVES 4  // 1 = no request (132 VGPRs, 3 waves per SIMD): the A/B baseline
+#endif
+template <typename T, typename GT, int VPL, bool DROP = false>
+__global__ __launch_bounds__(64 * kRowsPerBlock, (DROP && VPL <= 2) ? BF_LN_BWD_DROP_WAVES : 1) void add_layernorm_bwd_kernel(
     const T* __restrict__ x, const T* __restrict__ res, const GT* __restrict__ gamma, const T* __restrict__ dy,
     T* __restrict__ dz, float* __restrict__ partial, long long rows, int N, float eps, const bf_dropout_t drop,
-    T* __restrict__ dx, const T* __restrict__ dy2, long long rows_per_sample, int blocks_per_sample, int rows_per_block) {
-    extern __shared__ float sh[];  // [kRowsPerBlock][NP][N]
-    constexpr int NP = CS ? 3 : 2;
+    T* __restrict__ dx, const T* __restrict__ dy2) {
+    extern __shared__ float sh[];  // [kRowsPerBlock][2][N]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = N >> 3;
-    float gm[VPL][8], dgam[VPL][8], dbet[VPL][8], dcs[CS ? VPL : 1][8];
+    float gm[VPL][8], dgam[VPL][8], dbet[VPL][8];
 #pragma unroll
     for (int c = 0; c < VPL; ++c) {
         const int vi = lane + 64 * c;
 #pragma unroll
         for (int i = 0; i < 8; ++i) gm[c][i] = dgam[c][i] = dbet[c][i] = 0.f;
-        if constexpr (CS) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dcs[c][i] = 0.f;
-        }
         if (vi < nvec) load8(gamma + vi * 8, gm[c]);
     }
     const float inv_n = 1.0f / (float)N;
-    long long row_first = (long long)blockIdx.x * kRowsPerBlock + wave, row_end = rows, row_step = (long long)gridDim.x * kRowsPerBlock;
-    if constexpr (CS) {  // rows [first, end) of sample blockIdx.x / blocks_per_sample, the waves interleaved inside it
-        const long long smp = blockIdx.x / blocks_per_sample, j = blockIdx.x % blocks_per_sample;
-        const long long lo = smp * rows_per_sample + j * rows_per_block;
-        row_end = min(lo + rows_per_block, (smp + 1) * rows_per_sample);
-        row_first = lo + wave;
-        row_step = kRowsPerBlock;
-    }
-    for (long long row = row_first; row < row_end; row += row_step) {
+    for (long long row = (long long)blockIdx.x * kRowsPerBlock + wave; row < rows; row += (long long)gridDim.x * kRowsPerBlock) {
         float v[VPL][8], g[VPL][8];
+        uint32_t kept[DROP ? VPL : 1];  // the row's keep decisions: drawn once, used on load and on store
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < VPL; ++c) {
             const int vi = lane + 64 * c;
             if (vi < nvec) {
                 load8(x + row * N + vi * 8, v[c]);
-                if constexpr (DROP) drop8(drop, row, nvec, vi, v[c]);
+                if constexpr (DROP) {
+                    kept[c] = drop8_bits(drop, row, nvec, vi);
+                    drop8_apply(drop, kept[c], v[c]);
+                }
                 if (res) {
                     float r[8];
                     load8(res + row * N + vi * 8, r);
@@ -289,12 +285,8 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_bwd_kernel(
                 for (int i = 0; i < 8; ++i) o[i] = rstd * (g[c][i] - s1 - v[c][i] * s2);
                 store8(dz + row * N + vi * 8, o);
                 if constexpr (DROP) {
-                    drop8(drop, row, nvec, vi, o);  // the same groups, the same decisions: dx = dz o keep / (1 - p)
+                    drop8_apply(drop, kept[c], o);  // the same groups, the same decisions: dx = dz o keep / (1 - p)
                     store8(dx + row * N + vi * 8, o);
-                }
-                if constexpr (CS) {  // what the dense layer receives, as it is stored (rounded to T)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) dcs[c][i] += (float)(T)o[i];
                 }
             }
         }
@@ -306,42 +298,36 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_bwd_kernel(
         if (vi < nvec)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                sh[(wave * NP + 0) * N + vi * 8 + i] = dgam[c][i];
-                sh[(wave * NP + 1) * N + vi * 8 + i] = dbet[c][i];
-                if constexpr (CS) sh[(wave * NP + 2) * N + vi * 8 + i] = dcs[c][i];
+                sh[(wave * 2 + 0) * N + vi * 8 + i] = dgam[c][i];
+                sh[(wave * 2 + 1) * N + vi * 8 + i] = dbet[c][i];
             }
     }
     __syncthreads();
-    for (int n = threadIdx.x; n < NP * N; n += blockDim.x) {
+    for (int n = threadIdx.x; n < 2 * N; n += blockDim.x) {
         const int which = n / N, col = n - which * N;
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < kRowsPerBlock; ++w) acc += sh[(w * NP + which) * N + col];
-        partial[((long long)blockIdx.x * NP + which) * N + col] = acc;
+        for (int w = 0; w < kRowsPerBlock; ++w) acc += sh[(w * 2 + which) * N + col];
+        partial[((long long)blockIdx.x * 2 + which) * N + col] = acc;
     }
 }
 
 __global__ __launch_bounds__(1024) void layernorm_param_grad_kernel(const float* __restrict__ partial, int nblocks, int N,
-                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                    int np, int blocks_per_sample, float* __restrict__ colsum) {
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
     // block = 16 columns x 64 lanes over the workgroup axis (2 N / 16 blocks: 96 for N = 768 — with 64 columns per
-    // block the 24 blocks of a launch took 21 us for 6 MB of partials); fixed order -> deterministic.
-    // blockIdx.y = 0 dgamma, 1 dbeta, 2 + s: the column sums of sample s (partial row 2 of that sample's workgroups)
+    // block the 24 blocks of a launch took 21 us for 6 MB of partials); fixed order -> deterministic
     __shared__ float sh[64][16];
-    const int y = blockIdx.y, c = threadIdx.x & 15, n = blockIdx.x * 16 + c, cl = threadIdx.x >> 4;
-    const int which = y < 2 ? y : 2;
-    const int b0 = y < 2 ? 0 : (y - 2) * blocks_per_sample, b1 = y < 2 ? nblocks : b0 + blocks_per_sample;
+    const int which = blockIdx.y, c = threadIdx.x & 15, n = blockIdx.x * 16 + c, cl = threadIdx.x >> 4;
     float acc = 0.f;
     if (n < N)
-        for (int b = b0 + cl; b < b1; b += 64) acc += partial[((long long)b * np + which) * N + n];
+        for (int b = cl; b < nblocks; b += 64) acc += partial[((long long)b * 2 + which) * N + n];
     sh[cl][c] = acc;
     __syncthreads();
     if (cl == 0 && n < N) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 64; ++i) t += sh[i][c];
-        if (y >= 2) colsum[(long long)(y - 2) * N + n] = t;
-        else (which ? dbeta : dgamma)[n] = t;
+        (which ? dbeta : dgamma)[n] = t;
     }
 }
 
@@ -353,29 +339,27 @@ constexpr int kBwdBlocks = BF_LN_BWD_BLOCKS;  // workgroups (each leaves one [2]
 template <typename T, typename GT>
 int launch_bwd_vpl(const void* x, const void* res, const void* gamma, const void* dy, void* dz, float* partial,
                    int nblocks, long long rows, int N, float eps, hipStream_t stream, const bf_dropout_t* drop, void* dx,
-                   const void* dy2, long long rps = 0, int bps = 0, int rpb = 0) {
+                   const void* dy2) {
     const int nvec = N >> 3;
-    const bool cs = rps > 0;
-    const size_t lds = (size_t)kRowsPerBlock * (cs ? 3 : 2) * N * sizeof(float);
+    const size_t lds = (size_t)kRowsPerBlock * 2 * N * sizeof(float);
     const dim3 grid((unsigned)nblocks), block(64 * kRowsPerBlock);
     const bf_dropout_t d = drop ? *drop : bf_dropout_t{0, 0, 0, 0, 0, 1.0f, 0, 0};
-#define BF_LNB_LAUNCH1(VPL, DR, CSF)                                                                                        \
-    hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, GT, VPL, DR, CSF>), grid, block, lds, stream, (const T*)x,              \
-                       (const T*)res, (const GT*)gamma, (const T*)dy, (T*)dz, partial, rows, N, eps, d, (T*)dx,            \
-                       (const T*)dy2, rps, bps, rpb)
 #define BF_LNB_LAUNCH(VPL)                                                                                                  \
     do {                                                                                                                    \
-        if (d.thresh && cs) BF_LNB_LAUNCH1(VPL, true, true);                                                                \
-        else if (d.thresh) BF_LNB_LAUNCH1(VPL, true, false);                                                                \
-        else if (cs) BF_LNB_LAUNCH1(VPL, false, true);                                                                      \
-        else BF_LNB_LAUNCH1(VPL, false, false);                                                                             \
+        if (d.thresh)                                                                                                       \
+            hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, GT, VPL, true>), grid, block, lds, stream, (const T*)x,         \
+                               (const T*)res, (const GT*)gamma, (const T*)dy, (T*)dz, partial, rows, N, eps, d, (T*)dx,    \
+                               (const T*)dy2);                                                                              \
+        else                                                                                                                \
+            hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, GT, VPL, false>), grid, block, lds, stream, (const T*)x,        \
+                               (const T*)res, (const GT*)gamma, (const T*)dy, (T*)dz, partial, rows, N, eps, d, (T*)dx,    \
+                               (const T*)dy2);                                                                              \
     } while (0)
     if (nvec <= 64) BF_LNB_LAUNCH(1);
     else if (nvec <= 128) BF_LNB_LAUNCH(2);
     else if (nvec <= 256) BF_LNB_LAUNCH(4);
     else BF_LNB_LAUNCH(8);
 #undef BF_LNB_LAUNCH
-#undef BF_LNB_LAUNCH1
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -586,17 +570,14 @@ static int bwd_blocks(long long rows) {
 
 size_t bf_add_layernorm_bwd_ws_bytes(long long rows, int N) {
     if (rows < 1 || N < 1) return 0;
-    // (three partial rows per workgroup and the few extra workgroups of the per-sample decomposition: one size for both forms)
-    return ((size_t)bwd_blocks(rows) + 1024) * 3 * N * sizeof(float);
+    return (size_t)bwd_blocks(rows) * 2 * N * sizeof(float);
 }
 
 int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
                                 const void* d_dy, void* d_dz, float* d_dgamma, float* d_dbeta, void* d_workspace,
                                 size_t workspace_bytes, int dtype, long long rows, int N, float eps, hipStream_t stream,
-                                const bf_dropout_t* drop, void* d_dx, const void* d_dy2, int samples, float* d_colsum) {
+                                const bf_dropout_t* drop, void* d_dx, const void* d_dy2) {
     if ((uintptr_t)d_dy2 & 15) BF_FAIL("bf_add_layernorm_bwd: the second gradient must be 16-byte aligned");
-    if (d_colsum && (samples < 1 || rows % samples)) BF_FAIL("bf_add_layernorm_bwd: %lld rows are not %d samples", rows, samples);
-    if (d_colsum && samples > 1024) d_colsum = nullptr, samples = 0;  // (never the case in practice; the workspace bound above)
     if (drop && drop->thresh && (!d_dx || ((uintptr_t)d_dx & 15)))
         BF_FAIL("bf_add_layernorm_bwd: dropout needs a 16-byte aligned d_dx (the gradient of the dropped input)");
     if (rows < 0 || N <= 0) BF_FAIL("bf_add_layernorm_bwd: bad shape rows=%lld N=%d", rows, N);
@@ -612,22 +593,12 @@ int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const v
     if (al & 15) BF_FAIL("bf_add_layernorm_bwd: pointers must be 16-byte aligned");
     const size_t need = bf_add_layernorm_bwd_ws_bytes(rows, N);
     if (!d_workspace || workspace_bytes < need) BF_FAIL("bf_add_layernorm_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
-    int nb = bwd_blocks(rows);
-    // per-sample column sums: every workgroup takes `rpb` consecutive rows of ONE sample, `bps` workgroups per sample
-    long long rps = 0;
-    int bps = 0, rpb = 0;
-    if (d_colsum) {
-        rps = rows / samples;
-        const long long want = std::max<long long>(1, nb / samples);
-        rpb = (int)std::max<long long>(kRowsPerBlock, (rps + want - 1) / want);
-        bps = (int)((rps + rpb - 1) / rpb);
-        nb = bps * samples;
-    }
+    const int nb = bwd_blocks(rows);
     float* partial = reinterpret_cast<float*>(d_workspace);
     int rc = 1;
 #define BF_LNB_DISPATCH(T)                                                                                              \
-    rc = param_dtype == BF_DT_F32 ? launch_bwd_vpl<T, float>(d_x, d_residual, d_gamma, d_dy, d_dz, partial, nb, rows, N, eps, stream, drop, d_dx, d_dy2, rps, bps, rpb) \
-         : param_dtype == dtype   ? launch_bwd_vpl<T, T>(d_x, d_residual, d_gamma, d_dy, d_dz, partial, nb, rows, N, eps, stream, drop, d_dx, d_dy2, rps, bps, rpb)     \
+    rc = param_dtype == BF_DT_F32 ? launch_bwd_vpl<T, float>(d_x, d_residual, d_gamma, d_dy, d_dz, partial, nb, rows, N, eps, stream, drop, d_dx, d_dy2) \
+         : param_dtype == dtype   ? launch_bwd_vpl<T, T>(d_x, d_residual, d_gamma, d_dy, d_dz, partial, nb, rows, N, eps, stream, drop, d_dx, d_dy2)     \
                                   : (bf_set_error("bf_add_layernorm_bwd: gamma must be fp32 or have the activation dtype"), 1)
     switch (dtype) {
         case BF_DT_BF16: BF_LNB_DISPATCH(__bf16); break;
@@ -637,8 +608,8 @@ int bf_launch_add_layernorm_bwd(const void* d_x, const void* d_residual, const v
     }
 #undef BF_LNB_DISPATCH
     if (rc) return rc;
-    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((N + 15) / 16, d_colsum ? 2 + samples : 2), dim3(1024), 0, stream,
-                       partial, nb, N, d_dgamma, d_dbeta, d_colsum ? 3 : 2, bps, d_colsum);
+    hipLaunchKernelGGL(layernorm_param_grad_kernel, dim3((N + 15) / 16, 2), dim3(1024), 0, stream, partial, nb, N, d_dgamma,
+                       d_dbeta);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }

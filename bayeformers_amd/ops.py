@@ -411,7 +411,7 @@ def planned_linear_forward(x: Tensor, w_s: Tensor, b_s: Optional[Tensor], S: int
 
 COLSUMS_FOLDED = [0]  # bias gradients whose column sums came with the output gradient (tests, diagnostics)
 
-# Column sums a gradient's PRODUCER left for its consumer (add_layernorm_backward, attention_backward -> linear_backward).
+# Column sums a gradient's PRODUCER left for its consumer (attention_backward -> linear_backward of query / key / value).
 # Between the two the gradient passes through autograd — as the same tensor object or as views of it (HF's head split /
 # merge) — so the hand-over is keyed by where the gradient lives: (storage address, byte offset, elements), valid while that
 # very storage is alive AND unmodified: autograd's engine may add a second gradient into the producer's tensor IN PLACE
@@ -458,8 +458,8 @@ def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_
     M = x.shape[0] // S
     has_bias = not isinstance(layer.bias, NoneParameter)
     if dy_colsum is None and has_bias and not act:
-        # the kernel that produced grad_y may have left its per-sample column sums with it (add_layernorm_backward,
-        # attention_backward): valid for exactly this tensor, as it is (same dtype: no rounding in between)
+        # the kernel that produced grad_y may have left its per-sample column sums with it (attention_backward): valid for
+        # exactly this tensor, as it is (same dtype: no rounding in between)
         cs = take_colsum(grad_y, S, N) if (grad_y.dtype == cdt and grad_y.numel() == S * M * N) else None
         if cs is not None:
             dy_colsum = cs
@@ -778,7 +778,7 @@ class AttentionFn(torch.autograd.Function):
 
 
 def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor, grad_out: Tensor, eps: float,
-                           drop: Optional[Dropout] = None, grad_out2: Optional[Tensor] = None, colsum_samples: int = 0):
+                           drop: Optional[Dropout] = None, grad_out2: Optional[Tensor] = None):
     """Gradients of add_layernorm (bf_add_layernorm_bwd): returns (dz, dgamma, dbeta); dz is the gradient of both x
     and residual, dgamma / dbeta are fp32.  With `drop` (bf_add_layernorm_dropout_bwd) returns (dz, dgamma, dbeta, dx):
     dz is the residual's gradient, dx = dz o keep / (1 - p) the dropped input's.  grad_out2: the gradient of the
@@ -798,27 +798,6 @@ def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor,
     lib = _C.lib()
     need = lib.bf_add_layernorm_bwd_workspace_bytes(x2.shape[0], N)
     ws = workspace(x.device, need)
-    if colsum_samples > 0 and x2.shape[0] % colsum_samples == 0:
-        # the per-sample column sums of the gradient handed to x ride along (bf_add_layernorm_bwd_colsum): attached to that
-        # gradient as `_bf_colsum`, where the backward of the dense layer in front finds its bias gradient ready
-        h2 = None
-        if grad_out2 is not None:
-            h2 = grad_out2.reshape(-1, N)
-            h2 = (h2 if h2.dtype == x.dtype else h2.to(x.dtype)).contiguous()
-        dropping = drop is not None and drop.p > 0.0
-        dx = torch.empty_like(x2) if dropping else None
-        colsum = torch.empty((colsum_samples, N), dtype=torch.float32, device=x.device)
-        _C.check(lib.bf_add_layernorm_bwd_colsum(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
-                                                 _TORCH2BF[gamma.dtype], g2.data_ptr(), h2.data_ptr() if h2 is not None else None,
-                                                 dz.data_ptr(), dx.data_ptr() if dropping else None, dgamma.data_ptr(),
-                                                 dbeta.data_ptr(), ws.data_ptr(), ws.numel(), _TORCH2BF[x.dtype], x2.shape[0], N,
-                                                 float(eps), drop.p if dropping else 0.0, drop.seed if dropping else 0,
-                                                 drop.call if dropping else 0, drop.site if dropping else 0,
-                                                 drop.first_group(x2.shape[0], N // 8) if dropping else 0, colsum_samples,
-                                                 colsum.data_ptr(), _stream_ptr()), "bf_add_layernorm_bwd_colsum")
-        gx = dx.view(x.shape) if dropping else dz.view(x.shape)
-        offer_colsum(gx, colsum)
-        return (dz.view(x.shape), dgamma, dbeta, gx) if dropping else (gx, dgamma, dbeta)
     if grad_out2 is not None:
         h2 = grad_out2.reshape(-1, N)
         h2 = (h2 if h2.dtype == x.dtype else h2.to(x.dtype)).contiguous()
@@ -864,11 +843,8 @@ class AddLayerNormFn(torch.autograd.Function):
     are summed by autograd as always."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps, drop=None, twin=False, cs_samples=0):
+    def forward(ctx, x, residual, gamma, beta, eps, drop=None, twin=False):
         ctx.eps, ctx.has_res = eps, residual is not None
-        # cs_samples = S when x is the output of a Bayesian dense layer with a bias inside an S-sample forward: the backward
-        # then also leaves the per-sample column sums of x's gradient — that layer's bias gradient (add_layernorm_backward)
-        ctx.cs_samples = 0 if _NO_COLSUM_FOLD else int(cs_samples)
         ctx.drop = drop if (drop is not None and drop.p > 0.0) else None
         ctx.save_for_backward(x, residual if residual is not None else x, gamma)
         y = add_layernorm(x, residual, gamma, beta, eps, ctx.drop)
@@ -883,21 +859,21 @@ class AddLayerNormFn(torch.autograd.Function):
         if grad_out is None:
             grad_out, grad_twin = grad_twin, None
         if grad_out is None:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         dx = None
         if ctx.drop is not None:  # the mask is regenerated from (seed, call, site): nothing was stored
             dz, dgamma, dbeta, dx = add_layernorm_backward(x, residual if ctx.has_res else None, gamma, grad_out, ctx.eps, ctx.drop,
-                                                           grad_out2=grad_twin, colsum_samples=ctx.cs_samples)
+                                                           grad_out2=grad_twin)
         else:
             dz, dgamma, dbeta = add_layernorm_backward(x, residual if ctx.has_res else None, gamma, grad_out, ctx.eps,
-                                                       grad_out2=grad_twin, colsum_samples=ctx.cs_samples)
+                                                       grad_out2=grad_twin)
         need = ctx.needs_input_grad
         if gamma.dtype != torch.float32 and (need[2] or need[3]):
             # dgamma and dbeta are the two rows of one fp32 buffer: cast them with one launch
             both = dgamma._base.to(gamma.dtype) if dgamma._base is not None else torch.stack((dgamma, dbeta)).to(gamma.dtype)
             dgamma, dbeta = both[0], both[1]
         return ((dx if dx is not None else dz) if need[0] else None, dz if (ctx.has_res and need[1]) else None,
-                dgamma if need[2] else None, dbeta if need[3] else None, None, None, None, None)
+                dgamma if need[2] else None, dbeta if need[3] else None, None, None, None)
 
 
 def layernorm_supported(x: Tensor, residual: Optional[Tensor], ln) -> bool:

@@ -29,7 +29,7 @@ extern "C" {
                                tensors' effective prior kinds, bf_sample_logprob_table takes the launch's set of them;
                                4: bf_add_layernorm_bwd_sum; 5: bf_prior_t carries the device addresses its constants were
                                read from (re-checked by the kernels), bf_stale_counter; bf_linear_bwd takes d_dy_colsum,
-                               bf_add_layernorm_bwd_colsum, bf_attention_bwd_colsum */
+                               bf_attention_bwd_colsum; the dropout entries take first_group */
 
 /* element types of activations / sampled weights */
 enum { BF_DT_F32 = 0, BF_DT_BF16 = 1, BF_DT_F16 = 2 };
@@ -234,7 +234,7 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
  * act(y) and d_act_pre the forward's pre-activation y ([S][M][N] of `dtype`, 16-bit, N % 8 == 0): dy = d_dy * act'(y)
  * is formed first, in one pass that also yields the bias gradient's column sums.  act = BF_ACT_NONE: d_act_pre unused.
  * d_dy_colsum (nullable): [S][N] fp32 column sums of d_dy per sample, when the kernel that PRODUCED d_dy left them
- * (bf_add_layernorm_bwd_colsum, bf_attention_bwd_colsum): the bias gradient then needs no pass over d_dy of its own. */
+ * (bf_attention_bwd_colsum): the bias gradient then needs no pass over d_dy of its own. */
 size_t bf_linear_bwd_workspace_bytes(int S, int M, int N, int K, int has_bias, int dtype, int act);
 int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, int dtype, const bf_tensor_t* weight,
                   const bf_tensor_t* bias, void* d_dx, float* d_dmu_w, float* d_drho_w, float* d_dmu_b,
@@ -379,15 +379,6 @@ int bf_add_layernorm_bwd_sum(const void* d_x, const void* d_residual, const void
                              size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
                              uint32_t call, uint32_t site, uint64_t first_group, void* stream);
 
-/* bf_add_layernorm_bwd_sum that also leaves the per-sample COLUMN SUMS of the gradient it hands to the layer in front of
- * it — d_dx with dropout, d_dz without: d_colsum [samples][N] fp32, the `rows` being `samples` equal slabs.  In
- * LayerNorm(dropout(dense(h)) + input) that gradient is the dense layer's d_dy, and its column sums are the dense layer's
- * bias gradient per Monte-Carlo sample (/root/reference/examples/bert_glue.py:239: loss.backward() through
- * BertSelfOutput / BertOutput): bf_linear_bwd takes them as d_dy_colsum instead of reading d_dy once more. */
-int bf_add_layernorm_bwd_colsum(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,
-                                const void* d_dy2, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
-                                size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
-                                uint32_t call, uint32_t site, uint64_t first_group, int samples, float* d_colsum, void* stream);
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
  * While enabled, every sampling launch (kind BF_PROF_SAMPLE) and every GEMM launch (BF_PROF_GEMM) made through
