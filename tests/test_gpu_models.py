@@ -920,3 +920,32 @@ def test_fused_residual_blocks_pass_the_alias_along():
     # (the softmax does not depend on the key bias: that gradient is zero in exact arithmetic, rounding noise in any other)
     bad = {n: round(v, 6) for n, v in worst.items() if v > 1e-3 and ".key.bias" not in n}
     assert not bad, bad
+
+
+def test_bench_line_carries_the_contract_keys():
+    """bench.py prints ONE JSON line with the driver's keys, a roofline object and a cpu_baseline object (small workload, no PMC
+    passes: the schema, not the numbers)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "linear768", "--steps", "3", "--warmup", "1",
+                        "--no-traffic"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert d["roofline"]["bound"] in ("hbm", "mfma", "latency") and d["roofline"]["traffic"] is None
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] == "port" and d["value"] > 0
+    assert "HSA_ENABLE_IPC_MODE_LEGACY" in d["config"]["env"]
