@@ -64,6 +64,9 @@ class KernelLayer(Module):
         if ctx is not None:
             base, S, slot = ctx.sample_base, ctx.S, ctx.slot(self)
         else:
+            from ... import ops
+
+            ops.refresh_stale_epoch()   # a bare layer call (no bnn.Model around, which does this for its layers)
             base, S, slot = bfr.reserve_samples(1), 1, None
         if slot is None:
             if self._lp_own is None or self._lp_own.shape[0] != S or self._lp_own.device != device:

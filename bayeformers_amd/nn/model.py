@@ -130,14 +130,11 @@ class Model(Module):
             return super(Model, self).__call__(*args, **kwargs)
         S = self._mc_samples
         layers = self.fused_children()
-        if layers and ops.stale_priors_seen():
-            # a kernel of an earlier forward found a prior's baked constants different from the tensors they were read
-            # from (an in-place edit through .data: no version counter moved).  That forward's log-prior is NaN; from
-            # this one on every cached copy is dropped and the priors are described again.
-            ops.invalidate_caches(self)
-            warnings.warn("bayeformers_amd: a prior's tensors were edited in place through `.data` after a forward had "
-                          "cached their state; the log_prior of the forward(s) since the edit is NaN — the caches are "
-                          "dropped now (call bayeformers_amd.invalidate_caches(model) after such an edit)")
+        if layers:
+            # a kernel of an earlier forward may have found a prior's baked constants different from the tensors they were read
+            # from (an in-place edit through .data: no version counter moved).  That forward's log-prior is NaN; from this
+            # one on every cached copy is dropped and the priors are described again.
+            ops.refresh_stale_epoch()
         ops._COLSUM_OFFERS.clear()  # (column sums a backward pass offered and nobody took)
         slots = {}
         if layers:
@@ -157,7 +154,8 @@ class Model(Module):
                 shared = tuple(sorted({id(l._shared_input): l._shared_input for l in pl
                                        if l._shared_input is not None}.values(), key=lambda t: t[0].layer_id))
                 key = SamplePlan.make_key(pl, S, cdt, shared)
-                if self._plan is None or self._plan.key != key or not self._plan.alias_valid():
+                if (self._plan is None or self._plan.key != key or not self._plan.alias_valid()
+                        or self._plan.epoch != bfr.STATE.stale_epoch):
                     self._plan = SamplePlan(pl, S, cdt, layers[0].weight.mu.device, index=[i for i, _ in planned],
                                             shared=shared)
                 plan = self._plan

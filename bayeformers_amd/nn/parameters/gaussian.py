@@ -98,7 +98,7 @@ class ScaledGaussianMixture(Parameter):
         if not self.pi.is_cuda:
             return float(self.pi), float(self.sigma1), float(self.sigma2)
         key = (self.pi._version, self.sigma1._version, self.sigma2._version,
-               self.pi.data_ptr(), self.sigma1.data_ptr(), self.sigma2.data_ptr())
+               self.pi.data_ptr(), self.sigma1.data_ptr(), self.sigma2.data_ptr(), _bfr.STATE.stale_epoch)
         if self._consts is None or self._consts[0] != key:
             self._consts = (key, (float(self.pi), float(self.sigma1), float(self.sigma2)))
         return self._consts[1]

@@ -89,7 +89,7 @@ def prior_alias(gaussian, prior) -> Optional[float]:
     mu, pmu, prho = gaussian.mu, prior.mu, prior.rho
     if _NO_ALIAS or mu.requires_grad or pmu.shape != mu.shape or prho.shape != mu.shape or pmu.dtype != torch.float32:
         return None
-    state = (mu.data_ptr(), mu._version, pmu.data_ptr(), pmu._version, prho.data_ptr(), prho._version)
+    state = (mu.data_ptr(), mu._version, pmu.data_ptr(), pmu._version, prho.data_ptr(), prho._version, bfr.STATE.stale_epoch)
     hit = getattr(prior, "_bf_alias", None)
     if hit is not None and hit[0] == state:
         return hit[1]
@@ -104,20 +104,30 @@ def prior_alias(gaussian, prior) -> Optional[float]:
     return sigma_p
 
 
-_STALE_SEEN = [None]
+_WARNED_EPOCH = [0]
 
 
-def stale_priors_seen() -> bool:
-    """True once per change of the library's stale-prior counter (bf_stale_counter): some kernel found a prior's baked
-    constants — an asserted MOPED alias, a mixture's pi / sigma1 / sigma2 — different from the tensors they were read from
-    (an in-place edit through `.data`).  Reads a word of pinned host memory: no synchronisation."""
+def stale_epoch() -> int:
+    """The library's stale-prior counter (bf_stale_counter) as of the running forward: some kernel bumps it when it finds a
+    prior's baked constants — an asserted MOPED alias, a mixture's pi / sigma1 / sigma2 — different from the tensors they
+    were read from (an in-place edit through `.data`).  Every cached copy of prior state (`prior_alias`,
+    `ScaledGaussianMixture.constants`, the sampling plan) remembers the epoch it was made in and is void in a later one —
+    whichever module, model or bare layer it belongs to.  `refresh_stale_epoch()` reads the counter (a word of pinned host
+    memory: no synchronisation) once per forward."""
+    return bfr.STATE.stale_epoch
+
+
+def refresh_stale_epoch() -> None:
     now = _C.stale_counter()
-    if _STALE_SEEN[0] is None:
-        _STALE_SEEN[0] = now
-    if now != _STALE_SEEN[0]:
-        _STALE_SEEN[0] = now
-        return True
-    return False
+    if now != bfr.STATE.stale_epoch:
+        bfr.STATE.stale_epoch = now
+        if now != _WARNED_EPOCH[0]:
+            import warnings
+
+            _WARNED_EPOCH[0] = now
+            warnings.warn("bayeformers_amd: a prior's tensors were edited in place through `.data` after a forward had "
+                          "cached their state; the log_prior of the forward(s) since the edit is NaN — every cached copy "
+                          "is void from now on (call bayeformers_amd.invalidate_caches(model) right after such an edit)")
 
 
 def invalidate_caches(module) -> None:

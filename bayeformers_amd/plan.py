@@ -57,6 +57,7 @@ class SamplePlan:
         from .nn.parameters.base import NoneParameter
 
         self.S, self.cdt, self.device = S, cdt, device
+        self.epoch = bfr.STATE.stale_epoch  # the table bakes prior constants in: void once a kernel reported a stale one
         self.layers = layers
         self.index = list(index) if index is not None else list(range(len(layers)))
         self.key = self.make_key(layers, S, cdt, shared)

@@ -34,6 +34,7 @@ class _State:
         self.kl_gradient = False    # opt-in Bayes-by-Backprop gradient of the KL terms (the reference has none)
         self.next_dropout_call = 0  # dropout contract (csrc/bf_philox.h): one `call` number per forward
         self.next_dropout_site = 1  # ... and one `site` number per module that applies a dropout
+        self.stale_epoch = 0        # the library's stale-prior counter as of the running forward (ops.refresh_stale_epoch)
 
 
 STATE = _State()

@@ -244,7 +244,7 @@ def _graphed(model: Model, inputs, samples: int, select, group):
     cache = _GRAPHED.get(model)
     if cache is None:
         cache = _GRAPHED[model] = []
-        weakref.finalize(model, _close_all, cache)
+        weakref.finalize(model, _close_all, cache).atexit = False  # (not at interpreter exit: the HIP runtime may be gone)
     key = (GraphedSampler._sig(inputs), int(samples), _select_key(select), group)
     sampler = None
     for i, (k, sm) in enumerate(cache):
@@ -333,7 +333,7 @@ class GraphedSampler:
         from . import random as bfr
 
         plan = getattr(self.model, "_plan", None)
-        return bfr.STATE.seed, bfr.get_compute_dtype(), plan, (plan.key if plan is not None else None)
+        return bfr.STATE.seed, bfr.get_compute_dtype(), plan, (plan.key if plan is not None else None), bfr.STATE.stale_epoch
 
     def _capture(self) -> None:
         from . import random as bfr
@@ -354,9 +354,13 @@ class GraphedSampler:
         self.captures += 1
 
     def _still_valid(self) -> bool:
-        seed, cdt, plan, key = self._baked_state
+        from . import ops
+
+        ops.refresh_stale_epoch()  # (a replay whose kernels found a stale prior bumped the library's counter)
+        seed, cdt, plan, key, epoch = self._baked_state
         now = self._baked()
-        return now[0] == seed and now[1] == cdt and now[2] is plan and now[3] == key and (plan is None or plan.alias_valid())
+        return (now[0] == seed and now[1] == cdt and now[2] is plan and now[3] == key and now[4] == epoch
+                and (plan is None or plan.alias_valid()))
 
     # ------------------------------------------------------------------------------------------------------------
     @staticmethod
