@@ -162,7 +162,13 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][k
     bool all_full = true;
 #pragma unroll
     for (int j = 0; j < G; ++j) {
-        e0[j] = (((unsigned long long)a.rel_block * G + j) * kThreads + tid) * 4;
+#ifndef BF_SAMPLE_ADJ
+#define BF_SAMPLE_ADJ 0  // experiment (round 5): a thread's G groups are ADJACENT (8 consecutive scalars at G = 2), so that a sample's
+// bf16 weights leave as ONE 16-byte store per thread — half the store instructions — while the 16-byte parameter loads of a
+// wave interleave (32-byte lane stride).  profiles/r5n_sampling_adjacent_groups_ab.txt
+#endif
+        e0[j] = BF_SAMPLE_ADJ ? (((unsigned long long)a.rel_block * kThreads + tid) * G + j) * 4
+                              : (((unsigned long long)a.rel_block * G + j) * kThreads + tid) * 4;
         nvalid[j] = e0[j] >= a.n ? 0 : (a.n - e0[j] >= 4 ? 4 : (int)(a.n - e0[j]));
         all_full = all_full && nvalid[j] == 4;
 #pragma unroll
@@ -228,6 +234,9 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][k
             inv[j] = bf_philox_prepare((uint32_t)(e0[j] >> 2), (uint32_t)(e0[j] >> 34), a.stream, a.k0, a.k1);
         for (int s = s_begin; s < s_end; ++s) {
             f32x2_t q2 = {0.f, 0.f}, p2 = {0.f, 0.f};
+#if BF_SAMPLE_ADJ
+            f32x4_t wlo = {0.f, 0.f, 0.f, 0.f};
+#endif
 #ifdef BF_SAMPLE_HALF_PHILOX
             bf_u32x4 xprev = {0u, 0u, 0u, 0u};
 #endif
@@ -278,6 +287,15 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][k
                     p2 = __builtin_elementwise_fma(d01, d01, p2);
                     p2 = __builtin_elementwise_fma(d23, d23, p2);
                 }
+#if BF_SAMPLE_ADJ
+                static_assert(G == 2, "the adjacent-group store pairs two groups");
+                if (outp && out_dt == BF_DT_BF16) {  // both groups of the thread in one 16-byte store
+                    if (j == 0) { wlo = f32x4_t{w01[0], w01[1], w23[0], w23[1]}; continue; }
+                    const f32x8_t w8 = {wlo[0], wlo[1], wlo[2], wlo[3], w01[0], w01[1], w23[0], w23[1]};
+                    *reinterpret_cast<bf16x8_t*>(outp + ((unsigned long long)s * a.n + e0[0]) * 2) = __builtin_convertvector(w8, bf16x8_t);
+                    continue;
+                }
+#endif
                 if (outp) {
                     const unsigned long long idx = (unsigned long long)s * a.n + e0[j];
                     const f32x4_t w4 = {w01[0], w01[1], w23[0], w23[1]};
