@@ -48,9 +48,9 @@ class _LinearFn(torch.autograd.Function):
     log-prob scalars detached (they carry no gradient in the reference, layers/linear.py:99-102)."""
 
     @staticmethod
-    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, layer, S, seed, base, lp_out):
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, layer, S, seed, base, lp_out, need_grad=True):
         ctx.layer, ctx.S, ctx.seed, ctx.base = layer, S, seed, base
-        ctx.counter = bfr.counter_snapshot()
+        ctx.counter = bfr.counter_snapshot(need_grad)
         ctx.cdt = layer.compute_dtype or bfr.get_compute_dtype()
         ctx.save_for_backward(x)
         return ops.linear_forward(layer, x, S, seed, base, lp_out)
@@ -58,25 +58,26 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         dx, dmu_w, drho_w, dmu_b, drho_b = _backward(ctx, grad)
-        return dx, dmu_w, drho_w, dmu_b, drho_b, None, None, None, None, None
+        return dx, dmu_w, drho_w, dmu_b, drho_b, None, None, None, None, None, None
 
 
 class _PlannedLinearFn(torch.autograd.Function):
     """Forward of a layer whose weights were sampled by the model's cross-layer plan: only the MFMA GEMM is left."""
 
     @staticmethod
-    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, w_s, b_s, layer, S, seed, base, act, keep_pre=False):
+    def forward(ctx, x, mu_w, rho_w, mu_b, rho_b, w_s, b_s, layer, S, seed, base, act, need_grad=False):
         ctx.layer, ctx.S, ctx.seed, ctx.base = layer, S, seed, base
         fwd = bfr.STATE.ctx
         if fwd is not None and fwd.plan is not None and id(layer) in fwd.plan.group_of:
             ctx.kept = (fwd.plan, fwd.plan.group_of[id(layer)], fwd.token, w_s)  # see _backward
-        ctx.counter = bfr.counter_snapshot()
+        # need_grad is decided by the caller from torch.is_grad_enabled(): inside forward() grad mode is always off and
+        # needs_input_grad reflects requires_grad even under no_grad — an inference step must pay neither the copy of
+        # the device counter nor the second store below
+        ctx.counter = bfr.counter_snapshot(need_grad)
         ctx.cdt = w_s.dtype
         # an activation fused into the GEMM while gradients are recorded: the launch also stores the pre-activation,
         # and the backward folds act' (and the bias gradient's column sums) into one pass over the output gradient
-        # (keep_pre is decided by the caller from torch.is_grad_enabled(): inside forward() grad mode is always off and
-        # needs_input_grad reflects requires_grad even under no_grad — an inference step must not pay the second store)
-        if act and keep_pre:
+        if act and need_grad:
             y, pre = ops.planned_linear_forward(x, w_s, b_s, S, layer.out_features, layer.in_features, act, True)
             ctx.act = act
             ctx.save_for_backward(x, pre)
@@ -220,12 +221,13 @@ class Linear(KernelLayer):
             fused = want_act and (not need_grad or (x2.dtype != torch.float32 and self.out_features % 8 == 0
                                                     and w_s.dtype == x2.dtype))
             y = _PlannedLinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, w_s, b_s, self, S,
-                                       bfr.STATE.seed, base, 1 if fused else 0, fused and need_grad)
+                                       bfr.STATE.seed, base, 1 if fused else 0, need_grad)
             if want_act and not fused:
                 y = torch.nn.functional.gelu(y)
             self._lp_view, self._lp_dirty = slot, True
             return y.view(*input.shape[:-1], self.out_features)
-        y = _LinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, self, S, bfr.STATE.seed, base, slot)
+        y = _LinearFn.apply(x2, self.weight.mu, self.weight.rho, mu_b, rho_b, self, S, bfr.STATE.seed, base, slot,
+                            need_grad)
         if want_act:
             y = torch.nn.functional.gelu(y)
         self._end(ctx, slot)

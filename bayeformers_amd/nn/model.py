@@ -46,7 +46,11 @@ class _ForwardContext:
         self.plan, self.lp_buf = plan, lp_buf
         self.token = next(_TOKENS)
         self.shared_out = {}  # id(first layer of a stacked run) -> (input identity, [L, S, M, N] outputs)
-        self.counter = bfr.counter_snapshot()  # device-counter mode: the counter value this forward's kernels added
+        # device-counter mode: the counter value this forward's kernels added — what `replay` needs, i.e. only a forward
+        # that records gradients (the copy is a kernel launch)
+        self.counter = bfr.counter_snapshot(torch.is_grad_enabled())
+        if self.counter is not None:  # ... and the layers' autograd nodes share it (counter_snapshot's per-forward cache)
+            self._counter_snap = (bfr.STATE.device_counter, bfr.STATE.counter_moves, self.counter)
         self.graph_tasks = set()  # ids of the backward passes that reached this forward's outputs (bfr.remember_context)
         # the `call` of every dropout applied inside this forward; `shard_start` (the first global sample of this process's
         # shard within the step) is where the kernels start numbering their dropout groups (ops.Dropout.first_group): a

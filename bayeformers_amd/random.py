@@ -7,6 +7,8 @@ and the next unused Monte-Carlo sample index.  Every forward of a bnn.Model (or 
 consecutive sample indices; all layers inside one forward share them, which is what makes results independent
 of kernel tiling, of S-batching and of how samples are sharded over GPUs.
 """
+import os
+
 import torch
 
 DEFAULT_SEED = 0x5EED
@@ -35,6 +37,7 @@ class _State:
         self.next_dropout_call = 0  # dropout contract (csrc/bf_philox.h): one `call` number per forward
         self.next_dropout_site = 1  # ... and one `site` number per module that applies a dropout
         self.stale_epoch = 0        # the library's stale-prior counter as of the running forward (ops.refresh_stale_epoch)
+        self.counter_moves = 0      # host-side count of the writes to device_counter (counter_snapshot's cache key)
 
 
 STATE = _State()
@@ -48,6 +51,7 @@ def manual_seed(seed: int, next_sample: int = 0) -> None:
     if STATE.device_counter is not None:
         v = STATE.next_sample if STATE.next_sample < 2 ** 31 else STATE.next_sample - 2 ** 32
         STATE.device_counter.fill_(v)
+        STATE.counter_moves += 1
 
 
 def get_state():
@@ -70,6 +74,7 @@ def commit_samples(n: int) -> None:
     """Call after the kernels of a forward are enqueued: moves a device-resident counter past the n indices used."""
     if STATE.device_counter is not None:
         STATE.device_counter.add_(int(n))
+        STATE.counter_moves += 1
 
 
 def use_device_counter(enable: bool = True, device="cuda") -> None:
@@ -221,9 +226,26 @@ def set_kl_gradient(enable: bool = True) -> None:
     STATE.kl_gradient = bool(enable)
 
 
-def counter_snapshot():
-    """In device-counter mode: a copy of the counter as the forward saw it (backward regenerates the same eps)."""
-    return STATE.device_counter.clone() if STATE.device_counter is not None else None
+_AB_OLD_SNAPSHOT = os.environ.get("BF_AB_OLD_SNAPSHOT", "0") == "1"
+
+
+def counter_snapshot(needed: bool = True):
+    """In device-counter mode: a copy of the counter as the forward saw it (backward regenerates the same eps).
+    `needed` False — no gradient will be asked of this forward — gives None: the copy is a 4 us kernel, and every
+    Bayesian layer of a BERT-base forward used to launch one.  Inside a bnn.Model forward the layers share ONE copy for
+    as long as nothing moved the counter (commit_samples / manual_seed count their moves in STATE.counter_moves)."""
+    counter = STATE.device_counter
+    if _AB_OLD_SNAPSHOT:  # tools/r5r_ab.sh: one copy per call, as before round 5
+        return counter.clone() if counter is not None else None
+    if counter is None or not needed:
+        return None
+    fwd = STATE.ctx
+    if fwd is None:
+        return counter.clone()
+    snap = getattr(fwd, "_counter_snap", None)
+    if snap is None or snap[0] is not counter or snap[1] != STATE.counter_moves:
+        snap = fwd._counter_snap = (counter, STATE.counter_moves, counter.clone())
+    return snap[2]
 
 
 class counter_override:

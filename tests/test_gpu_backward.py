@@ -611,6 +611,55 @@ def test_checkpointed_blocks_recompute_the_forwards_epsilon(device_counter):
         assert (g0[n] - g1[n]).abs().max().item() <= 1e-6 * scale, n
 
 
+def test_device_counter_is_copied_once_per_forward_and_not_at_all_without_gradients(monkeypatch):
+    """In device-counter mode every Bayesian layer's autograd node keeps the counter value its forward saw.  That used to
+    be one 4 us copy kernel per layer and forward — 36 of them in a BERT-base inference step, which needs none.  A forward
+    under no_grad makes no copy; a forward that records gradients makes ONE, shared by its layers; the gradients are those
+    of the host-counter run."""
+    from bayeformers_amd import random as bfr
+
+    d, S, B = 128, 3, 80
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(d, 2 * d), torch.nn.GELU(), torch.nn.Linear(2 * d, d), torch.nn.Linear(d, 4))
+    bmodel = bf.to_bayesian(net, delta=0.05).cuda()
+    x = torch.randn(B, d, device="cuda")
+    copies = []
+    real = bfr.counter_snapshot
+
+    def counting(needed=True):
+        r = real(needed)
+        if r is not None:
+            copies.append(r)
+        return r
+
+    monkeypatch.setattr(bfr, "counter_snapshot", counting)
+
+    def run(grad):
+        for p in bmodel.parameters():
+            p.grad = None
+        bf.manual_seed(SEED, next_sample=5)
+        with torch.set_grad_enabled(grad), bmodel.monte_carlo(S):
+            out = bmodel(x.repeat(S, 1))
+        if grad:
+            (out ** 2).mean().backward()
+        return out.detach().clone(), {n: p.grad.clone() for n, p in bmodel.named_parameters() if p.grad is not None}
+
+    out_host, g_host = run(True)
+    assert not copies  # host-side counter: nothing to copy
+    bf.use_device_counter(True)
+    try:
+        out_ng, _ = run(False)
+        assert not copies, "a forward under no_grad copied the device counter"
+        out_dev, g_dev = run(True)
+        assert len(copies) >= 3 and len({id(c) for c in copies}) == 1, "the layers of one forward share one copy"
+    finally:
+        bf.use_device_counter(False)
+    assert torch.equal(out_host, out_ng) and torch.equal(out_host, out_dev)
+    assert g_host.keys() == g_dev.keys() and len(g_host) >= 6
+    for n in g_host:
+        assert torch.equal(g_host[n], g_dev[n]), n
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # Round 5: the bias gradients' column sums of the query / key / value layers ride in the kernel that PRODUCES their output
 # gradients (the one-tile attention backward) instead of three passes over those gradients.  (The same inside the residual +
