@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r5q; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -o t -- python3 bench.py --steps 4 --warmup 2 --no-traffic --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --output-format csv -d $OUT/prof -o t -- python3 bench.py ${1:+--workload $1} --steps 4 --warmup 2 --no-traffic --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
 python3 - <<'PY'
 import csv, glob, os
 out=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/r5q'
