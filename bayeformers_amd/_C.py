@@ -66,6 +66,8 @@ SYMBOLS = {
     "bf_gemm_tn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "bf_gemm_prepare": (_i, [_i, _i, _i, _i, _vp]),
     "bf_gemm_schedule": (_sz, [_i, _i, _i, _i, _i, _vp, _sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "bf_gemm_schedule_policy": (_sz, [_i, _i, _i, _i, _i, _i, _vp, _sz, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "bf_gemm_schedule_fetch_rows": (ctypes.c_int64, [_vp, _i, _i]),
     "bf_linear_fwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "bf_linear_fwd": (_i, [_vp, _i, _i64, _tp, _tp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u32, _vp, _vp, _sz, _vp]),
     "bf_linear_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),

@@ -22,20 +22,11 @@
 
 namespace {
 
-// BF_ATTN_OUT_STORES: how the attention output rows (the x of the attention-out GEMM that runs next) are written — 0 plain
-// (product), 1 nontemporal, 2 sc1, 3 sc0 sc1 (write-through).  Measured in the BERT-base step, one box, interleaved runs
-// (profiles/r5e_attention_store_policy_ab.txt): no policy beats plain stores.
-#ifndef BF_ATTN_OUT_STORES
-#define BF_ATTN_OUT_STORES 0
-#endif
+// The attention output rows (the x of the attention-out GEMM that runs next) leave through plain stores: nontemporal, sc1 and
+// sc0 sc1 (write-through) stores were measured in the BERT-base step, one box, interleaved runs
+// (profiles/r5e_gemm_variants_in_step_ab.txt): no policy beats plain stores.
 template <typename V>
-__device__ __forceinline__ void attn_st8(V* p, V v) {
-    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-    if (BF_ATTN_OUT_STORES == 1) __builtin_nontemporal_store(v, p);
-    else if (BF_ATTN_OUT_STORES == 2) asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u32x2, v)) : "memory");
-    else if (BF_ATTN_OUT_STORES == 3) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u32x2, v)) : "memory");
-    else *p = v;
-}
+__device__ __forceinline__ void attn_st8(V* p, V v) { *p = v; }
 
 
 constexpr int HD = 64;          // head size
@@ -92,13 +83,11 @@ struct AttnParams {
     uint32_t* keep_bits;  // [B][H][T][T / 32]
 };
 
+// 3 workgroups per CU, for the DROP instantiation too: at 3 it spills 12 registers (168 VGPRs + 48 B of scratch), at 2 it does
+// not (178 VGPRs); measured back to back, same box: 69.9 vs 72.0 us at the BERT-base shape, 278 vs 304 us at 160 x 16 heads x
+// 384 tokens — the third workgroup is worth more than the spills cost.
 template <typename T, bool DROP = false>
-#ifndef BF_ATTN_DROP_WGS
-#define BF_ATTN_DROP_WGS 3  // workgroups per CU the DROP instantiation is compiled for.  At 3 it spills 12 registers (168 VGPRs + 48 B
-// of scratch), at 2 it does not (178 VGPRs); measured back to back, same box: 69.9 vs 72.0 us at the BERT-base shape, 278 vs
-// 304 us at 160 x 16 heads x 384 tokens — the third workgroup is worth more than the spills cost.
-#endif
-__global__ __launch_bounds__(256, DROP ? BF_ATTN_DROP_WGS : 3) void attention_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams p) {
     using frag = typename Mfma<T>::frag;
     using half4 = typename Mfma<T>::half4;
     __shared__ __attribute__((aligned(16))) char smem[K_BYTES + V_BYTES + TKEY * 4];

@@ -25,9 +25,6 @@ int gemm_variant() {
 #ifdef BF_DEV
     const char* v = getenv("BF_GEMM_VARIANT");
     if (v) return atoi(v);
-#ifdef BF_R1_DEFAULT
-    return 1;  // A/B library: the round-1 kernel unless told otherwise
-#endif
 #endif
     return 2;
 }

@@ -547,13 +547,44 @@ unsigned xcd_remap(unsigned b, unsigned nwg) {
     return base + (b >> 3);
 }
 
+// Modelled fabric fetch of a schedule, in rows of K elements: every XCD's workgroups (block b runs on XCD b % 8, observed)
+// run their j-th tiles together and in k-lockstep, so a panel shared by several of them is fetched into the XCD's L2 once
+// per round — and nothing survives to the next round: the k-slices a round touches (a + b panels for a x b tiles, 12 x
+// 393 KB at K = 768) exceed the 4 MiB L2 under LRU.  Validated against TCC_EA0_RDREQ on the four BERT-base launches
+// (308 / 107 / 386 / 427 MB modelled, 308 / 108 / 384 / 428 MB counted: profiles/r6b_sched_l2_model.md), independent of
+// the modelled L2 size between 2 and 4 MiB.  tools/sched_l2_sim.py is the same model with an explicit LRU.
+long long schedule_fetch_rows(const std::vector<int4>& table, int rounds, int grid) {
+    long long rows = 0;
+    std::vector<long long> seen;
+    for (int xcd = 0; xcd < 8; ++xcd)
+        for (int j = 0; j < rounds; ++j) {
+            seen.clear();
+            for (int b = xcd; b < grid; b += 8) {
+                const int4 d = table[(size_t)j * grid + b];
+                const int h = d.z >> 24;
+                if (!h) continue;
+                seen.push_back(((long long)d.x << 32) | (unsigned)(d.z & 0xFFFFFF) | (1ll << 62));  // W panel (pair, n-tile)
+                for (int u = 0; u < h; ++u) seen.push_back(((long long)d.y << 32) | (unsigned)(d.w / UNIT + u));  // x unit
+            }
+            std::sort(seen.begin(), seen.end());
+            seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+            for (long long v : seen) rows += (v >> 62) ? TN : UNIT;
+        }
+    return rows;
+}
+
 // Cut S * layers * tiles_n columns of ceil(M / 32) units into tiles of 1..8 units and deal them to at most n_cu
 // workgroups.  Returns the table ([rounds][grid] int4) and the launch grid.
 // policy bit 0: workgroups at odd logical positions run their tiles in reverse order (short tiles first), which
 // spreads the workgroups' epilogue store bursts over time instead of all of them ending a tile in the same
 // microsecond.
-void build_schedule(int S, int layers, int tiles_n, int M, int n_cu, int policy, std::vector<int4>& table, int& rounds,
-                    int& grid) {
+// policy bit 12 (round 6): the columns that get one tile more than the others (the Bresenham remainder of the target tile
+// count) are the FIRST columns instead of being spread evenly: columns of one sample then share their row cuts, so the
+// tiles of a band of x rows that run together on an XCD fetch the same units (modelled fetch of the BERT-base FFN-up
+// launch 3.50 -> 2.90 x its operands, BERT-large Q/K/V 4.07 -> 3.33).
+// `cg` = columns per group of the locality order (policy bit 3).
+void build_schedule_cg(int S, int layers, int tiles_n, int M, int n_cu, int policy, int cg, std::vector<int4>& table,
+                       int& rounds, int& grid) {
     const int hmax = ((policy >> 4) & 15) ? std::min(HMAX, std::max(HMIN, (policy >> 4) & 15)) : HMAX;
     const int C = S * layers * tiles_n;
     const int Hc = (M + UNIT - 1) / UNIT;
@@ -566,8 +597,9 @@ void build_schedule(int S, int layers, int tiles_n, int M, int n_cu, int policy,
         const long long target = T * n_cu;
         tiles.clear();
         for (int c = 0; c < C; ++c) {
-            // Bresenham spread of the target tile count over the columns
+            // spread of the target tile count over the columns: Bresenham, or (bit 12) the remainder on the first columns
             long long n = (target * (c + 1)) / C - (target * c) / C;
+            if (policy & 0x1000) n = target / C + (c < target % C ? 1 : 0);
             n = std::min<long long>(std::max<long long>(n, n_min), n_max);
             if (policy & 2) n = n_min;  // fixed full-height tiles (the round-1 decomposition)
             const int q = Hc / (int)n, r = Hc % (int)n;
@@ -584,14 +616,11 @@ void build_schedule(int S, int layers, int tiles_n, int M, int n_cu, int policy,
                 t.h = hh;
                 // (sample, band of 1024 rows, column, row): the 32 concurrent tiles of an XCD share few panels
                 t.key = (((long long)xs * 4096 + t.m0 / 1024) * 4096 + cn) * 65536 + (t.m0 / UNIT);
-                // policy bit 8: (sample, group of 4 columns, 256-row band, column) — an XCD that walks this order keeps
-                // four W panels in its L2 while the x bands stream past them (groups of 3 / 4 / 6 / 9 / 12 columns measured
-                // in the BERT-base step on one box: GEMM 7.13 / 7.10 / 7.20 / 7.29 / 7.22 ms, L2 fills 302 / 307 / 299 / 310 /
-                // 318 MB per launch)
-                if (policy & 8) {
-                    const int cg = ((policy >> 8) & 15) ? (policy >> 8) & 15 : 4;  // columns per group (bits 8-11; 0 = 4)
-                    t.key = ((((long long)xs * 4096 + cn / cg) * 65536 + t.m0 / 256) * 4096 + cn) * 8 + (t.m0 / UNIT) % 8;
-                }
+                // policy bit 3: (sample, group of cg columns, 256-row band, column) — an XCD that walks this order keeps
+                // cg W panels in its L2 while the x bands stream past them (groups of 3 / 4 / 6 / 9 / 12 columns measured
+                // in the BERT-base step on one box, round 3: GEMM 7.13 / 7.10 / 7.20 / 7.29 / 7.22 ms, L2 fills 302 / 307 /
+                // 299 / 310 / 318 MB per launch)
+                if (policy & 8) t.key = ((((long long)xs * 4096 + cn / cg) * 65536 + t.m0 / 256) * 4096 + cn) * 8 + (t.m0 / UNIT) % 8;
                 tiles.push_back(t);
                 u += hh;
             }
@@ -623,10 +652,8 @@ void build_schedule(int S, int layers, int tiles_n, int M, int n_cu, int policy,
     if (whole_classes) {
         // Every XCD takes a CONTIGUOUS share of each height class (shares rotate so that the XCDs' tile counts stay
         // within one of each other) and its 32 workgroups walk that share 32 tiles at a time: consecutive rounds of an
-        // XCD are neighbours in the locality order, so the panels one round pulled into the XCD's L2 serve the next
-        // (modelled L2 fills of the q/k/v launch: 3.2 -> 2.4 x the operand bytes, tools/sched_l2_sim.py).  A workgroup
-        // draws every 32nd tile of its XCD's list, i.e. the same number of tiles of every class: the unit balance of
-        // the class-by-class dealing is kept.
+        // XCD are neighbours in the locality order.  A workgroup draws every 32nd tile of its XCD's list, i.e. the same
+        // number of tiles of every class: the unit balance of the class-by-class dealing is kept.
         const int span = grid / 8;
         std::vector<std::vector<int>> share(8);
         int carry = 0;
@@ -706,6 +733,25 @@ void build_schedule(int S, int layers, int tiles_n, int M, int n_cu, int policy,
     }
 }
 
+// policy bits 8-11: columns per group of the locality order (0 = 4).  policy bit 13 (round 6): the group size is CHOSEN per
+// shape — among 3, 4, 6, 8 and all columns of a sample — by the modelled fabric fetch of the resulting schedule
+// (schedule_fetch_rows); the tiles, their heights and every workgroup's unit count are the same for every candidate.
+void build_schedule(int S, int layers, int tiles_n, int M, int n_cu, int policy, std::vector<int4>& table, int& rounds,
+                    int& grid) {
+    const int cg0 = ((policy >> 8) & 15) ? (policy >> 8) & 15 : 4;
+    if (!(policy & 0x2000) || !(policy & 8)) return build_schedule_cg(S, layers, tiles_n, M, n_cu, policy, cg0, table, rounds, grid);
+    const int cols = tiles_n * layers;
+    long long best = -1;
+    for (int cg : {4, 3, 6, 8, cols}) {  // (the first candidate wins a tie: 4 is the round-3 default)
+        if (cg > cols && cg != 4) continue;
+        std::vector<int4> t;
+        int r = 0, g = 0;
+        build_schedule_cg(S, layers, tiles_n, M, n_cu, policy, cg, t, r, g);
+        const long long f = schedule_fetch_rows(t, r, g);
+        if (best < 0 || f < best) best = f, table.swap(t), rounds = r, grid = g;
+    }
+}
+
 typedef Gemm256Sched Sched;
 typedef std::tuple<int, int, int, int, int, int, int> SchedKey;  // device, S, layers, tiles_n, M, n_cu, policy
 std::mutex g_sched_mu;
@@ -773,13 +819,7 @@ int launch256_tn(const GemmParams& p, hipStream_t stream, int grid) {
 
 template <typename T>
 int launch256_nn(const GemmParams& p, hipStream_t stream, int grid) {
-#ifdef BF_RING_ROWMAJOR  // measured slower than the burst form for row-major operands (LABBOOK.md §4.2): developer builds only
-    if (p.segs > 1)
-        hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, true, true, true>), dim3(grid), dim3(512), 0, stream, p);
-    else if (p.K >= 2 * TK)
-        hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, true, false, true>), dim3(grid), dim3(512), 0, stream, p);
-    else
-#endif
+    // (the unit ring of the TN form was measured slower than the burst form for row-major operands: LABBOOK.md section 4.2)
     if (p.segs > 1) hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, true, true>), dim3(grid), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, true>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
@@ -790,10 +830,6 @@ template <typename T>
 int launch256(const GemmParams& p, int y_dtype, hipStream_t stream, int grid) {
     if (y_dtype == BF_DT_F32)
         hipLaunchKernelGGL((gemm256_sched_kernel<T, float>), dim3(grid), dim3(512), 0, stream, p);
-#ifdef BF_RING_ROWMAJOR
-    else if (p.K >= 2 * TK)
-        hipLaunchKernelGGL((gemm256_sched_kernel<T, T, false, false, false, true>), dim3(grid), dim3(512), 0, stream, p);
-#endif
     else
         hipLaunchKernelGGL((gemm256_sched_kernel<T, T>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
@@ -830,10 +866,22 @@ extern "C" int bf_gemm_prepare(int S, int L, int M, int N, void* stream) {
 
 extern "C" size_t bf_gemm_schedule(int S, int L, int M, int N, int n_cu, int32_t* out, size_t cap_values, int* rounds,
                                    int* grid) {
+    return bf_gemm_schedule_policy(S, L, M, N, n_cu, -1, out, cap_values, rounds, grid);
+}
+
+extern "C" int64_t bf_gemm_schedule_fetch_rows(const int32_t* table, int rounds, int grid) {
+    if (!table || rounds < 1 || grid < 1) return -1;
+    std::vector<int4> t((size_t)rounds * grid);
+    for (size_t i = 0; i < t.size(); ++i) t[i] = int4{table[4 * i], table[4 * i + 1], table[4 * i + 2], table[4 * i + 3]};
+    return schedule_fetch_rows(t, rounds, grid);
+}
+
+extern "C" size_t bf_gemm_schedule_policy(int S, int L, int M, int N, int n_cu, int policy, int32_t* out, size_t cap_values,
+                                          int* rounds, int* grid) {
     if (S < 1 || L < 1 || M < 1 || N < 1 || n_cu < 1) return 0;
     std::vector<int4> table;
     int r = 0, g = 0;
-    build_schedule(S, L, (N + TN - 1) / TN, M, n_cu, BF_SCHED_POLICY, table, r, g);
+    build_schedule(S, L, (N + TN - 1) / TN, M, n_cu, policy < 0 ? BF_SCHED_POLICY : policy, table, r, g);
     if (rounds) *rounds = r;
     if (grid) *grid = g;
     const size_t n = table.size() * 4;
@@ -872,7 +920,7 @@ int bf_launch_gemm256(const GemmParams& p0, int w_dtype, int y_dtype, hipStream_
     const char* fe = getenv("BF_GEMM_NT_FORM");
     if (fe) form = atoi(fe);
 #endif
-    if (form && bf_gemm256_r5_supported(p, w_dtype, y_dtype)) return bf_launch_gemm256_r5(p, w_dtype, stream, sc.grid, form != 2);  // developer builds: form 2 = the LDS-staged epilogue
+    if (form && bf_gemm256_r5_supported(p, w_dtype, y_dtype)) return bf_launch_gemm256_r5(p, w_dtype, stream, sc.grid);
     if (w_dtype == BF_DT_BF16) return launch256<__bf16>(p, y_dtype, stream, sc.grid);
     return launch256<_Float16>(p, y_dtype, stream, sc.grid);
 }

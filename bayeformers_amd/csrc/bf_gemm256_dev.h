@@ -8,9 +8,13 @@
 #include "bf_gemm_params.h"
 
 // schedule policy bits (build_schedule): 1 = odd workgroups run their tiles in reverse order, 2 = fixed full-height
-// tiles (no balancing), 4 = XCD-chunked dealing, 8 = every XCD walks a contiguous share of each height class
+// tiles (no balancing), 4 = XCD-chunked dealing, 8 = every XCD walks a contiguous share of each height class, bits 4-7 =
+// tallest tile (0 = 8 units), bits 8-11 = columns per group of the locality order (0 = 4), 0x1000 = the columns that get one
+// tile more are the first ones (columns of a sample share their row cuts), 0x2000 = the column-group size is chosen per shape
+// by the modelled fabric fetch.  0x300C since round 6 (12 before: same times, 9 % more fabric reads per BERT-base step:
+// profiles/r6b_sched_l2_model.md)
 #ifndef BF_SCHED_POLICY
-#define BF_SCHED_POLICY 12
+#define BF_SCHED_POLICY 0x300C
 #endif
 
 // The tile schedule of a shape (built on the host once per device, kept in device memory): bf_gemm256.hip.
@@ -22,7 +26,7 @@ int bf_gemm256_get_schedule(int S, int layers, int tiles_n, int M, int policy, h
 
 // the five-slot-ring forward kernel (bf_gemm256_r5.hip)
 bool bf_gemm256_r5_supported(const GemmParams& p, int w_dtype, int y_dtype);
-int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, int grid, bool reg_epilogue = true);
+int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, int grid);
 int bf_launch_gemm256_r5_nn(const GemmParams& p, int dtype, hipStream_t stream, int grid);
 
 namespace {
@@ -104,16 +108,8 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-#ifndef BF_NT_STORES
-#define BF_NT_STORES 1
-#endif
-constexpr int NT_STORES = BF_NT_STORES;  // 0 plain, 1 nontemporal (product), 2 / 3 = sc1 / sc0 sc1 write-through (experiments)
-__device__ __forceinline__ void gemm_st16(f32x4_t* p, f32x4_t v) {
-    if (NT_STORES == 1) __builtin_nontemporal_store(v, p);
-    else if (NT_STORES == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-    else if (NT_STORES == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-    else *p = v;
-}
+// output stores are nontemporal (plain and sc1 / sc0 sc1 write-through stores were measured: profiles/r3t_gemm_output_store_policy.txt)
+__device__ __forceinline__ void gemm_st16(f32x4_t* p, f32x4_t v) { __builtin_nontemporal_store(v, p); }
 
 
 // act() of a 16-byte chunk of YT outputs (8 x 16-bit or 4 x fp32), computed in fp32
@@ -142,8 +138,7 @@ __device__ __forceinline__ f32x4_t act_chunk(f32x4_t c, int act) {
 // when a wave gets here, see the kernel).
 template <typename YT, int H, int SLICES = 2>
 __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc)[4][H], YT* y, YT* y2, int m0,
-                                              int m_end, int n0, int N, int wm, int wn, int lane, int act,
-                                              int act_done = 0) {  // act_done: blocks 0 .. act_done - 1 are activated already
+                                              int m_end, int n0, int N, int wm, int wn, int lane, int act) {
     constexpr int ROWB = 64 * (int)sizeof(YT);   // 128 or 256
     constexpr int BLK = 16 * ROWB;               // 2 or 4 KiB
     constexpr int CH = ROWB / 16;                // 16-byte chunks per row: 8 or 16
@@ -169,7 +164,7 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
         char* R = scratch + (SLICES == 2 ? (mb & 1) * BLK : 0);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            const f32x4_t v = (y2 || mb < act_done) ? acc[nb][mb] : bf_apply_act<sizeof(YT) == 2>(acc[nb][mb], act);
+            const f32x4_t v = y2 ? acc[nb][mb] : bf_apply_act<sizeof(YT) == 2>(acc[nb][mb], act);
             char* dst = R + wr_off[nb];
             if constexpr (sizeof(YT) == 4)
                 *reinterpret_cast<f32x4_t*>(dst) = v;
@@ -222,82 +217,6 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
                     const YT* e = reinterpret_cast<const YT*>(&v);
                     for (int j = 0; j < EPC; ++j)
                         if (n + j < N) o[j] = e[j];
-                }
-            }
-        }
-    }
-}
-
-// ---- the register epilogue of the forward form (DPPE instantiations of bf_gemm256_r5.hip) -----------------------------
-// With the W fragment rows permuted — fragment row 4 q + j of block nb carries feature 16 q + 4 nb + j of the wave's 64
-// (the permutation lives in the fragment READ address; the LDS image and its swizzle are chosen so that it costs no bank
-// conflict) — a lane (column c = lane & 15 = output row, group q = lane >> 4) holds, for every 16-row block, SIXTEEN
-// CONSECUTIVE features 16 q .. 16 q + 15 of one output row: 32 bytes of a 128-byte line whose other three quarters sit in
-// the lanes (c, q') of the same column.  Two neighbouring columns (c even, c + 1) swap one 16-byte half each on the DPP
-// network (quad_perm [1,0,3,2]); after that, in store instruction A the 8 lanes {(c, q), (c + 1, q)} hold the 8 chunks of
-// row c and in instruction B those of row c + 1: every 16-byte store instruction writes 8 FULL 128-byte lines, exactly like
-// the LDS-staged epilogue, with no LDS write, read or wait in between (16 v_cvt_pk + 4 DPP moves + 8 selects per block).
-__device__ __forceinline__ unsigned bf_dpp_swap_pairs(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
-}
-
-template <int H>
-__device__ __forceinline__ void init_acc_perm(f32x4_t (&acc)[4][H], const float* bias, int n0, int N, int wn, int lane) {
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-        f32x4_t b = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-            const int n = n0 + wn * 64 + (lane >> 4) * 16 + nb * 4;
-            if (n + 3 < N) b = *reinterpret_cast<const f32x4_t*>(bias + n);  // N % 8 == 0 (host check): all or nothing
-        }
-#pragma unroll
-        for (int mb = 0; mb < H; ++mb) acc[nb][mb] = b;
-    }
-}
-
-template <typename YT, int H>
-__device__ __forceinline__ void epilogue_dpp(const f32x4_t (&acc)[4][H], YT* y, YT* y2, int m0, int m_end, int n0, int N,
-                                             int wm, int wn, int lane, int act) {
-    static_assert(sizeof(YT) == 2, "16-bit outputs");
-    typedef __attribute__((ext_vector_type(4))) YT yt4;
-    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-    asm volatile("" : "+v"(lane));  // per-tile arithmetic: nothing of it lives through the k-loop
-    const int c = lane & 15, q = lane >> 4;
-    const bool odd = (c & 1) != 0;
-    const int n = n0 + wn * 64 + (2 * q + (odd ? 1 : 0)) * 8;  // first feature of the chunk this lane stores
-    const bool n_ok = n < N;                                    // N % 8 == 0: a chunk is inside or outside as a whole
-    const int row_a = (c & ~1);
-#pragma unroll
-    for (int mb = 0; mb < H; ++mb) {
-        unsigned P[8];
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const f32x4_t v = y2 ? acc[nb][mb] : bf_apply_act<true>(acc[nb][mb], act);
-            const u32x2_t pk = __builtin_bit_cast(u32x2_t, __builtin_convertvector(v, yt4));
-            P[2 * nb] = pk[0];
-            P[2 * nb + 1] = pk[1];
-        }
-        u32x4_t da, db;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned lo = P[i], hi = P[4 + i];
-            const unsigned recv = bf_dpp_swap_pairs(odd ? lo : hi);  // even column sends its high half, odd its low half
-            da[i] = odd ? recv : lo;   // row c (even): chunk 2 q from its own lane, chunk 2 q + 1 from ... the odd lane
-            db[i] = odd ? hi : recv;   // row c + 1
-        }
-        const int m = m0 + (2 * mb + wm) * 16 + row_a;
-        if (n_ok) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                if (m + r < m_end) {
-                    f32x4_t v = __builtin_bit_cast(f32x4_t, r ? db : da);
-                    const unsigned off = (unsigned)((m + r) * N + n);
-                    if (y2) {
-                        gemm_st16(reinterpret_cast<f32x4_t*>(y2 + off), v);
-                        v = act_chunk<YT>(v, act);
-                    }
-                    gemm_st16(reinterpret_cast<f32x4_t*>(y + off), v);
                 }
             }
         }

@@ -26,14 +26,11 @@
 
 namespace {
 
-#ifndef BF_R5_ASYM
-#define BF_R5_ASYM 0  // experiment (round 5): ALL LDS-DMA pieces of a unit are issued by wave group 1 (8 per wave and L slot), group 0's
-// L slots carry fragment reads only — does a piece cost less when the partner group's slot is free of them?  Forward form only.
-// Measured: profiles/r5j_ring_asymmetric_dma_ab.txt.
-#endif
-#ifndef BF_R5_EARLY_ACT
-#define BF_R5_EARLY_ACT 0  // experiment, see `mfmas` below: an extra instantiation (EA) for launches with a fused activation
-#endif
+// Variants of this kernel that were built, measured in the BERT-base step and removed (LABBOOK.md section 4.2b; the sources are
+// in the history up to round 5): all DMA pieces issued by one wave group (profiles/r5j_*: 4-6 % slower), the fused activation
+// applied between the last k-step's MFMAs (r5e_*: 3-4 % slower), pieces issued behind the MFMA slot (r4l_*: 5 % slower), cache
+// policy bits on the DMA (r4s_*), a register-only epilogue on permuted W fragments (r4i_*: 7-18 % slower), an L2 prefetch ahead of
+// the DMA (r5v_*: 21 % slower), staggered workgroup starts, one barrier per k-step, no MFMA priority (r3aj_*, r3y_*).
 constexpr int SLOT_BYTES = 32768;  // one unit: 256 rows x 128 B (= X_BYTES)
 constexpr int NSLOT = 5;
 
@@ -45,15 +42,6 @@ constexpr int NSLOT = 5;
 // (on the DMA source address) and whose fragments come out through ds_read_b64_tr_b16, exactly as in bf_gemm256.hip.
 // SEG: the contraction runs over p.segs segments of K (x: [segs][S][M][K], w: [segs][S][K][N]) — the one input gradient
 // of the stacked query / key / value layers.
-// DPPE (forward form, 16-bit outputs, N % 8 == 0; DEVELOPER builds only — a measured dead end, see below): W fragment
-// rows permuted so that the epilogue runs in registers (epilogue_dpp in bf_gemm256_dev.h) instead of through LDS.
-// Bit-identical outputs, no LDS traffic in the epilogue — and 7 % (K = 4096) to 18 % (K = 768) slower per launch: a store
-// instruction still writes 8 full 128-byte lines, but a QUAD of consecutive lanes now holds 2 rows x 32 B instead of 64
-// contiguous bytes, and the vector memory pipe coalesces per quad — +6-8 us per tile.  Getting 64 contiguous bytes into a
-// quad needs the chunk index in lane bits 1:0, i.e. two more exchange stages (v_permlane16_swap + DPP + selects, ~28 VALU
-// per block) — about what the LDS round trip costs.  Not pursued.  The W units then use their own 16-byte-chunk swizzle,
-// chunk ^= ((row >> 1) & 1) | (((row >> 4) & 3) << 1): a fragment read touches rows {16 a + b + 4 i} (a, b = 0..3), whose
-// swizzle under the x units' (row >> 1) & 7 would take two values only.
 // T = float (round 5): the reference-precision form.  A unit is still 256 rows x 128 B — 32 fp32 values of k per row and
 // k-step instead of 64 16-bit ones — so the ring, the DMA pieces, the swizzle and the fragment reads (16 bytes = 4
 // consecutive k of a lane's row) are the 16-bit kernel's, byte for byte; a fragment feeds FOUR v_mfma_f32_16x16x4_f32
@@ -66,10 +54,9 @@ struct FragOf { using type = typename Mfma16<T>::frag; };
 template <>
 struct FragOf<float> { using type = f32x4_t; };
 
-template <typename T, typename YT, bool TRW = false, bool SEG = false, bool DPPE = false, bool EA = false>
+template <typename T, typename YT, bool TRW = false, bool SEG = false>
 __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams p) {
-    static_assert(!DPPE || (!TRW && sizeof(YT) == 2), "the register epilogue belongs to the forward form");
-    static_assert(sizeof(T) == 2 || (!TRW && !SEG && !DPPE && sizeof(YT) == 4), "fp32 operands: forward form, fp32 outputs");
+    static_assert(sizeof(T) == 2 || (!TRW && !SEG && sizeof(YT) == 4), "fp32 operands: forward form, fp32 outputs");
     using frag = typename FragOf<T>::type;
     constexpr unsigned ES = sizeof(T);            // bytes per operand element
     constexpr int TKE = ROW_BYTES / (int)ES;      // k-values per k-step: 64 (16-bit) or 32 (fp32)
@@ -97,8 +84,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     const T* xb;
     const T* wb;
     unsigned xo, wo;  // per-lane byte offset of piece 0 (rows 8 wid .. 8 wid + 7); piece i lies 64 rows = `rowblk` bytes further
-    constexpr bool ASYM = BF_R5_ASYM && !TRW && !SEG && !DPPE && sizeof(T) == 2;
-    const unsigned rowblk = (ASYM ? 32u : 64u) * (unsigned)K * ES;  // rows between a wave's consecutive pieces of a unit
+    const unsigned rowblk = 64u * (unsigned)K * ES;  // rows between a wave's consecutive pieces of a unit
     // An operand is fetched through a buffer descriptor that ends with the sample's operand: rows past M (N) of a partial
     // tile are out of range and arrive as zeros (their products land in rows / columns the epilogue masks) — no per-row
     // clamp, so ONE offset register per operand instead of four.
@@ -119,12 +105,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         } else {
             int prow, kc8;
             piece_lane(prow, kc8);
-            if constexpr (DPPE) {  // W units: chunk ^= ((row >> 1) & 1) | (((row >> 4) & 3) << 1), row = 64 i + 8 wid + prow
-                int ln = lane;
-                asm volatile("" : "+v"(ln));
-                kc8 = ((ln & 7) ^ (((ln >> 4) & 1) | ((wid >> 1) << 1))) * 8;
-            }
-            wo = ((unsigned)(n0 + (ASYM ? (wid & 3) : wid) * 8 + prow) * (unsigned)K + kc8) * ES;
+            wo = ((unsigned)(n0 + wid * 8 + prow) * (unsigned)K + kc8) * ES;
             w_bytes = (unsigned)N * (unsigned)K * ES;
         }
     };
@@ -133,31 +114,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         xb = reinterpret_cast<const T*>(p.x) + (long long)__builtin_amdgcn_readfirstlane(d.y) * p.x_sstride;
         int prow, kc8;
         piece_lane(prow, kc8);
-        xo = ((unsigned)(m0 + (ASYM ? (wid & 3) : wid) * 8 + prow) * (unsigned)K + kc8) * ES;
+        xo = ((unsigned)(m0 + wid * 8 + prow) * (unsigned)K + kc8) * ES;
         x_bytes = (unsigned)M * (unsigned)K * ES;
     };
     // one 1 KiB piece: `base` (a buffer of `bytes`) + per-lane byte offset `off` + wave-uniform byte offset `soff` -> LDS `dst`
-#ifndef BF_R5_AUX_X
-#define BF_R5_AUX_X 0  // cache policy bits of the x / W pieces (1 = sc0, 2 = nt, 16 = sc1): experiment, see LABBOOK.md 4.2b
-#endif
-#ifndef BF_R5_AUX_W
-#define BF_R5_AUX_W 0
-#endif
+    auto piece = [&](const T* base, unsigned bytes, unsigned off, int soff, char* dst) {
 #ifdef BF_DEV
-#define BF_R5_PIECE_GUARD if (p.flags & 1) return;  /* ablation: no DMA in the k-loop */
-#else
-#define BF_R5_PIECE_GUARD
+        if (p.flags & 1) return;  // ablation: no DMA in the k-loop
 #endif
-#define BF_R5_PIECE(NAME, AUX)                                                                                              \
-    auto NAME = [&](const T* base, unsigned bytes, unsigned off, int soff, char* dst) {                                     \
-        BF_R5_PIECE_GUARD                                                                                                   \
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)bytes, 0x00020000); \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, (int)off, soff, 0, AUX);                            \
-    }
-    BF_R5_PIECE(piece_x, BF_R5_AUX_X);
-    BF_R5_PIECE(piece_w, BF_R5_AUX_W);
-#undef BF_R5_PIECE
-#undef BF_R5_PIECE_GUARD
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)bytes, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst, 16, (int)off, soff, 0, 0);
+    };
     // segmented contraction: k-step kt lies in segment kt / (K / TK) (wave-uniform arithmetic)
     auto segment = [&](int& kt) -> int {
         if constexpr (SEG) {
@@ -170,50 +137,28 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     };
     // this wave's pieces of unit X(kt) / W(kt) into ring slot `slot`; only the 4 h pieces of the tile's rows of x are
     // fetched (h4 = 4 h: an integral_constant inside a tile's k-loop, so a full-height tile issues without branches)
-#ifndef BF_R5_SPLIT
-#define BF_R5_SPLIT 0  // experiment: pieces 2, 3 of a unit are issued at the END of the MFMA slot that follows its L slot
-// (behind the wave's last MFMA, where it would otherwise park at the barrier).  Measured in the BERT-base step, one box, three
-// interleaved runs each (profiles/r4l_split_dma_issue_ab.txt): roofline.frac 0.421-0.425 -> 0.399-0.404, i.e. 5 % SLOWER —
-// a piece costs the issuing wave as much behind its MFMAs as beside its fragment reads, and it lands a slot later.
-#endif
-    auto issue_x = [&](int kt, int slot, auto h4, int lo = 0, int hi = 4) {
+    auto issue_x = [&](int kt, int slot, auto h4) {
 #ifdef BF_DEV
         if (p.flags & 64) kt = 0;  // ablation: every k-step re-reads k-step 0 (operands L2-hot)
 #endif
-        if constexpr (ASYM) {  // group 1 only: piece q = i * 4 + (wid & 3), i = 0 .. 7
-            if (wm == 0) return;
-            char* base = smem + slot * SLOT_BYTES + (wid & 3) * 1024;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i * 4 + 3 < h4 || i * 4 + (wid & 3) < h4) piece_x(xb, x_bytes, xo + i * rowblk, kt * ROW_BYTES, base + i * 4096);
-            return;
-        }
         char* base = smem + slot * SLOT_BYTES + wid * 1024;
         const int seg = segment(kt);
         const T* xs = SEG ? xb + (long long)seg * p.x_seg_stride : xb;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (i >= lo && i < hi && (i * 8 + 7 < h4 || i * 8 + wid < h4)) piece_x(xs, x_bytes, xo + i * rowblk, kt * (TK * 2), base + i * 8192);
+            if (i * 8 + 7 < h4 || i * 8 + wid < h4) piece(xs, x_bytes, xo + i * rowblk, kt * (TK * 2), base + i * 8192);
     };
-    auto issue_w = [&](int kt, int slot, int lo = 0, int hi = 4) {
+    auto issue_w = [&](int kt, int slot) {
 #ifdef BF_DEV
         if (p.flags & 64) kt = 0;
 #endif
-        if constexpr (ASYM) {
-            if (wm == 0) return;
-            char* base = smem + slot * SLOT_BYTES + (wid & 3) * 1024;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) piece_w(wb, w_bytes, wo + i * rowblk, kt * ROW_BYTES, base + i * 4096);
-            return;
-        }
         char* base = smem + slot * SLOT_BYTES + wid * 1024;
         const int seg = segment(kt);
         const T* ws = SEG ? wb + (long long)seg * p.w_seg_stride : wb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (i < lo || i >= hi) continue;
-            if constexpr (TRW) piece_w(ws, w_bytes, wo, (kt * TK + i * 16) * N * 2, base + i * 8192);
-            else piece_w(ws, w_bytes, wo + i * rowblk, kt * (TK * 2), base + i * 8192);
+            if constexpr (TRW) piece(ws, w_bytes, wo, (kt * TK + i * 16) * N * 2, base + i * 8192);
+            else piece(ws, w_bytes, wo + i * rowblk, kt * (TK * 2), base + i * 8192);
         }
     };
 
@@ -224,12 +169,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     const unsigned foff0 = (lane & 15) * ROW_BYTES + ((((lane >> 4)) ^ fsw) << 4);
     const unsigned foff1 = (lane & 15) * ROW_BYTES + (((4 + (lane >> 4)) ^ fsw) << 4);
     const unsigned xrow0 = lds0 + wm * 16 * ROW_BYTES;  // + j * 32 rows: wave group wm owns blocks wm, wm + 2, ...
-    const unsigned wrow0 = lds0 + wn * 64 * ROW_BYTES;  // + i * 16 rows (DPPE: + i * 4 rows, permuted fragment rows)
-    // DPPE: fragment row li of block i is W row 16 (li >> 2) + 4 i + (li & 3) of the wave's 64; its swizzle depends on li only
-    const int wsw = ((lane >> 1) & 1) | (((lane >> 2) & 3) << 1);
-    const unsigned wperm = (16 * ((lane & 15) >> 2) + (lane & 3)) * ROW_BYTES;
-    const unsigned wfoff0 = DPPE ? wperm + ((((lane >> 4)) ^ wsw) << 4) : foff0;
-    const unsigned wfoff1 = DPPE ? wperm + (((4 + (lane >> 4)) ^ wsw) << 4) : foff1;
+    const unsigned wrow0 = lds0 + wn * 64 * ROW_BYTES;  // + i * 16 rows
     auto lds_read = [&](unsigned a, auto off) -> frag {
         frag v;
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(decltype(off)::value));
@@ -268,19 +208,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     int n0 = (__builtin_amdgcn_readfirstlane(d.z) & 0xFFFFFF) * TN;
     setup_w(d);
     setup_x(d);
-#ifdef BF_DEV
-    // experiment: the workgroups of an XCD (blockIdx % 8) start (blockIdx / 8) * k * 64 cycles apart, k = flags bits 8..11
-    if (p.flags & 0xF00) {
-        const int steps = (int)(blockIdx.x >> 3) * ((p.flags >> 8) & 15);
-        for (int i = 0; i < steps; ++i) __builtin_amdgcn_s_sleep(1);
-    }
-#endif
     int a = 0;  // ring slot of W of the k-step about to run; X of that step sits in a + 1, X(+1) goes to a + 3, W(+2) to a + 4
     issue_w(0, 0);
     issue_x(0, 1, 4 * h);
     issue_w(1, 2);
-    if (ASYM) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     int round = 0;
@@ -302,53 +234,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) wf[i] = tr_read(aw, i, half);
                 } else {
-                    const unsigned aw = wrow0 + slot_w * SLOT_BYTES + (HF ? wfoff1 : wfoff0);
+                    const unsigned aw = wrow0 + slot_w * SLOT_BYTES + (HF ? foff1 : foff0);
                     static_for<0, 4>([&](auto ic) {
-                        wf[decltype(ic)::value] = lds_read(aw, std::integral_constant<int, decltype(ic)::value * (DPPE ? 4 : 16) * ROW_BYTES>{});
+                        wf[decltype(ic)::value] = lds_read(aw, std::integral_constant<int, decltype(ic)::value * 16 * ROW_BYTES>{});
                     });
                 }
                 static_for<0, H>([&](auto jc) {
                     xf[decltype(jc)::value] = lds_read(ax, std::integral_constant<int, decltype(jc)::value * 32 * ROW_BYTES>{});
                 });
-#ifdef BF_DEV
-                if (p.flags & 16384) return;  // ablation (WRONG results): the L slot does not wait for its fragment reads
-#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
-#if 0
-#define BF_R5_EARLY_ACT_DOC 0  // experiment: the tile's LAST MFMA slot runs row block by row block and the
-// fused activation of block j - 2 is applied in place between the MFMAs of block j, so that the GELU's VALU time of the
-// first H - 2 blocks lies under matrix-pipe time instead of in the epilogue.  Bit-identical outputs.  Measured in the
-// BERT-base step (profiles/r5e_gemm_variants_in_step_ab.txt): see LABBOOK.md (round 5) — not adopted.
-#endif
-#ifndef BF_R5_EARLY_LAG
-#define BF_R5_EARLY_LAG 2   // the activation trails the MFMAs by this many row blocks (more = fewer live fragments beside it)
-#endif
-            constexpr int LAG = BF_R5_EARLY_LAG;
-            int act_done = 0;  // row blocks whose activation is already applied when the epilogue starts
-            auto mfmas = [&](auto lastc) {
-                if constexpr (EA && decltype(lastc)::value && sizeof(T) == 2 && !TRW && (H > LAG)) {
-                    {  // (EA instantiation: launched for act != NONE without a pre-activation output)
-                        __builtin_amdgcn_s_setprio(1);
-                        static_for<0, H>([&](auto jc) {
-                            constexpr int j = decltype(jc)::value;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) acc[i][j] = Mfma16<T>::run(wf[i], xf[j], acc[i][j]);
-                            if constexpr (j >= LAG) {
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) acc[i][j - LAG] = bf_apply_act<true>(acc[i][j - LAG], p.act);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        });
-                        __builtin_amdgcn_s_setprio(0);
-                        act_done = H - LAG;
-                        return;
-                    }
-                }
-#ifdef BF_DEV
-                if (p.flags & 8192) __builtin_amdgcn_s_setprio(0);  // experiment: no priority for the MFMA slot
-                else
-#endif
+            auto mfmas = [&] {
                 __builtin_amdgcn_s_setprio(1);
                 if constexpr (sizeof(T) == 4) {
 #pragma unroll
@@ -374,64 +270,44 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                 if (ax >= NSLOT) ax -= NSLOT;
                 if (a3 >= NSLOT) a3 -= NSLOT;
                 if (a4 >= NSLOT) a4 -= NSLOT;
-                auto dma0 = [&](int lo = 0, int hi = 4) {
+                auto dma0 = [&] {
                     if constexpr (MODE == 2) {
-                        if (has_next) issue_x(0, a3, 4 * h2, lo, hi);
+                        if (has_next) issue_x(0, a3, 4 * h2);
                     } else {
-                        issue_x(kt + 1, a3, std::integral_constant<int, 4 * H>{}, lo, hi);
+                        issue_x(kt + 1, a3, std::integral_constant<int, 4 * H>{});
                     }
                 };
-                auto dma1 = [&](int lo = 0, int hi = 4) {
-                    if constexpr (MODE == 0) issue_w(kt + 2, a4, lo, hi);
-                    else if (has_next) issue_w(MODE == 1 ? 0 : 1, a4, lo, hi);
+                auto dma1 = [&] {
+                    if constexpr (MODE == 0) issue_w(kt + 2, a4);
+                    else if (has_next) issue_w(MODE == 1 ? 0 : 1, a4);
                 };
                 auto wait_all_but_newest = [&] {
-#ifdef BF_DEV
-                    // ablation (WRONG results): the first two k-steps of a tile do not wait for the previous tile's stores
-                    if ((p.flags & 32) && MODE == 0 && kt < 2) { asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); return; }
-#endif
-                    if (MODE == 0 || has_next) {
-                        // (split issue: group 1 waits in its L1 with only the first two pieces of the newest unit out)
-                        if (BF_R5_SPLIT && wm == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                        else if (ASYM) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // a unit = 8 pieces of the issuing wave
-                        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (MODE == 0 || has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 };
-#ifdef BF_DEV
-                // experiment (flags bit 12): one barrier per k-step from the tile's second k-step on — the one that carries
-                // the landed / released units (group 0: after M1, group 1: after L1); the slots in between run unlocked
-                const bool relaxed = (p.flags & 4096) != 0;
-                const bool lock = !(relaxed && kt > 0);
-#else
-                constexpr bool relaxed = false, lock = true;
-#endif
-                dma0(0, BF_R5_SPLIT ? 2 : 4);
+                dma0();
                 read_frags(a, ax, std::integral_constant<int, 0>{});
                 __builtin_amdgcn_sched_barrier(0);
-                if (lock) __builtin_amdgcn_s_barrier();
-                mfmas(std::false_type{});
-                if (BF_R5_SPLIT) dma0(2, 4);
+                __builtin_amdgcn_s_barrier();
+                mfmas();
                 __builtin_amdgcn_sched_barrier(0);
-                if (lock) __builtin_amdgcn_s_barrier();
-                dma1(0, BF_R5_SPLIT ? 2 : 4);
+                __builtin_amdgcn_s_barrier();
+                dma1();
                 read_frags(a, ax, std::integral_constant<int, 1>{});
                 if (wm == 1) wait_all_but_newest();
                 __builtin_amdgcn_sched_barrier(0);
-                if (lock || wm == 1) __builtin_amdgcn_s_barrier();
-                mfmas(std::integral_constant<bool, MODE == 2>{});
-                if (BF_R5_SPLIT) dma1(2, 4);
+                __builtin_amdgcn_s_barrier();
+                mfmas();
                 if (wm == 0) wait_all_but_newest();
                 __builtin_amdgcn_sched_barrier(0);
                 // (group 1 does not meet group 0 again before the tile-end barrier: its last slot ends without one, which
                 // also keeps the two groups' barrier counts equal)
-                if (!(MODE == 2 && wm == 1) && !(relaxed && wm == 1)) __builtin_amdgcn_s_barrier();
+                if (!(MODE == 2 && wm == 1)) __builtin_amdgcn_s_barrier();
                 a += 2;
                 if (a >= NSLOT) a -= NSLOT;
             };
 
             if (wm == 1) __builtin_amdgcn_s_barrier();  // G1 runs one slot behind G0
-            if constexpr (DPPE) init_acc_perm<H>(acc, p.bias ? p.bias + (long long)s * N : nullptr, n0, N, wn, lane);
-            else
 #ifdef BF_DEV
             init_acc<H>(acc, (p.bias && !(p.flags & 2)) ? p.bias + (long long)s * N : nullptr, n0, N, wn, lane);
 #else
@@ -460,8 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
             if (p.flags & 16) m_end = 0;  // ablation: no global stores
             if (p.flags & 8) return;      // ablation: no epilogue
 #endif
-            if constexpr (DPPE) epilogue_dpp<YT, H>(acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act);
-            else epilogue_wave<YT, H, sizeof(YT) == 2 ? 2 : 1>(scratch, acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act, act_done);
+            epilogue_wave<YT, H, sizeof(YT) == 2 ? 2 : 1>(scratch, acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act);
         };
         switch (h) {
             case 8: body(std::integral_constant<int, 8>{}); break;
@@ -481,9 +356,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     }
 }
 
-template <typename T, typename YT, bool TRW, bool SEG, bool DPPE = false, bool EA = false>
+template <typename T, typename YT, bool TRW, bool SEG>
 int launch_r5(const GemmParams& p, hipStream_t stream, int grid) {
-    hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, TRW, SEG, DPPE, EA>), dim3(grid), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, TRW, SEG>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -499,25 +374,8 @@ bool bf_gemm256_r5_supported(const GemmParams& p, int w_dtype, int y_dtype) {
     return true;
 }
 
-int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, int grid, bool reg_epilogue) {
+int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, int grid) {
     if (p.segs > 1) BF_FAIL("bf_gemm256_r5: the forward form has no segments");
-#ifdef BF_DEV
-    // developer builds (BF_GEMM_NT_FORM=3): the register epilogue — measured 7-18 % SLOWER than the LDS-staged one
-    // (profiles/r4i_register_epilogue_ab.txt), so the product library does not instantiate it.  It stores whole 16-byte
-    // chunks: N a multiple of 8, 16-byte aligned outputs and fp32 bias rows.
-    if (reg_epilogue && p.N % 8 == 0 && (((uintptr_t)p.y | (uintptr_t)p.y2 | (uintptr_t)p.bias) & 15) == 0) {
-        if (w_dtype == BF_DT_BF16) return launch_r5<__bf16, __bf16, false, false, true>(p, stream, grid);
-        return launch_r5<_Float16, _Float16, false, false, true>(p, stream, grid);
-    }
-#else
-    (void)reg_epilogue;
-#endif
-#if BF_R5_EARLY_ACT
-    if (p.act != BF_ACT_NONE && !p.y2) {
-        if (w_dtype == BF_DT_BF16) return launch_r5<__bf16, __bf16, false, false, false, true>(p, stream, grid);
-        return launch_r5<_Float16, _Float16, false, false, false, true>(p, stream, grid);
-    }
-#endif
     if (w_dtype == BF_DT_BF16) return launch_r5<__bf16, __bf16, false, false>(p, stream, grid);
     return launch_r5<_Float16, _Float16, false, false>(p, stream, grid);
 }

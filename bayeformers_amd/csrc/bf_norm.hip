@@ -29,21 +29,14 @@ __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = a[i], v[4 + i] = b[i];
 }
-#ifndef BF_LN_NT_STORES
-#define BF_LN_NT_STORES 3
-#endif
-// BF_LN_NT_STORES: how the normalised rows are written — 0 plain stores, 1 nontemporal, 2 sc1, 3 sc0 sc1 (write-through).
-// Measured on the whole BERT-base step, three interleaved rounds on one box (profiles/r3k_layernorm_store_policy.txt):
-// nontemporal 8.81-8.87 ms, plain 8.78-8.79, sc1 8.71-8.77, sc0 sc1 8.70-8.75: write-through rows are what the GEMM that
-// reads them next (cold, from another XCD's point of view) finds fastest.
+// The normalised rows are written through (sc0 sc1).  Measured on the whole BERT-base step, three interleaved rounds on one
+// box (profiles/r3k_layernorm_store_policy.txt): nontemporal 8.81-8.87 ms, plain 8.78-8.79, sc1 8.71-8.77, sc0 sc1 8.70-8.75:
+// write-through rows are what the GEMM that reads them next (cold, from another XCD's point of view) finds fastest.
 __device__ __forceinline__ void st16(f32x4_t* p, f32x4_t v) {
-    if (BF_LN_NT_STORES == 1) __builtin_nontemporal_store(v, p);
     // (inline asm: there is no builtin for a flat-addressed store with these cache bits.  The trailing s_nop keeps the
     // compiler's next instruction from overwriting the data registers before the store has read them — it does not pad
     // hazards of instructions inside an asm statement)
-    else if (BF_LN_NT_STORES == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-    else if (BF_LN_NT_STORES == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-    else *p = v;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store8(__bf16* p, const float (&v)[8]) {
     const bf16x8_t t = __builtin_convertvector((f32x8_t{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]}), bf16x8_t);
@@ -200,11 +193,8 @@ __global__ __launch_bounds__(64 * kRowsPerBlock) void add_layernorm_half_kernel(
 // latency-bound pass runs 109 -> 79 us (two consumers: 129 -> 92 us) at the BERT-base training shape (tools/ln_bwd_bench.py, round 5).
 // (Folding the next dense layer's bias column sums into this kernel was built and measured in round 5: 16 more accumulators cost a
 // wave per SIMD again (+25-45 us), LDS ds_add_f32 accumulation 190-207 us — a column-sum pass of its own, 16 us, stays cheaper.)
-#ifndef BF_LN_BWD_DROP_WAVES
-#define BF_LN_BWD_DROP_WAVES 4  // 1 = no request (132 VGPRs, 3 waves per SIMD): the A/B baseline
-#endif
 template <typename T, typename GT, int VPL, bool DROP = false>
-__global__ __launch_bounds__(64 * kRowsPerBlock, (DROP && VPL <= 2) ? BF_LN_BWD_DROP_WAVES : 1) void add_layernorm_bwd_kernel(
+__global__ __launch_bounds__(64 * kRowsPerBlock, (DROP && VPL <= 2) ? 4 : 1) void add_layernorm_bwd_kernel(
     const T* __restrict__ x, const T* __restrict__ res, const GT* __restrict__ gamma, const T* __restrict__ dy,
     T* __restrict__ dz, float* __restrict__ partial, long long rows, int N, float eps, const bf_dropout_t drop,
     T* __restrict__ dx, const T* __restrict__ dy2) {
@@ -331,10 +321,7 @@ __global__ __launch_bounds__(1024) void layernorm_param_grad_kernel(const float*
     }
 }
 
-#ifndef BF_LN_BWD_BLOCKS
-#define BF_LN_BWD_BLOCKS 1024
-#endif
-constexpr int kBwdBlocks = BF_LN_BWD_BLOCKS;  // workgroups (each leaves one [2][N] partial row)
+constexpr int kBwdBlocks = 1024;  // workgroups (each leaves one [2][N] partial row)
 
 template <typename T, typename GT>
 int launch_bwd_vpl(const void* x, const void* res, const void* gamma, const void* dy, void* dz, float* partial,

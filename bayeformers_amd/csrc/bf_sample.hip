@@ -29,10 +29,7 @@
 namespace {
 
 constexpr int kThreads = 256;  // 4 waves
-#ifndef BF_SAMPLE_GPT
-#define BF_SAMPLE_GPT 2
-#endif
-constexpr int kGPT = BF_SAMPLE_GPT;  // groups of 4 scalars (= Philox blocks per sample) a thread owns
+constexpr int kGPT = 2;  // groups of 4 scalars (= Philox blocks per sample) a thread owns (1 / 2 / 3 measured: profiles/r2c_*)
 constexpr int kEPT = 4 * kGPT;         // scalars per thread
 constexpr int kMaxSChunk = 32;
 constexpr int kMaxSeg = 2;
@@ -162,13 +159,7 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][k
     bool all_full = true;
 #pragma unroll
     for (int j = 0; j < G; ++j) {
-#ifndef BF_SAMPLE_ADJ
-#define BF_SAMPLE_ADJ 0  // experiment (round 5): a thread's G groups are ADJACENT (8 consecutive scalars at G = 2), so that a sample's
-// bf16 weights leave as ONE 16-byte store per thread — half the store instructions — while the 16-byte parameter loads of a
-// wave interleave (32-byte lane stride).  profiles/r5n_sampling_adjacent_groups_ab.txt
-#endif
-        e0[j] = BF_SAMPLE_ADJ ? (((unsigned long long)a.rel_block * kThreads + tid) * G + j) * 4
-                              : (((unsigned long long)a.rel_block * G + j) * kThreads + tid) * 4;
+        e0[j] = (((unsigned long long)a.rel_block * G + j) * kThreads + tid) * 4;
         nvalid[j] = e0[j] >= a.n ? 0 : (a.n - e0[j] >= 4 ? 4 : (int)(a.n - e0[j]));
         all_full = all_full && nvalid[j] == 4;
 #pragma unroll
@@ -234,27 +225,10 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][k
             inv[j] = bf_philox_prepare((uint32_t)(e0[j] >> 2), (uint32_t)(e0[j] >> 34), a.stream, a.k0, a.k1);
         for (int s = s_begin; s < s_end; ++s) {
             f32x2_t q2 = {0.f, 0.f}, p2 = {0.f, 0.f};
-#if BF_SAMPLE_ADJ
-            f32x4_t wlo = {0.f, 0.f, 0.f, 0.f};
-#endif
-#ifdef BF_SAMPLE_HALF_PHILOX
-            bf_u32x4 xprev = {0u, 0u, 0u, 0u};
-#endif
 #pragma unroll
             for (int j = 0; j < G; ++j) {
                 float z[4];
-#ifdef BF_SAMPLE_HALF_PHILOX
-                // SPEED EXPERIMENT ONLY (wrong epsilon for the second group): one Philox block per TWO groups — twice the
-                // saving of "six normals per block"  — to bound what that contract change could gain
-                // (profiles/r5h_sampling_half_philox_bound.txt)
-                bf_u32x4 x;
-                if (j == 0) x = bf_philox_finish(inv[0], a.sample_base + (uint32_t)s, a.stream, a.k0, a.k1);
-                if (j == 0) { xprev = x; } else { x.x = xprev.x * 2654435761u; x.y = xprev.y ^ 0x9E3779B9u; x.z = xprev.z * 2246822519u; x.w = xprev.w ^ 0x85EBCA6Bu; }
-                bf_box_muller_dev(x.x, x.y, z[0], z[1]);
-                bf_box_muller_dev(x.z, x.w, z[2], z[3]);
-#else
                 bf_normal4_split_dev(inv[j], a.sample_base + (uint32_t)s, a.stream, a.k0, a.k1, z);
-#endif
                 const f32x2_t z01 = {z[0], z[1]}, z23 = {z[2], z[3]};
                 const f32x2_t w01 = __builtin_elementwise_fma(f32x2_t{sigma[j][0], sigma[j][1]}, z01, f32x2_t{mu[j][0], mu[j][1]});
                 const f32x2_t w23 = __builtin_elementwise_fma(f32x2_t{sigma[j][2], sigma[j][3]}, z23, f32x2_t{mu[j][2], mu[j][3]});
@@ -287,25 +261,11 @@ __device__ __forceinline__ void sample_body(const BodyArgs& a, float (*red)[4][k
                     p2 = __builtin_elementwise_fma(d01, d01, p2);
                     p2 = __builtin_elementwise_fma(d23, d23, p2);
                 }
-#if BF_SAMPLE_ADJ
-                static_assert(G == 2, "the adjacent-group store pairs two groups");
-                if (outp && out_dt == BF_DT_BF16) {  // both groups of the thread in one 16-byte store
-                    if (j == 0) { wlo = f32x4_t{w01[0], w01[1], w23[0], w23[1]}; continue; }
-                    const f32x8_t w8 = {wlo[0], wlo[1], wlo[2], wlo[3], w01[0], w01[1], w23[0], w23[1]};
-                    *reinterpret_cast<bf16x8_t*>(outp + ((unsigned long long)s * a.n + e0[0]) * 2) = __builtin_convertvector(w8, bf16x8_t);
-                    continue;
-                }
-#endif
                 if (outp) {
                     const unsigned long long idx = (unsigned long long)s * a.n + e0[j];
                     const f32x4_t w4 = {w01[0], w01[1], w23[0], w23[1]};
-#ifndef BF_SAMPLE_NT_STORES
-#define BF_SAMPLE_NT_STORES 0  // 1: the sampled weights leave through nontemporal stores (experiment, profiles/r5i_*)
-#endif
-                    if (out_dt == BF_DT_BF16) {
-                        if (BF_SAMPLE_NT_STORES) __builtin_nontemporal_store(__builtin_convertvector(w4, bf16x4_t), reinterpret_cast<bf16x4_t*>(outp + idx * 2));
-                        else *reinterpret_cast<bf16x4_t*>(outp + idx * 2) = __builtin_convertvector(w4, bf16x4_t);
-                    } else if (out_dt == BF_DT_F16) *reinterpret_cast<f16x4_t*>(outp + idx * 2) = __builtin_convertvector(w4, f16x4_t);
+                    if (out_dt == BF_DT_BF16) *reinterpret_cast<bf16x4_t*>(outp + idx * 2) = __builtin_convertvector(w4, bf16x4_t);
+                    else if (out_dt == BF_DT_F16) *reinterpret_cast<f16x4_t*>(outp + idx * 2) = __builtin_convertvector(w4, f16x4_t);
                     else *reinterpret_cast<f32x4_t*>(outp + idx * 4) = w4;
                 }
             }
@@ -431,13 +391,11 @@ struct TableEntry {
 // prior_kinds) — and the kernel is compiled for it alone: a launch of MOPED-aliased tensors (BERT with delta and
 // freeze=True: all of them) then needs 62-65 VGPRs = 8 waves per SIMD instead of the 80 / 6 of the kernel that must be able
 // to take every kind.
-#ifndef BF_SAMPLE_ONLY_WAVES
-#define BF_SAMPLE_ONLY_WAVES 8  // minimum waves per SIMD asked of the single-kind instantiations: 64 VGPRs (3 dwords of scratch)
+constexpr int kOnlyWaves = 8;  // minimum waves per SIMD asked of the single-kind instantiations: 64 VGPRs (3 dwords of scratch)
 // measured in the BERT-base step, one box, three interleaved runs each (profiles/r4e_sampling_kernel_occupancy_ab.txt):
 // kernel for every prior kind (80 VGPRs, 6 waves) 0.529-0.542 ms, single-kind at 68 VGPRs / 7 waves 0.520-0.527, at 64 / 8 waves 0.514-0.522
-#endif
 template <int ONLY>
-__global__ __launch_bounds__(kThreads, ONLY >= 0 ? BF_SAMPLE_ONLY_WAVES : 1) void bf_sample_table_kernel(const TableEntry* __restrict__ table,
+__global__ __launch_bounds__(kThreads, ONLY >= 0 ? kOnlyWaves : 1) void bf_sample_table_kernel(const TableEntry* __restrict__ table,
                                                                    const uint32_t* __restrict__ entry_of_block,
                                                                    uint32_t block0, int S, int ny, uint32_t k0,
                                                                    uint32_t k1, uint32_t sample_base,
@@ -467,59 +425,6 @@ __global__ __launch_bounds__(kThreads, ONLY >= 0 ? BF_SAMPLE_ONLY_WAVES : 1) voi
     else sample_body<BF_PRIOR_NONE, OUT_RUNTIME>(a, red, cst);
 }
 
-#ifndef BF_SAMPLE_PAIR
-#define BF_SAMPLE_PAIR 0  // experiment: at S <= BF_SAMPLE_PAIR samples per launch a workgroup takes TWO
-// consecutive table blocks and has the mu / rho loads of the second in flight while it works on the first (the memory-bound
-// regime of the strong-scaling shards: S_local = 1, 2).  Measured: profiles/r5e_sampling_pair_ab.txt — not adopted.
-#endif
-#if BF_SAMPLE_PAIR
-template <int ONLY>
-__global__ __launch_bounds__(kThreads) void bf_sample_table_pair_kernel(const TableEntry* __restrict__ table,
-                                                                        const uint32_t* __restrict__ entry_of_block,
-                                                                        uint32_t block0, uint32_t block_end, int S, int ny,
-                                                                        uint32_t k0, uint32_t k1, uint32_t sample_base,
-                                                                        const uint32_t* __restrict__ counter,
-                                                                        double* __restrict__ partials, uint32_t* stale) {
-    __shared__ float red[4][4][kMaxSChunk][2];
-    __shared__ float cst[4][2];
-    const int tid = threadIdx.x;
-    const uint32_t base = sample_base + (counter ? *counter : 0u);
-    auto args_of = [&](uint32_t gb) {
-        const TableEntry& e = table[entry_of_block[gb]];
-        BodyArgs a;
-        a.mu = e.mu; a.rho = e.rho; a.mu_p = e.mu_p; a.rho_p = e.rho_p; a.out = e.out; a.n = e.n;
-        a.a1 = e.a1; a.b1 = e.b1; a.a2 = e.a2; a.b2 = e.b2;
-        a.stream = e.stream; a.rel_block = gb - e.block_begin;
-        a.vec_in = e.vec_in; a.vec_out = e.vec_out; a.out_dt = e.out_dt;
-        a.S = S; a.ny = ny; a.k0 = k0; a.k1 = k1; a.sample_base = base;
-        a.partial_row = partials + (size_t)gb * S * 2;
-        a.chk = e.chk; a.rho_alias = e.rho_alias; a.stale = stale;
-        return a;
-    };
-    const uint32_t gb0 = block0 + 2 * blockIdx.x, gb1 = gb0 + 1;
-    const BodyArgs a0 = args_of(gb0);
-    if (gb1 >= block_end) {
-        sample_body<ONLY, OUT_RUNTIME>(a0, red, cst);
-        return;
-    }
-    const BodyArgs a1 = args_of(gb1);
-    // the second block's parameters first (they return first: loads complete in order), when all of its groups are full
-    const bool full = a1.vec_in && ((unsigned long long)(a1.rel_block + 1) * kThreads * kEPT <= a1.n);
-    PreLoaded pre;
-    if (full) {
-#pragma unroll
-        for (int j = 0; j < kGPT; ++j) {
-            const unsigned long long e = (((unsigned long long)a1.rel_block * kGPT + j) * kThreads + tid) * 4;
-            pre.mu[j] = *reinterpret_cast<const f32x4_t*>(a1.mu + e);
-            pre.rho[j] = *reinterpret_cast<const f32x4_t*>(a1.rho + e);
-        }
-    }
-    sample_body<ONLY, OUT_RUNTIME>(a0, red, cst);
-    __syncthreads();  // the first block's final LDS reads before the second block's writes
-    if (full) sample_body<ONLY, OUT_RUNTIME, true>(a1, red, cst, &pre);
-    else sample_body<ONLY, OUT_RUNTIME>(a1, red, cst);
-}
-#endif
 
 // out[g][s][j] = sum of partial rows [rows[g], rows[g+1]) in a fixed order.  grid = (2*S, G).
 __global__ __launch_bounds__(256) void bf_reduce_groups_kernel(const double* __restrict__ partials,
@@ -774,15 +679,6 @@ int bf_launch_sample_table(const void* d_blob, int n_tensors, uint32_t block_beg
                                                             bf_align_up((size_t)n_tensors * sizeof(TableEntry), 256));
     const uint32_t blk = block_end - block_begin;
     const int ny = pick_ny(blk, S);
-#if BF_SAMPLE_PAIR
-    if (S <= BF_SAMPLE_PAIR && ny == 1 && prior_kinds == (1 << PRIOR_GAUSS_ALIAS)) {
-        hipLaunchKernelGGL(bf_sample_table_pair_kernel<PRIOR_GAUSS_ALIAS>, dim3((blk + 1) / 2, 1), dim3(kThreads), 0, stream, ent,
-                           map, block_begin, block_end, S, ny, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base,
-                           bf_sample_counter(), d_partials, bf_stale_counter_dev());
-        BF_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
-#endif
 #define BF_TABLE_LAUNCH(ONLY)                                                                                          \
     hipLaunchKernelGGL(bf_sample_table_kernel<ONLY>, dim3(blk, (uint32_t)ny), dim3(kThreads), 0, stream, ent, map,      \
                        block_begin, S, ny, (uint32_t)seed, (uint32_t)(seed >> 32), sample_base, bf_sample_counter(), d_partials, \

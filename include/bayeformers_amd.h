@@ -203,6 +203,13 @@ int bf_gemm_prepare(int S, int L, int M, int N, void* stream);
  * height 0.  Entry = {pair = l * S + s, s, n_tile | h << 24, first row}.  Returns the number of int32 values the
  * table holds (4 * rounds * grid); fills `out` only when cap_values is large enough. */
 size_t bf_gemm_schedule(int S, int L, int M, int N, int n_cu, int32_t* out, size_t cap_values, int* rounds, int* grid);
+/* The same under another schedule policy (policy < 0: the library's default; bits in csrc/bf_gemm256_dev.h) — for
+ * tools/sched_l2_sim.py and the A/B of policies; and the model the library chooses a policy's column grouping by:
+ * bf_gemm_schedule_fetch_rows = rows of K elements the eight per-XCD L2s fetch over the fabric for a table (workgroup b on
+ * XCD b % 8, the workgroups of an XCD in k-lockstep on their j-th tiles, nothing kept between rounds), validated against
+ * TCC_EA0_RDREQ in profiles/r6b_sched_l2_model.md.  Multiply by K * element size for bytes.  -1 on bad arguments. */
+size_t bf_gemm_schedule_policy(int S, int L, int M, int N, int n_cu, int policy, int32_t* out, size_t cap_values, int* rounds, int* grid);
+int64_t bf_gemm_schedule_fetch_rows(const int32_t* table, int rounds, int grid);
 
 /* The whole of Linear.forward (layers/linear.py:83-104) for S Monte-Carlo samples in one call:
  * sample W_s and b_s, accumulate both log-probs, y[s] = x[s] W_s^T + b_s.
