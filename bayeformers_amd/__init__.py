@@ -23,7 +23,7 @@ from .ops import invalidate_caches  # noqa: F401
 from .random import (get_compute_dtype, manual_seed, set_compute_dtype, set_kl_gradient,  # noqa: F401
                      use_device_counter)
 
-__all__ = ["to_bayesian", "invalidate_caches", "fuse_activations", "fuse_residual_layernorm", "fuse_shared_inputs", "fuse_ffn_pairs", "fuse_attention", "fuse_embeddings", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
+__all__ = ["to_bayesian", "invalidate_caches", "fuse_activations", "fuse_residual_layernorm", "fuse_shared_inputs", "fuse_attention", "fuse_embeddings", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
            "use_device_counter", "set_kl_gradient"]
 
 
@@ -133,66 +133,6 @@ def _layernorm_forward(self, input):
     if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad):
         return ops.AddLayerNormFn.apply(input, None, self.weight, self.bias, self.eps)
     return ops.add_layernorm(input, None, self.weight, self.bias, self.eps)
-
-
-def _ffn_pair_chunk(self, attention_output):
-    """`feed_forward_chunk` of an HF transformer layer — output(intermediate(a), a) — with the two Bayesian dense layers
-    run window by window of the Monte-Carlo sample axis (ops.ffn_pair_forward) when that applies: an S-sample inference
-    forward whose two layers were sampled by the model's cross-layer plan, GELU fused into the first.  Anything else (a
-    gradient is needed, a single sample, layers outside the plan) runs the module's own method."""
-    from . import ops
-
-    up, down = self.intermediate.dense, self.output.dense
-    ctx = bfr.STATE.ctx
-    a = attention_output
-    windows = self._bf_ffn_windows
-    plan = ctx.plan if ctx is not None else None
-    usable = (plan is not None and windows > 1 and ctx.S >= 2 and id(up) in plan.group_of and id(down) in plan.group_of
-              and not up._small_m and not down._small_m and up.activation == "gelu" and down.activation is None
-              and isinstance(self.intermediate.intermediate_act_fn, _FusedIntoDense)
-              and up._shared_input is None and down._shared_input is None
-              and a.is_cuda and a.dtype in (torch.bfloat16, torch.float16) and a.shape[-1] == up.in_features
-              and (a.numel() // up.in_features) % ctx.S == 0 and (a.numel() // up.in_features) // ctx.S > 64)
-    if usable:
-        need_grad = torch.is_grad_enabled() and (a.requires_grad or any(p.requires_grad for l in (up, down) for p in l.parameters()))
-        usable = not need_grad and not (self.training and self.output.dropout.p > 0)
-    if not usable:
-        return self._bf_plain_ffn_chunk(attention_output)
-    S = ctx.S
-    seed, base = bfr.STATE.seed, ctx.sample_base
-    w1, b1 = plan.ensure(up, ctx.token, seed, base, ctx.lp_buf)
-    w2, b2 = plan.ensure(down, ctx.token, seed, base, ctx.lp_buf)
-    if w1.dtype != a.dtype or w2.dtype != a.dtype:
-        return self._bf_plain_ffn_chunk(attention_output)
-    y = ops.ffn_pair_forward(a.reshape(-1, up.in_features), w1, b1, w2, b2, S, 1, min(windows, S))
-    for l in (up, down):  # what Linear.forward leaves behind: the log-probs of this forward are the plan's
-        l._lp_view, l._lp_dirty = ctx.slot(l), True
-    y = y.view(*a.shape[:-1], down.out_features)
-    out = self.output
-    if getattr(out.LayerNorm, "_bf_fused", False) and isinstance(out.forward, types.MethodType) and out.forward.__func__ is _dense_residual_norm_forward:
-        return _residual_norm(out, y, a)
-    return out.LayerNorm(out.dropout(y) + a)
-
-
-def fuse_ffn_pairs(model: torch.nn.Module, windows: int = 2) -> int:
-    """Run the feed-forward pair of every HuggingFace-style transformer layer (modules with `intermediate.dense` and
-    `output.dense` as bnn.Linear children and a `feed_forward_chunk` method) window by window of the Monte-Carlo sample
-    axis: FFN-up then FFN-down for the first ceil(S / windows) samples, then for the next — the intermediate of a window
-    (BERT-base, S = 10: 126 MB per half) is read back while it is still in the Infinity Cache.  Call after
-    `fuse_activations`.  Inference-time rewrite like the other fuse_* functions.  Returns the number of layers rewritten."""
-    fused = 0
-    for m in model.modules():
-        inter, out = getattr(m, "intermediate", None), getattr(m, "output", None)
-        if (inter is not None and out is not None and isinstance(getattr(inter, "dense", None), nn.Linear)
-                and isinstance(getattr(out, "dense", None), nn.Linear) and hasattr(m, "feed_forward_chunk")
-                and isinstance(getattr(out, "LayerNorm", None), torch.nn.LayerNorm) and hasattr(out, "dropout")
-                and inter.dense.out_features == out.dense.in_features):
-            if not hasattr(m, "_bf_plain_ffn_chunk"):
-                m._bf_plain_ffn_chunk = m.feed_forward_chunk
-                m.feed_forward_chunk = types.MethodType(_ffn_pair_chunk, m)
-                fused += 1
-            m._bf_ffn_windows = int(windows)
-    return fused
 
 
 def fuse_residual_layernorm(model: torch.nn.Module) -> int:

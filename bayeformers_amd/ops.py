@@ -420,27 +420,6 @@ def planned_linear_forward(x: Tensor, w_s: Tensor, b_s: Optional[Tensor], S: int
     return gemm_nt(x, w_s, b_s, S, M, N, K, M * K, x.dtype, act).view(S * M, N)
 
 
-def ffn_pair_forward(x: Tensor, w1: Tensor, b1: Optional[Tensor], w2: Tensor, b2: Optional[Tensor], S: int, act: int,
-                     windows: int) -> Tensor:
-    """down(act(up(x))) of two sampled-weight layers back to back, run WINDOW BY WINDOW of the sample axis: for each
-    window of ceil(S / windows) samples the up-projection's launch is followed at once by the down-projection's, so the
-    [window, M, N1] intermediate the second launch reads is what the first has just written — small enough to still be in
-    the 256 MB Infinity Cache (BERT-base, S = 10: 252 MB per layer in one piece, 126 MB per half) — instead of a tensor
-    that has been pushed out to HBM by its own tail.  x: [S*M, K] sample-major; w1 [S,N1,K], w2 [S,N2,N1] as the sampling
-    plan lays them out; returns [S*M, N2].  Same launches, same values as the two layers run one after the other."""
-    K, N1, N2 = w1.shape[2], w1.shape[1], w2.shape[1]
-    x = x if x.is_contiguous() else x.contiguous()
-    M = x.shape[0] // S
-    y = torch.empty((S, M, N2), dtype=x.dtype, device=x.device)
-    xs = x.view(S, M, K)
-    per = -(-S // max(1, int(windows)))
-    for s0 in range(0, S, per):
-        sc = min(per, S - s0)
-        h = gemm_nt(xs[s0:s0 + sc], w1[s0:s0 + sc], b1[s0:s0 + sc] if b1 is not None else None, sc, M, N1, K, M * K, x.dtype, act)
-        gemm_nt(h, w2[s0:s0 + sc], b2[s0:s0 + sc] if b2 is not None else None, sc, M, N2, N1, M * N1, x.dtype, 0, out=y[s0:s0 + sc])
-    return y.view(S * M, N2)
-
-
 COLSUMS_FOLDED = [0]  # bias gradients whose column sums came with the output gradient (tests, diagnostics)
 
 # Column sums a gradient's PRODUCER left for its consumer (attention_backward -> linear_backward of query / key / value).

@@ -197,7 +197,6 @@ def build_bert(device, dtype):
     n_qkv = bf.fuse_shared_inputs(bmodel) if os.environ.get("BF_BENCH_NO_QKV_FUSION") is None else 0
     attn = bf.fuse_attention(bmodel) if os.environ.get("BF_BENCH_NO_ATTENTION") is None else False
     n_emb = bf.fuse_embeddings(bmodel) if os.environ.get("BF_BENCH_NO_EMBED_FUSION") is None else 0
-    n_ffn = bf.fuse_ffn_pairs(bmodel, int(os.environ.get("BF_BENCH_FFN_WINDOWS", "1")))
     if dtype != "fp32":
         bmodel = bmodel.to(torch.bfloat16 if dtype == "bf16" else torch.float16)
     g = torch.Generator().manual_seed(321)
@@ -205,8 +204,7 @@ def build_bert(device, dtype):
     labels = torch.randint(0, 2, (B,), generator=g)
     inputs = {"input_ids": ids.to(device), "attention_mask": torch.ones(B, L, dtype=torch.long, device=device)}
     info = {"gelu_fused_into_gemm": n_fused, "residual_layernorm_fused": n_ln, "qkv_in_one_launch": n_qkv,
-            "attention_kernel": bool(attn), "embeddings_in_one_launch": n_emb,
-            "ffn_pairs_windowed": n_ffn if int(os.environ.get("BF_BENCH_FFN_WINDOWS", "1")) > 1 else 0}
+            "attention_kernel": bool(attn), "embeddings_in_one_launch": n_emb}
     return bmodel, model, inputs, ids, labels, info
 
 
@@ -583,26 +581,20 @@ def measure_traffic(args):
         req, lvl = gemm.get("TCC_EA0_RDREQ_sum", []), gemm.get("TCC_EA0_RDREQ_LEVEL_sum", [])
         if shapes and len(req) > n_cal and len(req) == len(lvl) and len(gemm["FETCH_SIZE"]) == len(req):
             P = len(shapes)
-            # the launches of one encoder layer, by position: Q/K/V, attention-out, then FFN-up / FFN-down once per window of
-            # the sample axis (bayeformers_amd.fuse_ffn_pairs: BF_BENCH_FFN_WINDOWS)
-            S_run = args.samples or DEFAULTS[args.workload][0]
-            per = -(-S_run // max(1, min(int(os.environ.get("BF_BENCH_FFN_WINDOWS", "1")), S_run)))
-            pattern = [0, 1] + [2, 3] * (-(-S_run // per))
             by_pos, hbm = {}, 0.0
             for pos in range(P):
                 cold = lvl[3 * pos + 1] / req[3 * pos + 1]
                 hot = lvl[3 * pos + 2] / req[3 * pos + 2]
-                idx = [i for i in range(n_cal, len(req)) if pattern[(i - n_cal) % len(pattern)] == pos]
+                idx = [i for i in range(n_cal, len(req)) if (i - n_cal) % P == pos]
                 lat = sum(lvl[i] for i in idx) / sum(req[i] for i in idx)
-                # bytes per layer and position (a windowed position's launches add up)
-                fbytes = 2.0 * 1024.0 * sum(gemm["FETCH_SIZE"][i] for i in idx) / (len(idx) / pattern.count(pos))
+                fbytes = 2.0 * 1024.0 * mean([gemm["FETCH_SIZE"][i] for i in idx])
                 f = min(1.0, max(0.0, (cold - lat) / (cold - hot))) if cold > hot else None
                 by_pos[GEMM_POSITIONS[pos]] = {"fabric_fetch": round(fbytes), "ea_read_latency_clk": {
                     "operands_in_hbm": round(cold, 1), "operands_cache_resident": round(hot, 1), "in_step": round(lat, 1)},
                     "infinity_cache_hit_fraction": None if f is None else round(f, 3)}
                 hbm += fbytes * (1.0 - (f if f is not None else 0.0))
             res["by_position"] = by_pos
-            res["hbm_read_bytes_est"] = hbm / len(pattern)
+            res["hbm_read_bytes_est"] = hbm / P
             res["infinity_cache_hit_fraction_est"] = round(1.0 - res["hbm_read_bytes_est"] / fetch, 3) if fetch > 0 else None
         return res
     except Exception:
