@@ -85,15 +85,15 @@ SYMBOLS = {
     "bf_add_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, ctypes.c_float, _vp]),
     "bf_dropout_keep_host": (_i, [_vp, _u64, _u64, ctypes.c_float, _u64, _u32, _u32]),
     "bf_attention_fwd_dropout": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64, ctypes.c_float,
-                                      ctypes.c_float, _u64, _u32, _u32, _u64, _vp, _vp]),
+                                      ctypes.c_float, _u64, _u32, _u32, _u64, _vp, _vp, _vp]),
     "bf_attention_bwd_dropout": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64,
                                       ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "bf_add_layernorm_dropout": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, ctypes.c_float, ctypes.c_float, _u64, _u32,
-                                      _u32, _u64, _vp]),
+                                      _u32, _u64, _vp, _vp]),
     "bf_add_layernorm_dropout_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i64, _i, ctypes.c_float,
-                                          ctypes.c_float, _u64, _u32, _u32, _u64, _vp]),
+                                          ctypes.c_float, _u64, _u32, _u32, _u64, _vp, _vp]),
     "bf_add_layernorm_bwd_sum": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i64, _i, ctypes.c_float,
-                                      ctypes.c_float, _u64, _u32, _u32, _u64, _vp]),
+                                      ctypes.c_float, _u64, _u32, _u32, _u64, _vp, _vp]),
     "bf_attention_bwd_colsum": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i64,
                                      ctypes.c_float, ctypes.c_float, _vp, _i, _vp, _vp, _vp]),
     "bf_profile_enable": (_i, [_i]),
@@ -104,11 +104,12 @@ SYMBOLS = {
     "bf_fused_small_rows_for": (_i, [_i, _i]),
     "bf_profile_read": (_i, [_i, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double),
                              ctypes.POINTER(ctypes.c_double)]),
+    "bf_profile_read_launches": (_sz, [_i, _vp, _vp, _sz]),
 }
 BF_PROF_SAMPLE, BF_PROF_GEMM, BF_PROF_FUSED_SMALL, BF_PROF_FUSED_WS = 0, 1, 2, 3
 BF_ACT_NONE, BF_ACT_GELU = 0, 1
 
-ABI_VERSION = 5  # bf_version() of the library these bindings describe (include/bayeformers_amd.h: BF_VERSION_*)
+ABI_VERSION = 6  # bf_version() of the library these bindings describe (include/bayeformers_amd.h: BF_VERSION_*)
 
 # developer-build entry points (csrc/bf_dev_api.h): bound when the loaded library has them (BF_LIB_PATH=..._dev.so)
 DEV_SYMBOLS = {

@@ -86,7 +86,7 @@ def fuse_activations(model: torch.nn.Module) -> int:
         act = getattr(m, "intermediate_act_fn", None)
         if isinstance(dense, nn.Linear) and act is not None and _is_exact_gelu(act):
             dense.activation = "gelu"
-            m.intermediate_act_fn = _FusedIntoDense()
+            m.intermediate_act_fn = _FusedIntoDense().train(m.training)  # (a fresh module would be in training mode)
             fused += 1
     return fused
 
@@ -103,12 +103,13 @@ def _residual_norm(self, hidden_states, input_tensor):
     from . import ops
 
     ln = self.LayerNorm
-    dropping = self.training and self.dropout.p > 0
+    dropping = self.dropout.training and self.dropout.p > 0  # (the dropout module's own mode, as its forward reads it)
     if not ops.layernorm_supported(hidden_states, input_tensor, ln):
         return ln((self.dropout(hidden_states) if dropping else hidden_states) + input_tensor)
     # training mode (/root/reference/examples/bert_glue.py:221): the hidden dropout runs INSIDE the kernel, its Philox mask
     # regenerated in the backward pass — no mask tensor, no extra pass over the dense output
-    drop = ops.Dropout(self.dropout.p, bfr.STATE.seed, bfr.dropout_call(), bfr.dropout_site(self), bfr.dropout_origin()) if dropping else None
+    drop = ops.Dropout(self.dropout.p, bfr.STATE.seed, bfr.dropout_call(), bfr.dropout_site(self), bfr.dropout_origin(),
+                       bfr.dropout_counter()) if dropping else None
     if torch.is_grad_enabled() and (hidden_states.requires_grad or input_tensor.requires_grad or ln.weight.requires_grad):
         if ops._NO_TWIN:
             return ops.AddLayerNormFn.apply(hidden_states, input_tensor, ln.weight, ln.bias, ln.eps, drop)
@@ -167,7 +168,7 @@ def _embeddings_forward(self, input_ids=None, token_type_ids=None, position_ids=
     from . import ops
 
     w, t, p, ln = self.word_embeddings, self.token_type_embeddings, self.position_embeddings, self.LayerNorm
-    dropping = self.training and self.dropout.p > 0
+    dropping = self.dropout.training and self.dropout.p > 0
     plain = (input_ids is not None and inputs_embeds is None and input_ids.dim() == 2 and input_ids.is_cuda
              and input_ids.dtype == torch.long
              and not (torch.is_grad_enabled() and (w.weight.requires_grad or t.weight.requires_grad or
@@ -306,7 +307,8 @@ def _attention_interface(module, query, key, value, attention_mask, dropout: flo
             attention_mask = attention_mask.to(query.dtype)  # the framework's kernels want bool or the query's dtype
         return sdpa_attention_forward(module, query, key, value, attention_mask, dropout=dropout, scaling=scaling, **kwargs)
     scale = scaling if scaling is not None else query.shape[-1] ** -0.5
-    drop = ops.Dropout(dropout, bfr.STATE.seed, bfr.dropout_call(), bfr.dropout_site(module), bfr.dropout_origin()) if dropout > 0.0 else None
+    drop = ops.Dropout(dropout, bfr.STATE.seed, bfr.dropout_call(), bfr.dropout_site(module), bfr.dropout_origin(),
+                       bfr.dropout_counter()) if dropout > 0.0 else None
     if need_grad:  # training: the same kernel, with bf_attention_bwd behind it
         return ops.AttentionFn.apply(query, key, value, key_mask, mask_off, scale, drop), None
     return ops.attention_forward(query, key, value, key_mask, scale, mask_off, drop=drop), None

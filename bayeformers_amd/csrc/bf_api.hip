@@ -155,6 +155,22 @@ int bf_profile_read(int kind, uint64_t* launches, double* total_ms, double* tota
     return 0;
 }
 
+size_t bf_profile_read_launches(int kind, float* ms, double* work, size_t cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    size_t n = 0;
+    for (auto& e : g_prof) {
+        if (e.kind != kind) continue;
+        if (n < cap && (ms || work)) {
+            float t = 0.f;
+            if (hipEventSynchronize(e.stop) != hipSuccess || hipEventElapsedTime(&t, e.start, e.stop) != hipSuccess) t = -1.f;
+            if (ms) ms[n] = t;
+            if (work) work[n] = e.work;
+        }
+        ++n;
+    }
+    return n;
+}
+
 int bf_version(void) { return BF_VERSION_MAJOR * 1000 + BF_VERSION_MINOR; }
 
 int bf_stale_counter(const uint32_t** h_counter) {
@@ -454,8 +470,10 @@ int bf_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const fl
                                    dtype, B, T, H, head_dim, token_stride, scaling, (hipStream_t)stream);
 }
 
-static bf_dropout_t make_dropout(float p_drop, uint64_t seed, uint32_t call, uint32_t site, uint64_t first_group = 0) {
+static bf_dropout_t make_dropout(float p_drop, uint64_t seed, uint32_t call, uint32_t site, uint64_t first_group = 0,
+                                 const uint32_t* d_call = nullptr) {
     bf_dropout_t d;
+    d.d_call = d_call;
     d.k0 = (uint32_t)seed;
     d.k1 = (uint32_t)(seed >> 32);
     d.call = call;
@@ -483,9 +501,9 @@ int bf_dropout_keep_host(uint8_t* out, uint64_t first_group, uint64_t n_groups, 
 int bf_attention_fwd_dropout(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
                              void* d_out, float* d_lse, int dtype, int B, int T, int H, int head_dim, int64_t token_stride,
                              float scaling, float p_drop, uint64_t seed, uint32_t call, uint32_t site, uint64_t first_group, uint32_t* d_keep_bits,
-                             void* stream) {
+                             const uint32_t* d_call, void* stream) {
     if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_attention_fwd_dropout: p must be in [0, 1) (got %g)", p_drop);
-    const bf_dropout_t d = make_dropout(p_drop, seed, call, site, first_group);
+    const bf_dropout_t d = make_dropout(p_drop, seed, call, site, first_group, d_call);
     return bf_launch_attention_fwd(d_q, d_k, d_v, d_mask, d_mask_off, d_out, d_lse, dtype, B, T, H, head_dim, token_stride,
                                    scaling, (hipStream_t)stream, &d, d_keep_bits);
 }
@@ -518,9 +536,9 @@ int bf_attention_bwd_colsum(const void* d_q, const void* d_k, const void* d_v, c
 
 int bf_add_layernorm_dropout(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, int param_dtype,
                              void* d_out, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed, uint32_t call,
-                             uint32_t site, uint64_t first_group, void* stream) {
+                             uint32_t site, uint64_t first_group, const uint32_t* d_call, void* stream) {
     if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_add_layernorm_dropout: p must be in [0, 1) (got %g)", p_drop);
-    const bf_dropout_t d = make_dropout(p_drop, seed, call, site, first_group);
+    const bf_dropout_t d = make_dropout(p_drop, seed, call, site, first_group, d_call);
     return bf_launch_add_layernorm(d_x, d_residual, d_gamma, d_beta, param_dtype, d_out, dtype, rows, N, eps,
                                    (hipStream_t)stream, &d);
 }
@@ -528,9 +546,9 @@ int bf_add_layernorm_dropout(const void* d_x, const void* d_residual, const void
 int bf_add_layernorm_dropout_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
                                  const void* d_dy, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
                                  size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
-                                 uint32_t call, uint32_t site, uint64_t first_group, void* stream) {
+                                 uint32_t call, uint32_t site, uint64_t first_group, const uint32_t* d_call, void* stream) {
     if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_add_layernorm_dropout_bwd: p must be in [0, 1) (got %g)", p_drop);
-    const bf_dropout_t d = make_dropout(p_drop, seed, call, site, first_group);
+    const bf_dropout_t d = make_dropout(p_drop, seed, call, site, first_group, d_call);
     return bf_launch_add_layernorm_bwd(d_x, d_residual, d_gamma, param_dtype, d_dy, d_dz, d_dgamma, d_dbeta, d_workspace,
                                        workspace_bytes, dtype, rows, N, eps, (hipStream_t)stream, &d, d_dx);
 }
@@ -538,9 +556,9 @@ int bf_add_layernorm_dropout_bwd(const void* d_x, const void* d_residual, const 
 int bf_add_layernorm_bwd_sum(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,
                              const void* d_dy2, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
                              size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
-                             uint32_t call, uint32_t site, uint64_t first_group, void* stream) {
+                             uint32_t call, uint32_t site, uint64_t first_group, const uint32_t* d_call, void* stream) {
     if (!(p_drop >= 0.f) || !(p_drop < 1.f)) BF_FAIL("bf_add_layernorm_bwd_sum: p must be in [0, 1) (got %g)", p_drop);
-    const bf_dropout_t d = make_dropout(p_drop, seed, call, site, first_group);
+    const bf_dropout_t d = make_dropout(p_drop, seed, call, site, first_group, d_call);
     return bf_launch_add_layernorm_bwd(d_x, d_residual, d_gamma, param_dtype, d_dy, d_dz, d_dgamma, d_dbeta, d_workspace,
                                        workspace_bytes, dtype, rows, N, eps, (hipStream_t)stream, d.thresh ? &d : nullptr, d_dx,
                                        d_dy2);

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 3) void attention_fwd_kernel(const AttnParams 
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const unsigned long long g = g0 + 4ull * c;
-                    const uint32_t keep = bf_dropout_keep8((uint32_t)g, (uint32_t)(g >> 32), p.drop.call, p.drop.site,
+                    const uint32_t keep = bf_dropout_keep8((uint32_t)g, (uint32_t)(g >> 32), bf_dropout_call(p.drop), p.drop.site,
                                                            p.drop.k0, p.drop.k1, p.drop.thresh);
                     word |= keep << (8 * c);
 #pragma unroll
@@ -283,7 +283,7 @@ int bf_launch_attention_fwd(const void* d_q, const void* d_k, const void* d_v, c
 #endif
     const dim3 grid(T / TQ, H, B);
     p.keep_bits = nullptr;
-    p.drop = bf_dropout_t{0, 0, 0, 0, 0, 1.0f};
+    p.drop = bf_dropout_t{0, 0, 0, 0, 0, 1.0f, 0, 0, nullptr};
     if (drop && drop->thresh) {
         if (d_keep_bits && ((uintptr_t)d_keep_bits & 3)) BF_FAIL("bf_attention_fwd: keep bits must be 4-byte aligned");
         p.drop = *drop;

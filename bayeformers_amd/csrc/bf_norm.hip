@@ -57,7 +57,7 @@ constexpr int kRowsPerBlock = 4;  // one wave per row
 // the 8-element vector `vec` (= 8 consecutive features) of row `row` is dropout group row * (N / 8) + vec of bf_philox.h
 __device__ __forceinline__ uint32_t drop8_bits(const bf_dropout_t& d, long long row, int nvec, int vec) {
     const unsigned long long g = (unsigned long long)row * (unsigned)nvec + (unsigned)vec + (((unsigned long long)d.g0_hi << 32) | d.g0_lo);
-    return bf_dropout_keep8((uint32_t)g, (uint32_t)(g >> 32), d.call, d.site, d.k0, d.k1, d.thresh);
+    return bf_dropout_keep8((uint32_t)g, (uint32_t)(g >> 32), bf_dropout_call(d), d.site, d.k0, d.k1, d.thresh);
 }
 __device__ __forceinline__ void drop8_apply(const bf_dropout_t& d, uint32_t keep, float (&v)[8]) {
 #pragma unroll
@@ -330,7 +330,7 @@ int launch_bwd_vpl(const void* x, const void* res, const void* gamma, const void
     const int nvec = N >> 3;
     const size_t lds = (size_t)kRowsPerBlock * 2 * N * sizeof(float);
     const dim3 grid((unsigned)nblocks), block(64 * kRowsPerBlock);
-    const bf_dropout_t d = drop ? *drop : bf_dropout_t{0, 0, 0, 0, 0, 1.0f, 0, 0};
+    const bf_dropout_t d = drop ? *drop : bf_dropout_t{0, 0, 0, 0, 0, 1.0f, 0, 0, nullptr};
 #define BF_LNB_LAUNCH(VPL)                                                                                                  \
     do {                                                                                                                    \
         if (d.thresh)                                                                                                       \
@@ -355,7 +355,7 @@ template <typename T, typename GT>
 int launch_vpl(const void* x, const void* res, const void* gamma, const void* beta, void* out, long long rows, int N,
                float eps, hipStream_t stream, const bf_dropout_t* drop) {
     const int nvec = N >> 3;
-    const bf_dropout_t d = drop ? *drop : bf_dropout_t{0, 0, 0, 0, 0, 1.0f, 0, 0};
+    const bf_dropout_t d = drop ? *drop : bf_dropout_t{0, 0, 0, 0, 0, 1.0f, 0, 0, nullptr};
     if (nvec % 32 == 0 && nvec <= 128) {  // N = 256, 512, 768, 1024: half a wave per row
         const dim3 hgrid((unsigned)((rows + 2 * kRowsPerBlock - 1) / (2 * kRowsPerBlock))), hblock(64 * kRowsPerBlock);
 #define BF_LNH_LAUNCH(V)                                                                                                \

@@ -122,9 +122,15 @@ struct bf_dropout_t {
     // group index of the tensor's FIRST group in the step's GLOBAL numbering: an S-sharded rank passes (first global sample
     // of its shard) x (groups per sample), so that sample s draws the same masks whichever rank — or how many — run it
     uint32_t g0_lo, g0_hi;
+    // device-resident part of `call` (NULL: none): the kernels use call + *d_call.  What makes a training step replayable from
+    // a HIP graph: the graph bakes the host-side `call`, a one-element counter the captured step copies and increments moves
+    // every replay on to fresh masks (the sample counter's scheme, bf_set_sample_counter)
+    const uint32_t* d_call;
 };
 
 #if defined(__HIPCC__) || defined(__HIP__)
+BF_D uint32_t bf_dropout_call(const bf_dropout_t& d) { return d.call + (d.d_call ? *d.d_call : 0u); }
+
 // Device Box-Muller on the hardware transcendental units.
 //   v_log_f32 is log2; v_sin_f32 / v_cos_f32 take their argument in revolutions (valid for |x| <= 256).
 BF_D void bf_box_muller_dev(uint32_t a, uint32_t b, float& z0, float& z1) {

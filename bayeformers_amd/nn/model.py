@@ -22,6 +22,7 @@ from torch.nn import Module
 
 from .. import ops
 from .. import random as bfr
+from ..graphs import GraphCache, auto_forward
 from ..plan import SamplePlan
 from .layers.base import KernelLayer
 from .layers.linear import Linear
@@ -41,7 +42,7 @@ class _ForwardContext:
     """What the Bayesian layers of one Model.forward share: the reserved sample indices, their log-prob slots and
     (when every layer is plannable) the cross-layer sampling plan."""
 
-    def __init__(self, sample_base: int, S: int, slots: dict, plan=None, lp_buf=None, shard_start: int = 0):
+    def __init__(self, sample_base: int, S: int, slots: dict, plan=None, lp_buf=None, shard_start: int = 0, dropping: bool = True):
         self.sample_base, self.S, self._slots = sample_base, S, slots
         self.plan, self.lp_buf = plan, lp_buf
         self.token = next(_TOKENS)
@@ -56,6 +57,7 @@ class _ForwardContext:
         # shard within the step) is where the kernels start numbering their dropout groups (ops.Dropout.first_group): a
         # sample's masks are a function of its GLOBAL index, so S-sharded training draws the single-process masks
         self.drop_call = bfr.reserve_dropout_call()
+        self.drop_counter = bfr.reserve_dropout_counter(needed=dropping)  # device-counter mode: this forward's copy of it
         self.shard_start = int(shard_start)
 
     @contextlib.contextmanager
@@ -65,10 +67,12 @@ class _ForwardContext:
         arenas are reused; overwritten ones are drawn again from the same counters."""
         prev = bfr.STATE.ctx
         bfr.STATE.ctx = self
+        self._replaying = True
         try:
             with bfr.counter_override(self.counter):
                 yield self
         finally:
+            self._replaying = False
             bfr.STATE.ctx = prev
             if self.plan is not None and prev is None:
                 self.plan.pending.clear()  # the log-probs of these samples were reduced when the forward ended
@@ -121,6 +125,10 @@ class Model(Module):
         self._last_base = None
         self._plan: Optional[SamplePlan] = None
         self.cross_layer_sampling = True  # one sampling launch per ~96 MB group of layers instead of one per layer
+        # evaluation forwards (eval mode, no_grad, one sample per call: the reference's own caller loop,
+        # /root/reference/examples/bert_glue.py:63-66) are replayed from a HIP graph from their third call on (graphs.py)
+        self.graph_replay = True
+        self._graphs = GraphCache()
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, *args, **kwargs) -> Any:
@@ -132,6 +140,12 @@ class Model(Module):
     def __call__(self, *args, **kwargs):
         if bfr.STATE.ctx is not None:  # nested bnn.Model: the outer forward owns the sample indices
             return super(Model, self).__call__(*args, **kwargs)
+        out = auto_forward(self, args, kwargs)  # an evaluation forward seen before: replayed from its HIP graph
+        if out is not None:
+            return out
+        return self._eager_call(*args, **kwargs)
+
+    def _eager_call(self, *args, **kwargs):
         S = self._mc_samples
         layers = self.fused_children()
         if layers:
@@ -163,12 +177,14 @@ class Model(Module):
                     self._plan = SamplePlan(pl, S, cdt, layers[0].weight.mu.device, index=[i for i, _ in planned],
                                             shared=shared)
                 plan = self._plan
+        if plan is None:
+            self._plan = None  # (a plan of an earlier forward that no layer would use now: its arenas are released)
         # every rank reserves the GLOBAL sample indices of the step and runs its own contiguous slice of them
         start, total = self._mc_span
         base = bfr.reserve_samples(total) + start
         self._last_base, self._last_seed, self._last_S = base, bfr.STATE.seed, S
         self._last_counter = bfr.counter_snapshot() if bfr.STATE.kl_gradient else None
-        ctx = bfr.STATE.ctx = _ForwardContext(base, S, slots, plan, self._lp_buf, shard_start=start)
+        ctx = bfr.STATE.ctx = _ForwardContext(base, S, slots, plan, self._lp_buf, shard_start=start, dropping=self.training)
         out = None
         try:
             out = super(Model, self).__call__(*args, **kwargs)
@@ -200,10 +216,12 @@ class Model(Module):
         if S < 1 or start < 0 or start + S > total:
             raise ValueError(f"monte_carlo: samples={S} at offset {start} do not fit in the step's {total} sample indices")
         self._mc_samples, self._mc_span = S, (start, total)
+        self._mc_harness = getattr(self, "_mc_harness", 0) + 1  # (inside a harness: no transparent graph replay, graphs.py)
         try:
             yield self
         finally:
             self._mc_samples, self._mc_span = prev
+            self._mc_harness -= 1
 
     def fused_children(self) -> List[KernelLayer]:
         """The kernel-backed children (bnn.Linear, bnn.Embedding) in registration order; their layer_id (Philox
@@ -217,6 +235,10 @@ class Model(Module):
     def refresh(self) -> None:
         """Re-scan the children after the module tree was edited."""
         self._fused, self._lp_buf, self._plan = None, None, None
+        self.__dict__.pop("_children_kept", None)
+        cache = self.__dict__.get("_graphs")
+        if cache is not None:
+            cache.close()  # captured forwards hold the old layers' buffers
 
     # ------------------------------------------------------------------------------------------ log-probs
     @property
@@ -227,13 +249,32 @@ class Model(Module):
         return children
 
     def _only_fused(self) -> bool:
-        return all(isinstance(c, KernelLayer) for c in self.bayesian_children)
+        return self._children()[1]
+
+    def _children(self):
+        """(Bayesian children, all of them kernel-backed?) — walked once and kept: the walk over a converted BERT-base's ~600
+        modules is 1.5 ms, and the reference's caller loop asks twice per sample (log_prior(), log_variational_posterior():
+        /root/reference/examples/bert_glue.py:65-66).  Like `fused_children()` the result stands until `refresh()`; a kept
+        child that is no longer registered where it was found (a layer swapped out) makes it stale at once."""
+        kept = self.__dict__.get("_children_kept")
+        if kept is not None and all(parent._modules.get(name) is child for parent, name, child in kept[2]):
+            return kept[0], kept[1]
+        children = list(self.bayesian_children)
+        where = []
+        wanted = {id(c) for c in children}
+        for parent in self.modules():
+            for name, child in parent._modules.items():
+                if id(child) in wanted:
+                    where.append((parent, name, child))
+        only = all(isinstance(c, KernelLayer) for c in children)
+        self.__dict__["_children_kept"] = (children, only, where)
+        return children, only
 
     def _sum(self, index: int, name: str):
-        children = list(self.bayesian_children)
+        children, only_fused = self._children()
         if not len(children):
             warnings.warn("No Bayesian Child is present in this model")
-        if len(children) and self._lp_buf is not None and self._only_fused():
+        if len(children) and self._lp_buf is not None and only_fused:
             # one reduction over the [L, S, 2] buffer the kernels wrote: sum over layers, mean over samples
             if bfr.STATE.kl_gradient and torch.is_grad_enabled():
                 return self.log_prob_samples()[:, index].mean().to(torch.float32)

@@ -585,19 +585,33 @@ class Dropout:
     rate p, the Philox seed, `call` = the number of the forward it belongs to (reserved with the forward's sample indices, so
     a backward pass and the recomputation of a checkpointed block find the same mask) and `site` = the module.
     `origin` = (first global sample of this process's shard, samples in the shard): the kernels number their groups from
-    first_sample x (groups per sample), so a sample's masks do not depend on which rank runs it (random.dropout_origin)."""
-    __slots__ = ("p", "seed", "call", "site", "origin")
+    first_sample x (groups per sample), so a sample's masks do not depend on which rank runs it (random.dropout_origin).
+    `counter`: device-counter mode (random.use_device_counter) — a 1-element int32 device tensor, the forward's copy of the
+    device-resident call counter, which the kernels add to `call` (then 0): forward, backward and a recomputed block read
+    the same copy, and a step replayed from a HIP graph draws fresh masks every replay (random.dropout_counter)."""
+    __slots__ = ("p", "seed", "call", "site", "origin", "counter")
 
-    def __init__(self, p: float, seed: int, call: int, site: int, origin=(0, 1)):
+    def __init__(self, p: float, seed: int, call: int, site: int, origin=(0, 1), counter=None):
         self.p, self.seed, self.call, self.site = float(p), int(seed), int(call) & 0xFFFFFFFF, int(site) & 0x7FFFFFFF
         self.origin = (int(origin[0]), max(1, int(origin[1])))
+        self.counter = counter
+
+    @property
+    def d_call(self):
+        return self.counter.data_ptr() if self.counter is not None else None
 
     def first_group(self, units: int, groups_per_unit: int) -> int:
         """Global index of the first group of a tensor made of `units` rows (or sequences) of `groups_per_unit` groups each,
         the units being this shard's samples in equal slabs."""
         start, s_local = self.origin
-        if start == 0 or units % s_local:
+        if start == 0:
             return 0
+        if units % s_local:
+            # a shard that does not start at sample 0 must know how many units one sample has: numbering its groups from 0
+            # instead would draw the masks of global samples 0.. — correlated across ranks, and silently
+            raise _C.BayeFormersAMDError(
+                f"dropout: a tensor of {units} rows / sequences cannot be split into this shard's {s_local} Monte-Carlo samples "
+                f"(first global sample {start}); the dropped tensor must hold the samples in equal, sample-major slabs")
         return start * (units // s_local) * int(groups_per_unit)
 
     @property
@@ -635,7 +649,8 @@ def add_layernorm(x: Tensor, residual: Optional[Tensor], gamma: Tensor, beta: Te
         _C.check(_C.lib().bf_add_layernorm_dropout(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
                                                    beta.data_ptr(), _TORCH2BF[gamma.dtype], out.data_ptr(),
                                                    _TORCH2BF[x.dtype], x2.shape[0], N, float(eps), drop.p, drop.seed,
-                                                   drop.call, drop.site, drop.first_group(x2.shape[0], N // 8), _stream_ptr()),
+                                                   drop.call, drop.site, drop.first_group(x2.shape[0], N // 8), drop.d_call,
+                                                   _stream_ptr()),
                  "bf_add_layernorm_dropout")
         return out.view(x.shape)
     _C.check(_C.lib().bf_add_layernorm(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),
@@ -702,7 +717,7 @@ def attention_forward(q: Tensor, k: Tensor, v: Tensor, key_mask: Optional[Tensor
                                                    lse.data_ptr() if lse is not None else None, _TORCH2BF[q.dtype], B, T, H,
                                                    D, H * D, float(scaling), drop.p, drop.seed, drop.call, drop.site,
                                                    drop.first_group(B, H * T * (T // 32) * 4),
-                                                   keep.data_ptr() if keep is not None else None, _stream_ptr()),
+                                                   keep.data_ptr() if keep is not None else None, drop.d_call, _stream_ptr()),
                  "bf_attention_fwd_dropout")
         res = (out,) + ((lse,) if want_lse else ()) + ((keep,) if want_keep else ())
         return res if len(res) > 1 else out
@@ -820,7 +835,8 @@ def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor,
                                               ws.data_ptr(), ws.numel(), _TORCH2BF[x.dtype], x2.shape[0], N, float(eps),
                                               drop.p if dropping else 0.0, drop.seed if dropping else 0,
                                               drop.call if dropping else 0, drop.site if dropping else 0,
-                                              drop.first_group(x2.shape[0], N // 8) if dropping else 0, _stream_ptr()),
+                                              drop.first_group(x2.shape[0], N // 8) if dropping else 0,
+                                              drop.d_call if dropping else None, _stream_ptr()),
                  "bf_add_layernorm_bwd_sum")
         return (dz.view(x.shape), dgamma, dbeta, dx.view(x.shape)) if dropping else (dz.view(x.shape), dgamma, dbeta)
     if drop is not None and drop.p > 0.0:
@@ -829,7 +845,7 @@ def add_layernorm_backward(x: Tensor, residual: Optional[Tensor], gamma: Tensor,
                                                   _TORCH2BF[gamma.dtype], g2.data_ptr(), dz.data_ptr(), dx.data_ptr(),
                                                   dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   _TORCH2BF[x.dtype], x2.shape[0], N, float(eps), drop.p, drop.seed, drop.call,
-                                                  drop.site, drop.first_group(x2.shape[0], N // 8), _stream_ptr()),
+                                                  drop.site, drop.first_group(x2.shape[0], N // 8), drop.d_call, _stream_ptr()),
                  "bf_add_layernorm_dropout_bwd")
         return dz.view(x.shape), dgamma, dbeta, dx.view(x.shape)
     _C.check(lib.bf_add_layernorm_bwd(x2.data_ptr(), r2.data_ptr() if r2 is not None else None, gamma.data_ptr(),

@@ -60,6 +60,7 @@ class SamplePlan:
         self.epoch = bfr.STATE.stale_epoch  # the table bakes prior constants in: void once a kernel reported a stale one
         self.layers = layers
         self.index = list(index) if index is not None else list(range(len(layers)))
+        self.shared = tuple(shared)
         self.key = self.make_key(layers, S, cdt, shared)
         lib = _C.lib()
         esz = 4 if cdt == torch.float32 else 2

@@ -33,6 +33,7 @@ class _State:
         self.compute_dtype = torch.bfloat16
         self.next_layer_id = 0
         self.device_counter = None  # 1-element int32 device tensor when the sample counter lives on the GPU
+        self.device_drop_counter = None  # ... and, with it, the dropout `call` counter (1-element int32)
         self.kl_gradient = False    # opt-in Bayes-by-Backprop gradient of the KL terms (the reference has none)
         self.next_dropout_call = 0  # dropout contract (csrc/bf_philox.h): one `call` number per forward
         self.next_dropout_site = 1  # ... and one `site` number per module that applies a dropout
@@ -51,6 +52,7 @@ def manual_seed(seed: int, next_sample: int = 0) -> None:
     if STATE.device_counter is not None:
         v = STATE.next_sample if STATE.next_sample < 2 ** 31 else STATE.next_sample - 2 ** 32
         STATE.device_counter.fill_(v)
+        STATE.device_drop_counter.zero_()
         STATE.counter_moves += 1
 
 
@@ -89,15 +91,20 @@ def use_device_counter(enable: bool = True, device="cuda") -> None:
         if STATE.device_counter is None:
             v = STATE.next_sample if STATE.next_sample < 2 ** 31 else STATE.next_sample - 2 ** 32
             STATE.device_counter = torch.full((1,), v, dtype=torch.int32, device=device)
+            # the dropout `call` numbers move with it: the device counter takes over where the host's stands, the host part
+            # every later forward hands the kernels is 0
+            c = STATE.next_dropout_call if STATE.next_dropout_call < 2 ** 31 else STATE.next_dropout_call - 2 ** 32
+            STATE.device_drop_counter = torch.full((1,), c, dtype=torch.int32, device=device)
         # the library keeps one pointer per HIP device, selected by the CURRENT device: make it the counter's
         with torch.cuda.device(STATE.device_counter.device):
             _C.check(_C.lib().bf_set_sample_counter(STATE.device_counter.data_ptr()), "bf_set_sample_counter")
     else:
         if STATE.device_counter is not None:
             STATE.next_sample = int(STATE.device_counter.item()) & 0xFFFFFFFF
+            STATE.next_dropout_call = int(STATE.device_drop_counter.item()) & 0xFFFFFFFF
             with torch.cuda.device(STATE.device_counter.device):
                 _C.check(_C.lib().bf_set_sample_counter(None), "bf_set_sample_counter")
-        STATE.device_counter = None
+        STATE.device_counter = STATE.device_drop_counter = None
 
 
 def set_compute_dtype(dtype) -> None:
@@ -183,10 +190,41 @@ def recompute_context():
 
 def reserve_dropout_call() -> int:
     """A fresh `call` number of the dropout contract (csrc/bf_philox.h): every bnn.Model forward takes one, so that all the
-    dropouts of that forward — and their regeneration in backward or in a recomputed checkpointed block — share it."""
+    dropouts of that forward — and their regeneration in backward or in a recomputed checkpointed block — share it.
+    Device-counter mode: the host part is always 0, the number lives in `reserve_dropout_counter()`'s copy."""
+    if STATE.device_drop_counter is not None:
+        return 0
     c = STATE.next_dropout_call
     STATE.next_dropout_call = (c + 1) & 0xFFFFFFFF
     return c
+
+
+def reserve_dropout_counter(needed: bool = True):
+    """Device-counter mode: this forward's COPY of the device-resident call counter (what its dropout kernels, their
+    backward and a recomputed block add to `call`), taken before the counter moves on by one; None in host mode — and for a
+    forward of a model that is not in training mode (`needed` False: no dropout will ask), which then leaves the counter
+    where it is, exactly as the host counter only matters to forwards that drop."""
+    if STATE.device_drop_counter is None:
+        return None
+    if not needed:
+        STATE.device_drop_counter.add_(1)
+        return None
+    snap = STATE.device_drop_counter.clone()
+    STATE.device_drop_counter.add_(1)
+    return snap
+
+
+def dropout_counter():
+    """The call-counter copy for a dropout applied now (see dropout_call): the running forward's, the original forward's in
+    a recomputed block; a fresh one outside any forward in device-counter mode; None in host mode."""
+    ctx = STATE.ctx if STATE.ctx is not None else recompute_context()
+    if ctx is None:
+        return reserve_dropout_counter()
+    if ctx.drop_counter is None and STATE.device_drop_counter is not None and ctx is STATE.ctx:
+        # a forward that was not expected to drop (the bnn.Model in eval mode, a child switched to train() on its own): the
+        # counter has moved past this forward's number by exactly one — no other forward can have begun since
+        ctx.drop_counter = STATE.device_drop_counter.clone().sub_(1)
+    return ctx.drop_counter
 
 
 def dropout_call() -> int:
@@ -242,6 +280,11 @@ def counter_snapshot(needed: bool = True):
     fwd = STATE.ctx
     if fwd is None:
         return counter.clone()
+    if getattr(fwd, "_replaying", False) and fwd.counter is not None:
+        # a checkpointed block recomputed during backward (_ForwardContext.replay): the autograd nodes built NOW are the
+        # ones that run backward under use_reentrant=True, and the live counter has moved past this forward — they must
+        # regenerate epsilon from the value the forward itself saw
+        return fwd.counter
     snap = getattr(fwd, "_counter_snap", None)
     if snap is None or snap[0] is not counter or snap[1] != STATE.counter_moves:
         snap = fwd._counter_snap = (counter, STATE.counter_moves, counter.clone())

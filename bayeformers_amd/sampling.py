@@ -214,38 +214,74 @@ def sample_bayesian(model: Model, inputs, samples: int, select: Optional[Callabl
 
 
 _GRAPHED_KEEP = 2  # GraphedSamplers kept per model by sample_bayesian(graph=True): the last two batch signatures
-# model -> [(key, sampler)], most recent last.  Kept OUTSIDE the module (weakly keyed): a model with captured graphs in its
-# __dict__ could be neither deep-copied nor pickled; when the model goes away its samplers are closed (the sample counter
-# returns to the host).
-_GRAPHED: "weakref.WeakKeyDictionary" = None
+
+
+def graphed_samplers(model: Model) -> list:
+    """[(key, GraphedSampler)], most recent last: the samplers `sample_bayesian(graph=True)` keeps for `model`.  They live in
+    the model's graph cache (graphs.GraphCache: copies and pickles of the model start with an empty one); model -> cache ->
+    sampler -> model is an ordinary reference cycle, so a dropped model is collected with its samplers, whose graphs are then
+    released and whose hold on the device-resident sample counter ends (GraphCache.__del__)."""
+    from .graphs import GraphCache
+
+    cache = model.__dict__.get("_graphs")
+    if cache is None:
+        cache = model.__dict__["_graphs"] = GraphCache()
+    return cache.samplers
+
+
+_IMMUTABLE = (type(None), bool, int, float, str, bytes)
 
 
 def _select_key(select):
-    """Cache identity of a `select` callable: a lambda written at the call site is a new object on every call but the same
-    code with the same captured values."""
+    """Cache identity of a `select` callable, or None when two calls cannot be told to select the same thing (then nothing is
+    cached: every call captures).  A lambda written at the call site is a new object on every call but the same code; it is
+    the same selection only if what it captured is the same VALUE — closures over immutable scalars (and tuples of them) are
+    compared by value, anything else (a list or tensor that may be mutated, an object whose id may be reused) is refused.
+    A plain function without a closure and a bound method of a live object are themselves the key; a functools.partial is
+    keyed by its function and (immutable) arguments."""
+    import functools
+
+    def frozen(v):
+        if isinstance(v, _IMMUTABLE):
+            return True
+        return isinstance(v, tuple) and all(frozen(x) for x in v)
+
+    if select is None:
+        return ("default",)
+    if isinstance(select, functools.partial):
+        inner = _select_key(select.func)
+        kw = tuple(sorted(select.keywords.items()))
+        if inner is None or not frozen(select.args) or not frozen(tuple(v for _, v in kw)):
+            return None
+        return ("partial", inner, select.args, kw)
     code = getattr(select, "__code__", None)
     if code is None:
-        return select
-    cells = tuple(id(c.cell_contents) for c in (select.__closure__ or ()))
-    return code, select.__defaults__, cells, getattr(select, "__self__", None)
-
-
-def _close_all(entries):
-    for _, sampler in entries:
-        sampler.close()
+        return ("object", select)  # a callable object: held by the key, compared by identity (its default __eq__) or its own
+    cells = []
+    for c in select.__closure__ or ():
+        try:
+            v = c.cell_contents
+        except ValueError:  # an empty cell
+            return None
+        if not frozen(v):
+            return None
+        cells.append(v)
+    if not frozen(select.__defaults__ or ()):
+        return None
+    return ("function", code, select.__defaults__, tuple(cells), getattr(select, "__self__", None))
 
 
 def _graphed(model: Model, inputs, samples: int, select, group):
-    import weakref
-
-    global _GRAPHED
-    if _GRAPHED is None:
-        _GRAPHED = weakref.WeakKeyDictionary()
-    cache = _GRAPHED.get(model)
-    if cache is None:
-        cache = _GRAPHED[model] = []
-        weakref.finalize(model, _close_all, cache).atexit = False  # (not at interpreter exit: the HIP runtime may be gone)
-    key = (GraphedSampler._sig(inputs), int(samples), _select_key(select), group)
+    cache = graphed_samplers(model)
+    skey = _select_key(select)
+    if skey is None:  # a selection that cannot be recognised again: capture for this call only
+        sampler = GraphedSampler(model, inputs, samples, select=select, group=group)
+        try:
+            raw, means, log_prior, lvp = sampler(inputs)
+            return tuple(r.clone() for r in raw), tuple(m.clone() for m in means), log_prior.clone(), lvp.clone()
+        finally:
+            sampler.close()
+    key = (GraphedSampler._sig(inputs), int(samples), skey, group)
     sampler = None
     for i, (k, sm) in enumerate(cache):
         if k == key and sm.graph is not None:
@@ -266,9 +302,6 @@ def _graphed(model: Model, inputs, samples: int, select, group):
 def elbo(log_prior: Tensor, log_variational_posterior: Tensor, nll: Tensor, n_batches: int) -> Tensor:
     """loss = (lvp - log_prior) / n_batches + nll  (bert_glue.py:235, mlp_mnist.py:107, README.md:72)."""
     return torch.add(nll, log_variational_posterior - log_prior, alpha=1.0 / n_batches)
-
-
-_GRAPH_USERS = {"n": 0, "moved": False}  # open GraphedSamplers; whether the first of them moved the sample counter to the device
 
 
 class GraphedSampler:
@@ -298,7 +331,7 @@ class GraphedSampler:
 
     def __init__(self, model: Model, inputs, samples: int, select: Optional[Callable] = None,
                  group: Optional["dist.ProcessGroup"] = None, warmup: int = 2) -> None:
-        from . import random as bfr
+        from . import graphs
 
         if model.training:
             raise RuntimeError("GraphedSampler: the model is in training mode (dropout masks are per step); call model.eval()")
@@ -314,11 +347,8 @@ class GraphedSampler:
         self._signature = self._sig(inputs)
         self._rep = self._map(inputs, lambda v: v.repeat(self._s_local, *([1] * (v.dim() - 1))) if v.dim() > 0 else v.clone())
         # the captured kernels hold the counter's ADDRESS: it must stay on the device until the last sampler is closed
-        if _GRAPH_USERS["n"] == 0:
-            _GRAPH_USERS["moved"] = bfr.STATE.device_counter is None
-        _GRAPH_USERS["n"] += 1
+        graphs.acquire_counter(self.device)
         self._open = True
-        bfr.use_device_counter(True, device=self.device)
         self.graph = self._static = None
         self._warmup = max(1, int(warmup))
         self.captures = 0
@@ -330,10 +360,9 @@ class GraphedSampler:
 
     def _baked(self):
         """The host state a capture bakes into its launches."""
-        from . import random as bfr
+        from . import graphs
 
-        plan = getattr(self.model, "_plan", None)
-        return bfr.STATE.seed, bfr.get_compute_dtype(), plan, (plan.key if plan is not None else None), bfr.STATE.stale_epoch
+        return graphs.baked_state(self.model)
 
     def _capture(self) -> None:
         from . import random as bfr
@@ -355,13 +384,9 @@ class GraphedSampler:
         self.captures += 1
 
     def _still_valid(self) -> bool:
-        from . import ops
+        from . import graphs
 
-        ops.refresh_stale_epoch()  # (a replay whose kernels found a stale prior bumped the library's counter)
-        seed, cdt, plan, key, epoch = self._baked_state
-        now = self._baked()
-        return (now[0] == seed and now[1] == cdt and now[2] is plan and now[3] == key and now[4] == epoch
-                and (plan is None or plan.alias_valid()))
+        return graphs.still_valid(self.model, self._baked_state)
 
     # ------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -421,11 +446,9 @@ class GraphedSampler:
     def close(self) -> None:
         """Drop the graph; when the last open sampler closes and the samplers had moved the sample counter to the device,
         it moves back to the host (advanced by what the replays consumed)."""
-        from . import random as bfr
+        from . import graphs
 
         self.graph = self._static = None
         if self._open:
             self._open = False
-            _GRAPH_USERS["n"] -= 1
-            if _GRAPH_USERS["n"] == 0 and _GRAPH_USERS["moved"]:
-                bfr.use_device_counter(False)
+            graphs.release_counter()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — MC-samples/sec (fwd+ELBO) of the MI355X Monte-Carlo variational forward path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bert_base|bert_large_qa|bert_base_train|bert_large_qa_train|linear768|linear768_m32|mlp]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bert_base|bert_base_serial|bert_large_qa|bert_base_train|bert_large_qa_train|linear768|linear768_m32|mlp]
 
 With --gpus N > 1 and no torch.distributed environment (WORLD_SIZE unset) this process only LAUNCHES the job: it starts
 `python -m torch.distributed.run --nproc-per-node N ... bench.py <same flags>` as a child process (it never touches a
@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="bert_base", choices=["bert_base", "bert_large_qa", "linear768", "linear768_m32", "mlp", "bert_base_train", "bert_large_qa_train"])
+    ap.add_argument("--workload", default="bert_base", choices=["bert_base", "bert_base_serial", "bert_large_qa", "linear768", "linear768_m32", "mlp", "bert_base_train", "bert_large_qa_train"])
     ap.add_argument("--samples", type=int, default=None, help="MC samples per GPU per step (default: workload's)")
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--strong", action="store_true",
@@ -89,7 +89,8 @@ def _ranks() -> int:
 def honoured_env():
     """Every BF_* variable set in this process's environment: they are developer switches that change what is built or
     timed (BF_BENCH_NO_*_FUSION, BF_BENCH_TRAIN_*, BF_BENCH_SHARE_GPU, BF_PLAN_ARENA_BYTES, BF_LIB_PATH, ...), so a line
-    produced under any of them says so in its `config` (an empty dict = the defaults the driver measures)."""
+    produced under any of them says so in its `config`.  The defaults the driver measures show exactly ONE entry: the
+    HSA_ENABLE_IPC_MODE_LEGACY setting, which is always echoed with where its value came from."""
     env = {k: os.environ[k] for k in sorted(os.environ) if k.startswith("BF_")}
     # the one runtime setting multi-process GPU work depends on here (dmabuf IPC; RCCL and CUDA-tensor sharing fail without
     # it on this driver): always echoed, with where its value came from
@@ -208,7 +209,7 @@ def build_bert(device, dtype):
     return bmodel, model, inputs, ids, labels, info
 
 
-def make_bert(device, S, dtype, train=False, train_mode=False):
+def make_bert(device, S, dtype, train=False, train_mode=False, serial=False):
     from bayeformers_amd.sampling import elbo, sample_bayesian
 
     B, L, n_batches = 32, 128, 2105  # SST-2: 67,349 train sentences / 32
@@ -224,6 +225,22 @@ def make_bert(device, S, dtype, train=False, train_mode=False):
             return elbo(lp, lq, nll.double(), n_batches)
 
     step.harness = harness
+    if serial:
+        # The reference's own caller loop, unchanged (/root/reference/examples/bert_glue.py:56-73): S serial forwards of ONE
+        # sample each, the two log-prob sums read after every forward, then the means and the ELBO — what a user script that
+        # switches packages without adopting sample_bayesian() runs.  bnn.Model.__call__ replays such evaluation forwards
+        # from a HIP graph from the third call of a signature on (bayeformers_amd/graphs.py; BF_NO_AUTO_GRAPH=1: eager).
+        def step():  # noqa: F811
+            with torch.no_grad():
+                logits, lps, lqs = [], [], []
+                for _ in range(S):
+                    logits.append(bmodel(**inputs).logits)
+                    lps.append(bmodel.log_prior())
+                    lqs.append(bmodel.log_variational_posterior())
+                mean = torch.stack(logits).float().mean(0)
+                nll = torch.nn.functional.cross_entropy(mean, labels_d)
+                return elbo(torch.stack(lps).double().mean(), torch.stack(lqs).double().mean(), nll.double(), n_batches)
+
     if train:
         # the reference's training step (examples/bert_glue.py:227-241) — forward, ELBO, backward through
         # every sampled-weight layer (eps regenerated from the Philox counter), Adam on the unfrozen parameters
@@ -265,7 +282,8 @@ def make_bert(device, S, dtype, train=False, train_mode=False):
     cfgd = {"workload": "to_bayesian(BERT-base seq-cls, delta=0.05, freeze=True) " +
                         (("training step: fwd+ELBO+backward+clip+AdamW, " +
                           ("model.train(): HF dropout 0.1 inside the fused kernels" if train_mode else "dropout off (--no-dropout)"))
-                         if train else "fwd+ELBO"), "samples_per_gpu": S,
+                         if train else ("fwd+ELBO as S SERIAL single-sample forwards (the reference's caller loop, examples/bert_glue.py:63-66)"
+                                        if serial else "fwd+ELBO")), "samples_per_gpu": S,
             "batch": B, "seq_len": L, "bayesian_linears": len(bmodel.fused_children()), "bayesian_scalars": 85609730}
     cfgd.update(info)
     return step, cpu_baseline, cfgd, bmodel
@@ -712,7 +730,7 @@ def dry_run(args, world, rank, device, samples):
         sys.exit(3)
 
 
-DEFAULTS = {"bert_base": (10, "bf16"), "bert_base_train": (10, "bf16"), "bert_large_qa": (10, "fp16"),
+DEFAULTS = {"bert_base": (10, "bf16"), "bert_base_serial": (10, "bf16"), "bert_base_train": (10, "bf16"), "bert_large_qa": (10, "fp16"),
             "bert_large_qa_train": (10, "bf16"), "linear768": (10, "bf16"), "linear768_m32": (10, "bf16"), "mlp": (5, "bf16")}
 
 
@@ -781,6 +799,12 @@ def main():
     bf.manual_seed(0x5EED)
     if args.workload == "bert_base":
         step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype)
+    elif args.workload == "bert_base_serial":
+        if world > 1:
+            print("bench.py: bert_base_serial is the single-process caller loop (--gpus 1)", file=sys.stderr)
+            sys.exit(2)
+        step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype, serial=True)
+        delattr(step, "harness") if hasattr(step, "harness") else None
     elif args.workload == "bert_base_train":
         step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype, train=True, train_mode=not args.no_dropout)
     elif args.workload == "bert_large_qa":
@@ -865,6 +889,11 @@ def main():
     prof_step = eager_step if use_graph else step
     if harness is not None:
         harness.graphed(False)  # the profiling hooks time single launches: eager calls
+    auto_replays = None
+    if hasattr(bmodel, "graph_replay"):
+        cache = bmodel.__dict__.get("_graphs")
+        auto_replays = bool(cache is not None and cache.forwards)  # did bnn.Model.__call__ replay the timed forwards?
+        bmodel.graph_replay = False
     for _ in range(prof_steps):
         prof_step()
     torch.cuda.synchronize()
@@ -874,6 +903,11 @@ def main():
         n, ms, work = ctypes.c_uint64(), ctypes.c_double(), ctypes.c_double()
         _C.check(lib.bf_profile_read(kind, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(work)), "bf_profile_read")
         prof[name] = (n.value, ms.value, work.value)
+    # the tiled-GEMM launches one by one, in launch order: a BERT step's launch i is position i % 4 of encoder layer i // 4
+    n_g = prof["gemm"][0]
+    g_ms, g_work = (ctypes.c_float * max(n_g, 1))(), (ctypes.c_double * max(n_g, 1))()
+    lib.bf_profile_read_launches(_C.BF_PROF_GEMM, g_ms, g_work, n_g)
+    gemm_launches = [(float(g_ms[i]), float(g_work[i])) for i in range(n_g)]
     lib.bf_profile_reset()
 
     # the step's one collective on its own: the packed [sum of outputs | sum log_prior | sum lvp] fp64 buffer
@@ -909,8 +943,10 @@ def main():
         sn, sms, sbytes = prof["sample"]
         aliased = False
         plan = getattr(bmodel, "_plan", None)
-        if sbytes == 0 and plan is not None:
-            # cross-layer launches: algorithmic bytes = mu,rho (+ Gaussian prior mu,rho) read once, S samples written
+        if plan is not None:
+            # cross-layer launches (they report no byte count themselves): algorithmic bytes = mu,rho (+ Gaussian prior mu,rho)
+            # read once, S samples written — ADDED to what the per-layer launches of the step reported (fp32: the pooler and
+            # the classifier sample through bf_sample_logprob, whose few MB used to stand for the whole 4 GB of the plan)
             from bayeformers_amd import ops as bf_ops
             from bayeformers_amd.nn import Gaussian
             l0 = plan.layers[0]
@@ -918,7 +954,7 @@ def main():
             per_read = 16 if isinstance(l0.weight_prior, Gaussian) and bf_ops.prior_alias(l0.weight, l0.weight_prior) is None else 8
             aliased = isinstance(l0.weight_prior, Gaussian) and per_read == 8
             esz = 4 if dtype == "fp32" else 2
-            sbytes = float(plan.scalars) * (per_read + S * esz) * prof_steps
+            sbytes += float(plan.scalars) * (per_read + plan.S * esz) * prof_steps
         fn, fms, fflop = prof["fused"]
         fused = {"kernel": "fused_small_kernel (sampling + log-probs + MFMA in one launch, M <= 64)", "bound": "latency",
                  "launches_per_step": fn // prof_steps, "avg_launch_us": round(1e3 * fms / max(fn, 1), 2),
@@ -929,11 +965,32 @@ def main():
             gn, gms, gflop = fn, fms, fflop
             kernel, bound, fused = fused["kernel"], "latency", None
         else:
-            kernel = ("gemm256_ring5_kernel<float> (sampled-weight GEMM on v_mfma_f32_16x16x4_f32, five-slot LDS ring; mean over "
-                      "the step's tiled-GEMM launches)" if dtype == "fp32" else
-                      "gemm256_ring5_kernel (sampled-weight GEMM, five-slot LDS ring; mean over the step's tiled-GEMM launches)")
+            if dtype == "fp32" and os.environ.get("BF_F32_GENERIC") is not None:
+                # (bf_launch_gemm_nt dispatches the generic kernel under this switch — and for shapes the ring form refuses:
+                # K % 32, N % 4, unaligned operands, M * N < 128 * 128; none of the workloads here has such a layer)
+                kernel = "gemm_nt_f32_kernel (generic fp32 kernel: BF_F32_GENERIC is set)"
+            elif dtype == "fp32":
+                kernel = ("gemm256_ring5_kernel<float> (sampled-weight GEMM on v_mfma_f32_16x16x4_f32, five-slot LDS ring; mean "
+                          "over the step's tiled-GEMM launches)")
+            else:
+                kernel = "gemm256_ring5_kernel (sampled-weight GEMM, five-slot LDS ring; mean over the step's tiled-GEMM launches)"
             bound = "mfma"
         tflops = gflop / (gms * 1e-3) / 1e12 if gms > 0 else 0.0
+        # by position (BERT forward workloads: 4 tiled launches per encoder layer, in the model's order)
+        by_position = None
+        per_step = len(gemm_launches) // prof_steps if prof_steps else 0
+        n_enc = 4 * getattr(getattr(getattr(bmodel, "model", None), "config", None), "num_hidden_layers", 0)  # encoder launches per step
+        if args.workload in ("bert_base", "bert_large_qa") and bound == "mfma" and n_enc and per_step >= n_enc \
+                and len(gemm_launches) == per_step * prof_steps and all(t >= 0 for t, _ in gemm_launches):
+            # (fp32: the pooler and the classifier run the tiled kernel too, after the encoder's launches — they are part of
+            # roofline.frac and of no position)
+            by_position = {}
+            enc_ms = sum(t for i, (t, _) in enumerate(gemm_launches) if i % per_step < n_enc)
+            for pos, name in enumerate(GEMM_POSITIONS):
+                sel = [gemm_launches[i] for i in range(len(gemm_launches)) if i % per_step < n_enc and (i % per_step) % 4 == pos]
+                t_ms, fl = sum(t for t, _ in sel), sum(w for _, w in sel)
+                by_position[name] = {"frac": round(fl / (t_ms * 1e-3) / 1e12 / peak, 4), "achieved": round(fl / (t_ms * 1e-3) / 1e12, 1),
+                                     "avg_launch_us": round(1e3 * t_ms / len(sel), 2), "share_of_gemm_time": round(t_ms / enc_ms, 4)}
         # the north star asks for ONE fused reparameterise + GEMM kernel; here the weights are sampled by their own launch
         # (LABBOOK.md section 4.3), so the fraction a fused kernel would be held to is flop / (GEMM time + sampling time)
         tflops_ws = gflop / ((gms + sms) * 1e-3) / 1e12 if gms + sms > 0 else 0.0
@@ -942,6 +999,7 @@ def main():
                     "frac": round(tflops / peak, 4), "frac_with_sampling": round(tflops_ws / peak, 4), "traffic": None,
                     "launches_per_step": gn // prof_steps, "avg_launch_us": round(1e3 * gms / max(gn, 1), 2),
                     "flop_per_step": gflop / prof_steps, "gemm_ms_per_step": round(gms / prof_steps, 3),
+                    "by_position": by_position,
                     "fused_small_kernel": fused,
                     "sample_kernel": {"bound": "hbm", "achieved": round(sbytes / (sms * 1e-3) / 1e9, 1) if sms > 0 else 0.0,
                                       "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -951,7 +1009,7 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
-        if world == 1 and not args.no_traffic and gn > 0 and not args.workload.endswith("_train"):
+        if world == 1 and not args.no_traffic and gn > 0 and not args.workload.endswith("_train") and args.workload != "bert_base_serial":
             tr = measure_traffic(args)
             if tr is not None:
                 roofline["traffic"] = round(tr["bytes_per_launch"])
@@ -983,7 +1041,7 @@ def main():
         if pre is not None:  # the N-rank run's own preflight: who took part, what the two message kinds cost
             cfgd["preflight"] = {k: pre[k] for k in ("backend", "ranks", "ranks_counted", "bucket_ranks_counted",
                                                      "allreduce_ms", "rccl_version") if k in pre}
-        cfgd.update({"env": honoured_env(), "parallelism": f"mc-sample-shard x{n_ranks}", "last_elbo": last, "hip_graph": graph_note if harness is not None and graph_note else bool(use_graph),
+        cfgd.update({"env": honoured_env(), "parallelism": f"mc-sample-shard x{n_ranks}", "last_elbo": last, "hip_graph": graph_note if harness is not None and graph_note else (bool(use_graph) or ("bnn.Model.__call__ replay" if auto_replays else False)),
                      "samples_total": total_samples, "samples_per_step": per_step,
                      "allreduce_ms_per_step": round(allreduce_ms, 4) if allreduce_ms is not None else None})
         metric = "MC-samples/sec (fwd+ELBO+backward+AdamW)" if args.workload.endswith("_train") else "MC-samples/sec (fwd+ELBO)"

@@ -25,11 +25,13 @@ extern "C" {
 #endif
 
 #define BF_VERSION_MAJOR 0
-#define BF_VERSION_MINOR 5  /* 2: bf_embed_layernorm takes the table row counts; 3: bf_sample_table_build reports the
+#define BF_VERSION_MINOR 6  /* 2: bf_embed_layernorm takes the table row counts; 3: bf_sample_table_build reports the
                                tensors' effective prior kinds, bf_sample_logprob_table takes the launch's set of them;
                                4: bf_add_layernorm_bwd_sum; 5: bf_prior_t carries the device addresses its constants were
                                read from (re-checked by the kernels), bf_stale_counter; bf_linear_bwd takes d_dy_colsum,
-                               bf_attention_bwd_colsum; the dropout entries take first_group */
+                               bf_attention_bwd_colsum; the dropout entries take first_group; 6: the dropout entries take d_call
+                               (device-resident part of the call number), bf_gemm_schedule_policy / _fetch_rows,
+                               bf_profile_read_launches */
 
 /* element types of activations / sampled weights */
 enum { BF_DT_F32 = 0, BF_DT_BF16 = 1, BF_DT_F16 = 2 };
@@ -345,13 +347,17 @@ int bf_attention_bwd(const void* d_q, const void* d_k, const void* d_v, const fl
  *   (b, h, q, key/128, lg), bit c*8 + e*4 + j.
  * bf_attention_bwd_dropout: bf_attention_bwd for that forward (any supported T; d_keep_bits as the forward wrote them).
  * bf_add_layernorm_dropout: LayerNorm(dropout(x) + residual); group of element (row, n): row * (N/8) + n/8, field n % 8.
- * bf_add_layernorm_dropout_bwd: its backward; d_dz = gradient of the residual, d_dx = d_dz o keep / (1 - p). */
+ * bf_add_layernorm_dropout_bwd: its backward; d_dz = gradient of the residual, d_dx = d_dz o keep / (1 - p).
+ * d_call (nullable, ABI 6): a device-resident uint32 the kernels ADD to `call` — the device-resident part of the forward's
+ *   number.  A training step captured in a hipGraph bakes the host-side `call`; the captured step copies a one-element device
+ *   counter (the copy is what d_call points at, forward and backward alike) and increments it, so replay k draws the masks
+ *   the k-th eager step would have drawn (the scheme of bf_set_sample_counter for epsilon). */
 int bf_dropout_keep_host(uint8_t* out, uint64_t first_group, uint64_t n_groups, float p_drop, uint64_t seed, uint32_t call,
                          uint32_t site);
 int bf_attention_fwd_dropout(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
                              void* d_out, float* d_lse, int dtype, int B, int T, int H, int head_dim, int64_t token_stride,
                              float scaling, float p_drop, uint64_t seed, uint32_t call, uint32_t site, uint64_t first_group, uint32_t* d_keep_bits,
-                             void* stream);
+                             const uint32_t* d_call, void* stream);
 int bf_attention_bwd_dropout(const void* d_q, const void* d_k, const void* d_v, const float* d_mask, const uint8_t* d_mask_off,
                              const void* d_out, const void* d_dout, const float* d_lse, float* d_delta, void* d_dq, void* d_dk,
                              void* d_dv, int dtype, int B, int T, int H, int head_dim, int64_t token_stride, float scaling,
@@ -370,11 +376,11 @@ int bf_attention_bwd_colsum(const void* d_q, const void* d_k, const void* d_v, c
                             void* stream);
 int bf_add_layernorm_dropout(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, int param_dtype,
                              void* d_out, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed, uint32_t call,
-                             uint32_t site, uint64_t first_group, void* stream);
+                             uint32_t site, uint64_t first_group, const uint32_t* d_call, void* stream);
 int bf_add_layernorm_dropout_bwd(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype,
                                  const void* d_dy, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
                                  size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
-                                 uint32_t call, uint32_t site, uint64_t first_group, void* stream);
+                                 uint32_t call, uint32_t site, uint64_t first_group, const uint32_t* d_call, void* stream);
 
 /* bf_add_layernorm_bwd / bf_add_layernorm_dropout_bwd (p_drop = 0: no dropout, d_dx unused) for an output that had TWO
  * consumers — in a transformer layer the normalised rows feed the next dense layer AND the next residual connection
@@ -384,7 +390,7 @@ int bf_add_layernorm_dropout_bwd(const void* d_x, const void* d_residual, const 
 int bf_add_layernorm_bwd_sum(const void* d_x, const void* d_residual, const void* d_gamma, int param_dtype, const void* d_dy,
                              const void* d_dy2, void* d_dz, void* d_dx, float* d_dgamma, float* d_dbeta, void* d_workspace,
                              size_t workspace_bytes, int dtype, int64_t rows, int N, float eps, float p_drop, uint64_t seed,
-                             uint32_t call, uint32_t site, uint64_t first_group, void* stream);
+                             uint32_t call, uint32_t site, uint64_t first_group, const uint32_t* d_call, void* stream);
 
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg).
@@ -399,6 +405,10 @@ enum { BF_PROF_SAMPLE = 0, BF_PROF_GEMM = 1, BF_PROF_FUSED_SMALL = 2, BF_PROF_FU
 int bf_profile_enable(int on);
 int bf_profile_reset(void);
 int bf_profile_read(int kind, uint64_t* launches, double* total_ms, double* total_work);
+/* The same launch by launch, in launch order: ms[i] / work[i] of the i-th recorded launch of `kind` (up to cap entries; a
+ * launch whose events could not be read has ms = -1).  Returns the number of recorded launches of that kind.  bench.py
+ * derives the per-position fractions of a BERT step from it (launch i of a step is position i % 4 of layer i / 4). */
+size_t bf_profile_read_launches(int kind, float* ms, double* work, size_t cap);
 
 /* Rows per sample (M) up to which bf_linear_fwd runs an N x K layer as its single fused kernel (sampling + log-probs +
  * MFMA in one launch, no sampled weights in memory) instead of sampling launch + tiled GEMM: bf_fused_small_rows_for(N, K)

@@ -342,9 +342,15 @@ def bert_large_qa_case():
             lp[s] = float(bmodel.log_prior())
             lq[s] = float(bmodel.log_variational_posterior())
             print(f"    sample {s}: {time.time() - t0:.0f}s", flush=True)
+    # round 6: samples 3 and 6 of BOTH heads at four sequences (in the uneven 8-rank split of this configuration — 2, 2, 1, 1, 1,
+    # 1, 1, 1 — sample 3 closes rank 1's shard and sample 6 is all of rank 4's: per-sample logits of the middle of the step are
+    # now pinned too, not only through the means)
+    seqs = [0, 5, 10, 15]
+    mid = {f"{head}_s{k}": t2n(t[k][seqs]) for k in (3, 6) for head, t in (("start", start), ("end", end))}
     return {"S": S, "B": B, "L": L, "model_seed": 0, "input_seed": 654, "delta": 0.05, "n_layers": len(layers),
             "checksum": csum, "ids_sum": int(ids.sum()), "start_mean": t2n(start.mean(0)), "end_mean": t2n(end.mean(0)),
-            "start_s0": t2n(start[0]), "end_s9": t2n(end[9]), "log_prior": t2n(lp), "lvp": t2n(lq)}
+            "start_s0": t2n(start[0]), "end_s9": t2n(end[9]), "log_prior": t2n(lp), "lvp": t2n(lq),
+            "mid_seqs": np.array(seqs), **mid}
 
 
 def checkpoint_case():
@@ -490,7 +496,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, "bert_tiny_train.npz"), **bert_train_case())
         return
     if args.only_bert_large:
-        np.savez_compressed(os.path.join(HERE, "bert_large_qa_c5.npz"), **bert_large_qa_case())
+        np.savez_compressed(os.path.join(os.environ.get("BF_GOLDEN_OUT", HERE), "bert_large_qa_c5.npz"), **bert_large_qa_case())
         return
     if args.only_grads:
         np.savez_compressed(os.path.join(HERE, "linear_grads.npz"), **grad_cases())

@@ -547,12 +547,14 @@ def test_sharded_training_step_gradients_match_reference_bert_tiny(golden_dir, d
     _check_tiny_train_grads(g, params, tol, tol_vec)
 
 
-@pytest.mark.parametrize("device_counter", [False, True])
-def test_checkpointed_blocks_recompute_the_forwards_epsilon(device_counter):
+@pytest.mark.parametrize("device_counter,reentrant", [(False, False), (True, False), (False, True), (True, True)])
+def test_checkpointed_blocks_recompute_the_forwards_epsilon(device_counter, reentrant):
     """torch.utils.checkpoint re-runs a block's forward DURING backward, outside any bnn.Model forward.  The Bayesian
     layers inside must then draw the epsilon of the forward they repeat (bayeformers_amd.random.recompute_context) —
     the same sample indices, also with the device-resident counter, which has moved on by then: outputs, log-probs and
-    every gradient equal those of the run without checkpointing."""
+    every gradient equal those of the run without checkpointing.  use_reentrant=True: there the autograd nodes
+    built DURING the recomputation are the ones that run backward — they must regenerate epsilon from the counter value the
+    forward saw, not from the live counter."""
     from torch.utils.checkpoint import checkpoint
 
     class Block(torch.nn.Module):
@@ -568,11 +570,11 @@ def test_checkpointed_blocks_recompute_the_forwards_epsilon(device_counter):
             super().__init__()
             self.blocks = torch.nn.ModuleList([Block(d) for _ in range(3)])
             self.head = torch.nn.Linear(d, 4)
-            self.ckpt = ckpt
+            self.ckpt, self.reentrant = ckpt, False
 
         def forward(self, x):
             for blk in self.blocks:
-                x = checkpoint(blk, x, use_reentrant=False) if self.ckpt else blk(x)
+                x = checkpoint(blk, x, use_reentrant=self.reentrant) if self.ckpt else blk(x)
             return self.head(x)
 
     d, S, B = 128, 3, 80   # 80 rows per sample: the planned (cross-layer sampled) path; the head (N = 4) runs on its own
@@ -584,12 +586,13 @@ def test_checkpointed_blocks_recompute_the_forwards_epsilon(device_counter):
 
     def run(ckpt):
         net_b = bmodel.model
-        net_b.ckpt = ckpt
+        net_b.ckpt, net_b.reentrant = ckpt, reentrant
         for p in bmodel.parameters():
             p.grad = None
         bf.manual_seed(SEED, next_sample=7)
         with bmodel.monte_carlo(S):
-            out = bmodel(x.repeat(S, 1))
+            # (the reentrant form only checkpoints a block whose input requires a gradient)
+            out = bmodel(x.repeat(S, 1).requires_grad_(reentrant))
         lps = bmodel.log_prob_samples().clone()
         # a second forward between forward and backward would move a host-side counter; the device counter has moved anyway
         ((out - target) ** 2).mean().backward()

@@ -119,7 +119,7 @@ def test_sample_bayesian_graph_flag_caches_two_signatures():
 
     with torch.no_grad():
         sample_bayesian(bmodel, batches[0], 2, graph=True)  # captures
-        cache = sampling._GRAPHED[bmodel]
+        cache = sampling.graphed_samplers(bmodel)
         first = cache[0][1]
         bf.manual_seed(SEED)
         got = _host(sample_bayesian(bmodel, batches[1], 2, graph=True))  # same signature: the cached sampler, new batch
@@ -169,7 +169,7 @@ def test_graph_follows_seed_dtype_and_starts_at_the_callers_sample_index():
                     assert got[2] == w[2] and got[3] == w[3], (step, seed, dtype)
                 # the convenience path returns copies of the means: the second call did not overwrite the first's
                 assert np.array_equal(mean0.float().cpu().numpy(), want[0][1])
-                cache = sampling._GRAPHED[bmodel]
+                cache = sampling.graphed_samplers(bmodel)
                 assert len(cache) == 1 and cache[0][1].captures == step + 1   # one sampler, captured again per change
         # the model carries no graph: it can be copied while samplers exist
         assert "_bf_graphed" not in bmodel.__dict__
@@ -177,6 +177,92 @@ def test_graph_follows_seed_dtype_and_starts_at_the_callers_sample_index():
         assert sum(p.numel() for p in clone.parameters()) == sum(p.numel() for p in bmodel.parameters())
     finally:
         bf.set_compute_dtype("bf16")
-        for _, sm in sampling._GRAPHED.get(bmodel, []):
+        for _, sm in sampling.graphed_samplers(bmodel):
             sm.close()
     assert bfr.STATE.device_counter is None
+
+
+def test_model_call_replays_the_reference_loop_and_equals_eager():
+    """bnn.Model.__call__ under no_grad in eval mode, one sample per call (the reference's caller loop): the third call of a
+    signature captures, later ones replay — call k is the k-th eager call bit for bit, new batch VALUES are copied in, the
+    outputs are copies, log_prior() / the layers' lazy scalars follow the replays, another signature runs eagerly."""
+    import bayeformers_amd as bf
+    from bayeformers_amd import random as bfr
+
+    bmodel, batches = _build()
+    bf.set_compute_dtype("bf16")
+    order = [0, 1, 0, 1, 1, 0]
+    first = bmodel.fused_children()[0]
+
+    def loop(replay):
+        bmodel.graph_replay = replay
+        bf.manual_seed(SEED)
+        outs = []
+        with torch.no_grad():
+            for b in order:
+                o = bmodel(**batches[b])
+                outs.append((o.logits, float(bmodel.log_prior()), float(bmodel.log_variational_posterior()),
+                             float(first.log_prior), float(first.log_variational_posterior)))
+        return outs
+
+    try:
+        eager = loop(False)
+        assert not bmodel._graphs.forwards and bfr.STATE.device_counter is None
+        got = loop(True)
+        assert len(bmodel._graphs.forwards) == 1 and bfr.STATE.device_counter is not None
+        for k, (e, r) in enumerate(zip(eager, got)):
+            assert torch.equal(e[0], r[0]), k
+            assert e[1:] == r[1:], k
+        assert len({o[0].data_ptr() for o in got}) == len(got)   # every call handed out its own copy
+        # a batch of another shape is another signature: eager until seen twice, the captured one stays
+        small = {k: v[:2].clone() for k, v in batches[0].items()}
+        with torch.no_grad():
+            bmodel(**small)
+        assert len(bmodel._graphs.forwards) == 1
+        # training mode and recorded gradients never replay
+        with torch.no_grad():
+            bmodel.train()
+            bmodel(**batches[0])
+            bmodel.eval()
+        n = bmodel._graphs.forwards[0][1].captures
+        bmodel(**batches[0])   # gradients enabled: eager
+        assert bmodel._graphs.forwards[0][1].captures == n
+        # another seed: captured again, and still the eager result
+        bf.manual_seed(SEED + 1)
+        with torch.no_grad():
+            r2 = bmodel(**batches[0]).logits
+        assert bmodel._graphs.forwards[0][1].captures == n + 1
+        bmodel.graph_replay = False
+        bf.manual_seed(SEED + 1)
+        with torch.no_grad():
+            assert torch.equal(bmodel(**batches[0]).logits, r2)
+    finally:
+        bmodel.graph_replay = True
+        bmodel._graphs.close()
+    assert bfr.STATE.device_counter is None
+
+
+def test_dropped_model_releases_its_graphs():
+    """the samplers kept for `sample_bayesian(graph=True)` (and the forwards __call__ captured) must not keep their
+    model alive: `del model; gc.collect()` ends them, and the sample counter returns to the host."""
+    import gc
+    import weakref
+
+    import bayeformers_amd as bf
+    from bayeformers_amd import random as bfr
+    from bayeformers_amd.sampling import sample_bayesian
+
+    bmodel, batches = _build()
+    bf.set_compute_dtype("bf16")
+    bf.manual_seed(SEED)
+    with torch.no_grad():
+        sample_bayesian(bmodel, batches[0], 2, graph=True)
+        for _ in range(3):
+            bmodel(**batches[0])
+    assert bfr.STATE.device_counter is not None
+    assert len(bmodel._graphs.samplers) == 1 and len(bmodel._graphs.forwards) == 1
+    ref = weakref.ref(bmodel)
+    del bmodel
+    gc.collect()
+    assert ref() is None
+    assert bfr.STATE.device_counter is None and bfr.get_state()[1] == 2 + 3

@@ -74,6 +74,7 @@ def _hidden_rows_error(hidden, g):
 # The benchmarked configuration (bf16, every fusion on): max |logit - ref| = 4.83e-3 with logits up to 1.97 and a
 # sample-to-sample spread of 0.82; max |last-layer hidden - ref| = 2.05e-2 on unit-variance rows whose samples spread by 0.90.
 C3_LOGIT_TOL = 1.0e-2
+C4_LOGIT_TOL = 1.3e-2   # the same model, 64 samples instead of 10: 2x the largest of the 8 x 8 x 64 errors (6.4e-3, profiles/r6d_pytest_new_parity.txt)
 C3_HIDDEN_TOL = 4.5e-2
 
 
@@ -168,6 +169,50 @@ def test_benchmarked_configuration_matches_reference_c3(golden_dir):
     assert float(elbo(lp, lq, nll.double(), n_batches)) == pytest.approx(ref_loss, rel=1e-3)
 
 
+def test_reference_style_serial_loop_matches_c3(golden_dir):
+    """The reference's own caller loop, as a user script that only swaps the package would run it
+    (/root/reference/examples/bert_glue.py:63-66: S serial forwards of one sample each, log_prior() and
+    log_variational_posterior() read after every forward), on the benchmarked BERT-base model against the reference's
+    per-sample outputs (tests/golden/bert_c3.npz).  Forwards 0 and 1 run eagerly, from the third on bnn.Model.__call__
+    replays the forward from a HIP graph (bayeformers_amd/graphs.py): both paths are held to the same fixture rows."""
+    import bench
+    from bayeformers_amd import random as bfr
+
+    g = np.load(f"{golden_dir}/bert_c3.npz")
+    S, B = int(g["S"]), int(g["B"])
+    bf.set_compute_dtype("bf16")
+    bmodel, _, inputs, ids, labels, _ = bench.build_bert(torch.device("cuda"), "bf16")
+    assert int(ids.sum()) == int(g["ids_sum"])
+    logits = torch.zeros(S, B, 2, device="cuda")
+    log_prior = torch.zeros(S, device="cuda", dtype=torch.float64)
+    lvp = torch.zeros(S, device="cuda", dtype=torch.float64)
+    bf.manual_seed(SEED)
+    try:
+        with torch.no_grad():
+            for s in range(S):
+                logits[s] = bmodel(**inputs)[0]
+                log_prior[s] = bmodel.log_prior()
+                lvp[s] = bmodel.log_variational_posterior()
+        cache = bmodel._graphs
+        assert len(cache.forwards) == 1 and cache.forwards[0][1].captures == 1   # forwards 2 .. 9 were replays
+        assert bfr.STATE.device_counter is not None and int(bfr.STATE.device_counter.item()) == S
+    finally:
+        bmodel._graphs.close()
+    assert bfr.STATE.device_counter is None and bfr.get_state()[1] == S   # the counter is back on the host, advanced by S
+    # log_prior() is the reference's fp32 scalar: one fp32 rounding of a ~3e8 sum
+    np.testing.assert_allclose(log_prior.cpu().numpy(), g["log_prior"], rtol=2e-6)
+    np.testing.assert_allclose(lvp.cpu().numpy(), g["lvp"], rtol=2e-6)
+    err = np.abs(logits.cpu().numpy() - g["logits"]).max(axis=(1, 2))
+    print("[c3 serial reference loop] max |logit - ref| per sample: " + " ".join(f"{e:.2e}" for e in err))
+    assert err.max() < C3_LOGIT_TOL
+    mean_logits = logits.mean(0)
+    nll = torch.nn.functional.cross_entropy(mean_logits, labels.cuda())
+    assert float(nll) == pytest.approx(float(g["nll"]), abs=1e-3)
+    n_batches = 2105
+    ref_loss = (g["lvp"].mean() - g["log_prior"].mean()) / n_batches + float(g["nll"])
+    assert float(elbo(log_prior.mean(), lvp.mean(), nll.double(), n_batches)) == pytest.approx(ref_loss, rel=1e-3)
+
+
 def test_config4_shards_of_8_match_reference_c4(golden_dir):
     """BASELINE config 4 at size: S = 64 Monte-Carlo samples of BERT-base (B=32, L=128) as 8 shards of 8 — what rank r
     of 8 runs is `monte_carlo(8, shard=(r, 8))` — executed here one shard after the other on one GPU, in the
@@ -187,8 +232,7 @@ def test_config4_shards_of_8_match_reference_c4(golden_dir):
     rep = repeat_inputs(inputs, s_local)
     sum_logits = torch.zeros(B, 2, dtype=torch.float64, device="cuda")
     sum_lp = torch.zeros(2, dtype=torch.float64, device="cuda")
-    tol = 5e-2
-    scale = max(1.0, np.abs(g["logits"]).max())
+    errs = []
     for r in range(G):
         bf.manual_seed(SEED)  # every rank starts the step from the same global sample counter
         with torch.no_grad(), bmodel.monte_carlo(s_local, shard=(r, G)):
@@ -198,12 +242,15 @@ def test_config4_shards_of_8_match_reference_c4(golden_dir):
         sl = slice(r * s_local, (r + 1) * s_local)
         np.testing.assert_allclose(lps[:, 0].cpu().numpy(), g["log_prior"][sl], rtol=2e-6)
         np.testing.assert_allclose(lps[:, 1].cpu().numpy(), g["lvp"][sl], rtol=2e-6)
-        assert np.abs(logits.cpu().numpy() - g["logits"][sl]).max() < tol * scale, r
+        errs.append(float(np.abs(logits.cpu().numpy() - g["logits"][sl]).max()))
         sum_logits += logits.double().sum(0)   # what the rank would contribute to the all-reduce
         sum_lp += lps.sum(0)
     mean_logits = (sum_logits / S).float()
     nll = torch.nn.functional.cross_entropy(mean_logits, labels.cuda())
-    assert float(nll) == pytest.approx(float(g["nll"]), rel=tol, abs=tol)
+    print("[c4 shards of 8] max |logit - ref| per shard: " + " ".join(f"{e:.2e}" for e in errs) +
+          f" (max |logit| {np.abs(g['logits']).max():.3f}); |nll - ref| = {abs(float(nll) - float(g['nll'])):.3e}")
+    assert max(errs) < C4_LOGIT_TOL, errs   # an ABSOLUTE bound at 2x the measured error, like configuration 3's
+    assert float(nll) == pytest.approx(float(g["nll"]), abs=1e-3)
     lp, lq = sum_lp[0] / S, sum_lp[1] / S
     n_batches = 2105
     ref_loss = (g["lvp"].mean() - g["log_prior"].mean()) / n_batches + float(g["nll"])
@@ -406,7 +453,9 @@ def _c5_scales(g):
 # tolerances relative to the largest per-sample logit (operand rounding through 24 layers); the mean over S = 10 samples
 # is checked against the same ABSOLUTE bound / sqrt(S): rounding errors of independent samples average out like the
 # logits themselves do
-@pytest.mark.parametrize("dtype,tol", [("fp16", 2e-2), ("bf16", 8e-2)])
+# round 6: 2x the measured errors (profiles/r6d_pytest_new_parity.txt: fp16 1.28e-3 per sample / 3.8e-4 on the means, bf16 1.02e-2 /
+# 3.7e-3, largest |logit| 1.048) — the bounds were 2e-2 and 8e-2
+@pytest.mark.parametrize("dtype,tol", [("fp16", 2.5e-3), ("bf16", 2.0e-2)])
 def test_bert_large_qa_c5(golden_dir, dtype, tol):
     """BASELINE config 5: to_bayesian(BERT-large QA), S=10, seq=384, batch=16, fp16 MFMA (and bf16), vs the reference."""
     g = np.load(f"{golden_dir}/bert_large_qa_c5.npz")
@@ -424,11 +473,17 @@ def test_bert_large_qa_c5(golden_dir, dtype, tol):
     np.testing.assert_allclose(lps[:, 1], g["lvp"], rtol=2e-6)
     start, end = raw[0].float().cpu().numpy(), raw[1].float().cpu().numpy()
     mean_scale, sample_scale = _c5_scales(g)
-    assert np.abs(start[0] - g["start_s0"]).max() < tol * sample_scale
-    assert np.abs(end[9] - g["end_s9"]).max() < tol * sample_scale
-    assert np.abs(start.mean(0) - g["start_mean"]).max() < tol * sample_scale / np.sqrt(S)
-    assert np.abs(end.mean(0) - g["end_mean"]).max() < tol * sample_scale / np.sqrt(S)
-    assert np.abs(mean[0].float().cpu().numpy() - g["start_mean"]).max() < tol * sample_scale / np.sqrt(S)
+    seqs = g["mid_seqs"]
+    e_s = {"start[0]": np.abs(start[0] - g["start_s0"]).max(), "end[9]": np.abs(end[9] - g["end_s9"]).max()}
+    for k in (3, 6):  # round 6: two samples from the middle of the step, both heads, four sequences
+        e_s[f"start[{k}]"] = np.abs(start[k][seqs] - g[f"start_s{k}"]).max()
+        e_s[f"end[{k}]"] = np.abs(end[k][seqs] - g[f"end_s{k}"]).max()
+    e_m = {"start": np.abs(start.mean(0) - g["start_mean"]).max(), "end": np.abs(end.mean(0) - g["end_mean"]).max(),
+           "returned start": np.abs(mean[0].float().cpu().numpy() - g["start_mean"]).max()}
+    print(f"[c5 {dtype}] per-sample max |logit - ref| (largest |logit| {sample_scale:.3f}): " +
+          " ".join(f"{k} {v:.2e}" for k, v in e_s.items()) + "; means: " + " ".join(f"{k} {v:.2e}" for k, v in e_m.items()))
+    assert max(e_s.values()) < tol * sample_scale, e_s
+    assert max(e_m.values()) < tol * sample_scale / np.sqrt(S), e_m
 
 
 def test_config5_shards_match_reference_c5(golden_dir):
@@ -441,7 +496,7 @@ def test_config5_shards_match_reference_c5(golden_dir):
 
     g = np.load(f"{golden_dir}/bert_large_qa_c5.npz")
     S, B, L = int(g["S"]), int(g["B"]), int(g["L"])
-    G, dtype, tol = 8, "fp16", 2e-2
+    G, dtype, tol = 8, "fp16", 2.5e-3
     spans = [shard_span(S, r, G) for r in range(G)]
     assert [c for _, c in spans] == [2, 2, 1, 1, 1, 1, 1, 1] and [s for s, _ in spans] == [0, 2, 4, 5, 6, 7, 8, 9]
     bmodel, inputs = _bert_large_c5(g, dtype)
@@ -465,6 +520,13 @@ def test_config5_shards_match_reference_c5(golden_dir):
                 assert np.abs(st[0].cpu().numpy() - g["start_s0"]).max() < tol * sample_scale
             if start + count == S:
                 assert np.abs(en[-1].cpu().numpy() - g["end_s9"]).max() < tol * sample_scale
+            for k in (3, 6):  # a rank whose whole shard is one of the samples pinned in full at four sequences
+                if start <= k < start + count:
+                    seqs = g["mid_seqs"]
+                    e3 = max(np.abs(st[k - start].cpu().numpy()[seqs] - g[f"start_s{k}"]).max(),
+                             np.abs(en[k - start].cpu().numpy()[seqs] - g[f"end_s{k}"]).max())
+                    print(f"[c5 shards] rank {r} runs sample {k}: max |logit - ref| = {e3:.2e}")
+                    assert e3 < tol * sample_scale
             sum_start += st.double().sum(0)
             sum_end += en.double().sum(0)
             assert bf.random.get_state()[1] == S  # the step consumed the 10 global indices on every rank
@@ -949,3 +1011,30 @@ def test_bench_line_carries_the_contract_keys():
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["value"] > 0
     assert "HSA_ENABLE_IPC_MODE_LEGACY" in d["config"]["env"]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+def test_bench_bert_line_accounts_for_the_sampling_launch_and_the_positions(dtype):
+    """every dtype's line charges the cross-layer sampling launch with the plan's bytes (fp32 used to report
+    the pooler's 33 MB for the model's 4 GB: frac 0.005), and carries the per-position fractions of the tiled GEMM."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "bert_base", "--dtype", dtype, "--steps", "2",
+                        "--warmup", "1", "--no-traffic", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    roof = d["roofline"]
+    sk = roof["sample_kernel"]
+    es = 4 if dtype == "fp32" else 2
+    assert sk["bytes_per_step"] >= 85609730 * (8 + 10 * es) * 0.98          # the plan's scalars: read once, ten samples written
+    assert 0.3 < sk["frac"] < 1.0, sk
+    pos = roof["by_position"]
+    assert set(pos) == {"qkv", "attn_out", "ffn_up_gelu", "ffn_down"}
+    assert abs(sum(v["share_of_gemm_time"] for v in pos.values()) - 1.0) < 1e-3
+    assert all(0.05 < v["frac"] < 1.0 for v in pos.values()), pos
+    lo, hi = min(v["frac"] for v in pos.values()), max(v["frac"] for v in pos.values())
+    assert lo * 0.9 <= roof["frac"] <= hi   # (fp32: roofline.frac also holds the pooler's and the classifier's small launches)

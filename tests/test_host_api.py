@@ -111,7 +111,7 @@ def test_header_and_library_export_the_same_symbols():
     lib = ctypes.CDLL(_C.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert _C.lib().bf_version() == _C.ABI_VERSION == 5
+    assert _C.lib().bf_version() == _C.ABI_VERSION == 6
 
 
 def test_struct_layout_matches_header():
@@ -298,3 +298,21 @@ def test_moped_prior_alias_is_decided_on_contents_and_tracks_edits():
     with torch.no_grad():
         lin.weight_prior.mu.copy_(lin.weight.mu)
     assert ops.prior_alias(lin.weight, lin.weight_prior) is not None
+
+
+def test_bayesian_children_walk_is_kept_and_notices_a_swapped_layer():
+    """Model.log_prior() asks for the Bayesian children on every call (model.py:70-78); the walk is kept between calls and
+    thrown away when a kept child is no longer registered where it was found."""
+    import bayeformers_amd as bf
+
+    net = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.ReLU(), torch.nn.Linear(8, 4))
+    b = bf.to_bayesian(net)
+    first, only = b._children()
+    assert len(first) == 2 and only and b._children()[0] is first          # kept
+    assert list(b.bayesian_children) == first                              # the reference's property still walks
+    b.model[2] = torch.nn.Linear(8, 4)                                     # a frequentist layer takes a Bayesian one's place
+    again, only = b._children()
+    assert len(again) == 1 and again is not first and only
+    b.model[2] = bnn.Linear(8, 4)
+    b.refresh()
+    assert len(b._children()[0]) == 2

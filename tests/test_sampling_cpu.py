@@ -193,3 +193,38 @@ def test_local_step_and_finish_are_sample_bayesian():
         mean2, lp2, lq2 = _finish_step(raw2, sizes, local, 3, None, False)
     assert torch.equal(raw[0], raw2[0]) and torch.equal(mean[0], mean2[0]) and lp == lp2 and lq == lq2
     assert len(local) == 1 and local[0].dtype == torch.float64 and local[0].numel() == sizes[0] + 2
+
+
+def test_select_key_recognises_a_selection_only_by_value():
+    """the cache key of a `select` callable must not rest on id()s of captured objects (an id is reused once its
+    object is gone; a captured list can be mutated in place)."""
+    import functools
+
+    from bayeformers_amd.sampling import _select_key
+
+    def pick(i):
+        return lambda out: (out[i],)
+
+    assert _select_key(pick(1)) == _select_key(pick(1)) and _select_key(pick(1)) != _select_key(pick(2))
+    assert _select_key(None) == _select_key(None)
+    idx = [0]
+    assert _select_key(lambda out: (out[idx[0]],)) is None       # a captured list: could be mutated between calls
+    t = torch.zeros(1)
+    assert _select_key(lambda out: (out + t,)) is None            # a captured tensor
+
+    def plain(out):
+        return (out,)
+
+    assert _select_key(plain) == _select_key(plain)
+    assert _select_key(functools.partial(plain)) == _select_key(functools.partial(plain))
+    assert _select_key(functools.partial(pick, 1)) == _select_key(functools.partial(pick, 1))
+    assert _select_key(functools.partial(pick, [1])) is None
+
+    def outer():
+        def inner(out):
+            return late(out)   # noqa: F821 - a cell that is still empty when the key is taken
+        key = _select_key(inner)
+        late = plain   # noqa: F841
+        return key
+
+    assert outer() is None

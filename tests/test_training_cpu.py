@@ -309,3 +309,18 @@ def test_buckets_settle_on_the_parameters_that_receive_gradients():
     buckets.zero()
     with pytest.raises(RuntimeError, match="had no gradient in the first step"):
         (torch.ones(2, 8) @ (w + prior) + b).sum().backward()
+
+
+def test_dropout_group_numbering_refuses_an_unsplittable_shard():
+    """a shard that does not start at global sample 0 numbers its dropout groups from
+    first_sample x (groups per sample); a tensor that cannot be cut into the shard's samples used to fall back to 0 —
+    the masks of samples 0.., correlated across ranks — without a word."""
+    from bayeformers_amd import _C
+    from bayeformers_amd.ops import Dropout
+
+    d0 = Dropout(0.1, 1, 0, 1, origin=(0, 3))
+    assert d0.first_group(7, 96) == 0                     # the first shard numbers from 0 whatever the tensor looks like
+    d = Dropout(0.1, 1, 0, 1, origin=(4, 2))              # global samples 4 and 5
+    assert d.first_group(2 * 160, 96) == 4 * 160 * 96
+    with pytest.raises(_C.BayeFormersAMDError, match="cannot be split"):
+        d.first_group(2 * 160 + 1, 96)
