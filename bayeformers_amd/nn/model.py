@@ -42,7 +42,8 @@ class _ForwardContext:
     """What the Bayesian layers of one Model.forward share: the reserved sample indices, their log-prob slots and
     (when every layer is plannable) the cross-layer sampling plan."""
 
-    def __init__(self, sample_base: int, S: int, slots: dict, plan=None, lp_buf=None, shard_start: int = 0, dropping: bool = True):
+    def __init__(self, sample_base: int, S: int, slots: dict, plan=None, lp_buf=None, shard_start: int = 0, dropping: bool = True,
+                 drop_sites=None):
         self.sample_base, self.S, self._slots = sample_base, S, slots
         self.plan, self.lp_buf = plan, lp_buf
         self.token = next(_TOKENS)
@@ -59,6 +60,7 @@ class _ForwardContext:
         self.drop_call = bfr.reserve_dropout_call()
         self.drop_counter = bfr.reserve_dropout_counter(needed=dropping)  # device-counter mode: this forward's copy of it
         self.shard_start = int(shard_start)
+        self.drop_sites = drop_sites  # the owning model's [next free dropout site number] (random.dropout_site)
 
     @contextlib.contextmanager
     def replay(self):
@@ -184,7 +186,8 @@ class Model(Module):
         base = bfr.reserve_samples(total) + start
         self._last_base, self._last_seed, self._last_S = base, bfr.STATE.seed, S
         self._last_counter = bfr.counter_snapshot() if bfr.STATE.kl_gradient else None
-        ctx = bfr.STATE.ctx = _ForwardContext(base, S, slots, plan, self._lp_buf, shard_start=start, dropping=self.training)
+        ctx = bfr.STATE.ctx = _ForwardContext(base, S, slots, plan, self._lp_buf, shard_start=start, dropping=self.training,
+                                              drop_sites=self.__dict__.setdefault("_drop_sites", [1]))
         out = None
         try:
             out = super(Model, self).__call__(*args, **kwargs)

@@ -242,11 +242,19 @@ def dropout_origin():
 
 
 def dropout_site(module) -> int:
-    """The `site` number of a module (assigned at its first dropout, in execution order: stable for a given model)."""
+    """The `site` number of a module: assigned at its first dropout, in execution order, from the counter of the bnn.Model whose
+    forward is running — a model's masks are a function of (seed, call, its own modules), not of what other models this process
+    ran before (round 6: the counter used to be process-wide).  Outside any bnn.Model forward: a process-wide counter."""
     site = getattr(module, "_bf_drop_site", None)
     if site is None:
-        site = module._bf_drop_site = STATE.next_dropout_site
-        STATE.next_dropout_site += 1
+        ctx = STATE.ctx if STATE.ctx is not None else recompute_context()
+        counter = getattr(ctx, "drop_sites", None) if ctx is not None else None
+        if counter is not None:
+            site = module._bf_drop_site = counter[0]
+            counter[0] += 1
+        else:
+            site = module._bf_drop_site = STATE.next_dropout_site
+            STATE.next_dropout_site += 1
     return site
 
 

@@ -273,3 +273,111 @@ def training_step(model: Model, inputs, samples: int, nll_fn: Callable, optimize
             if hasattr(optimizer, name):
                 delattr(optimizer, name)
     return loss.detach()
+
+
+class GraphedTrainingStep:
+    """`training_step` for ONE batch signature on one process, replayed from a HIP graph: forward of the S samples, ELBO,
+    backward, gradient clipping and the optimizer update are captured once and replayed — the 681 launches of a BERT-base
+    step cost the host one `graph.replay()` instead of 19-22 ms of Python and launch calls (profiles/r5s_*), which is what
+    bounds the step once a rank's shard is one or two samples.
+
+        opt = torch.optim.AdamW(params, lr=2e-5, fused=True, capturable=True)
+        step = GraphedTrainingStep(bmodel.train(), inputs, samples=10, nll_fn=nll, optimizer=opt, n_batches=2105)
+        for batch in loader:
+            loss = step(batch)          # same shapes / dtypes: copied into the captured buffers
+
+    Step k is the k-th eager `training_step` bit for bit: the Monte-Carlo sample counter AND the dropout call counter live in
+    device memory while the object exists (`random.use_device_counter`), the captured step copies and advances both, so every
+    replay draws fresh epsilon and fresh masks; torch's own dropout (the embedding block) advances through its graph-safe
+    generator.  The first `eager_steps` calls run the ordinary eager step (they ARE training steps: optimizer state, sampling
+    plan, workspaces and tile schedules come into being there); the next call captures and replays.
+    Needs: one process (S-sharded ranks keep the eager step: their bucketed gradient all-reduce runs under backward), an
+    optimizer built with `capturable=True`; its learning rate is turned into a device tensor (a scheduler's `fill_` is seen by
+    the replays).  What a capture bakes in besides the shapes — seed, compute dtype, sampling plan, parameter addresses — is
+    re-checked before every replay; a difference captures again (graphs.still_valid).  The returned loss is the graph's buffer."""
+
+    def __init__(self, model: Model, inputs, samples: int, nll_fn: Callable, optimizer: torch.optim.Optimizer, n_batches: int,
+                 max_grad_norm: Optional[float] = 1.0, select: Optional[Callable] = None, eager_steps: int = 2) -> None:
+        from . import graphs
+        from .sampling import GraphedSampler
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError("GraphedTrainingStep: S-sharded ranks run the eager training_step (bucketed all-reduce under backward)")
+        if not all(g.get("capturable") for g in optimizer.param_groups):
+            raise RuntimeError("GraphedTrainingStep: build the optimizer with capturable=True (its step count must live on the GPU)")
+        leaves = GraphedSampler._leaves(inputs)
+        tensors = [v for v in leaves if isinstance(v, Tensor)]
+        if not tensors or not all(t.is_cuda for t in tensors):
+            raise RuntimeError("GraphedTrainingStep: the inputs must be tensors on the GPU the model runs on")
+        self.model, self.samples, self.nll_fn, self.optimizer = model, int(samples), nll_fn, optimizer
+        self.n_batches, self.max_grad_norm, self.select = n_batches, max_grad_norm, select
+        self.device = tensors[0].device
+        self._signature = GraphedSampler._sig(inputs)
+        self._inputs = GraphedSampler._map(inputs, lambda v: v.clone())
+        for g in optimizer.param_groups:  # a python float would be baked into the captured update
+            if not isinstance(g["lr"], Tensor):
+                g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float32, device=self.device)
+        self.graph = self._loss = None
+        self.steps = self.captures = 0
+        self._eager_steps = max(1, int(eager_steps))
+        graphs.acquire_counter(self.device)
+        self._open = True
+
+    def load(self, inputs) -> None:
+        from .sampling import GraphedSampler
+
+        if GraphedSampler._sig(inputs) != self._signature:
+            raise ValueError("GraphedTrainingStep: the batch differs from the captured one in structure, shape, dtype or device")
+        for dst, src in zip(GraphedSampler._leaves(self._inputs), GraphedSampler._leaves(inputs)):
+            if isinstance(src, Tensor):
+                dst.copy_(src)
+
+    def _eager(self) -> Tensor:
+        return training_step(self.model, self._inputs, self.samples, self.nll_fn, self.optimizer, self.n_batches,
+                             max_grad_norm=self.max_grad_norm, select=self.select)
+
+    def _capture(self) -> None:
+        from . import graphs, sampling
+
+        self.graph = self._loss = None
+        sampling._REPEAT_CACHE.clear()  # the S-fold repeat of the inputs must be a launch OF the graph, not a kept tensor
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.device(self.device):
+            self.optimizer.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                loss = self._eager()
+        sampling._REPEAT_CACHE.clear()  # (what the capture put there lives in the graph's memory pool)
+        self.graph, self._loss = graph, loss
+        self._baked = graphs.baked_state(self.model)
+        self.captures += 1
+
+    def __call__(self, inputs=None) -> Tensor:
+        from . import graphs
+
+        if not self._open:
+            raise RuntimeError("GraphedTrainingStep: closed")
+        if inputs is not None:
+            self.load(inputs)
+        if self.graph is None and self.steps < self._eager_steps:
+            self.steps += 1
+            return self._eager()
+        if self.graph is None or not graphs.still_valid(self.model, self._baked):
+            self._capture()   # (a capture executes nothing: the replay below is this call's step)
+        self.graph.replay()
+        self.steps += 1
+        return self._loss
+
+    def close(self) -> None:
+        from . import graphs
+
+        self.graph = self._loss = None
+        if self._open:
+            self._open = False
+            graphs.release_counter()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -68,7 +68,8 @@ def parse():
                     help="replay the step from a HIP graph (device-resident sample counter: every replay draws fresh "
                          "epsilon); auto = the single-layer / MLP workloads on one rank (whole step captured) and the BERT "
                          "forward workloads through sampling.GraphedSampler: on one rank always, on several ranks when a "
-                         "rank's shard is <= 4 samples; training steps are never captured")
+                         "rank's shard is <= 4 samples; the training workloads through training.GraphedTrainingStep on one rank "
+                         "(S-sharded ranks run the eager step: bucketed gradient all-reduce under backward)")
     return ap.parse_args()
 
 
@@ -209,7 +210,30 @@ def build_bert(device, dtype):
     return bmodel, model, inputs, ids, labels, info
 
 
-def make_bert(device, S, dtype, train=False, train_mode=False, serial=False):
+def _graphed_train_step(bmodel, inputs, samples, nll_fn, opt, n_batches, max_grad_norm, eager):
+    """The training workloads' step through training.GraphedTrainingStep (one process): two eager steps, then the step replayed
+    from a HIP graph.  If the capture fails the eager step keeps running and the line says so (`step.note`)."""
+    from bayeformers_amd.training import GraphedTrainingStep
+
+    state = {"g": GraphedTrainingStep(bmodel, inputs, samples, nll_fn, opt, n_batches, max_grad_norm=max_grad_norm), "note": None}
+
+    def step():
+        g = state["g"]
+        if g is None:
+            return eager()
+        try:
+            return g()
+        except Exception as e:  # noqa: BLE001 - whatever the capture raised, the eager step is still the product path
+            state["g"], state["note"] = None, f"capture failed, step ran eagerly ({type(e).__name__}: {str(e)[:160]})"
+            print(f"bench.py: {state['note']}", file=sys.stderr)
+            g.close()
+            return eager()
+
+    step.state, step.eager = state, eager
+    return step
+
+
+def make_bert(device, S, dtype, train=False, train_mode=False, serial=False, graph_train=False):
     from bayeformers_amd.sampling import elbo, sample_bayesian
 
     B, L, n_batches = 32, 128, 2105  # SST-2: 67,349 train sentences / 32
@@ -251,7 +275,8 @@ def make_bert(device, S, dtype, train=False, train_mode=False, serial=False):
         if train_mode:
             bmodel.train()
         params = [p for p in bmodel.parameters() if p.requires_grad]
-        opt = torch.optim.AdamW(params, lr=2e-5, eps=1e-8, weight_decay=0.0, fused=True)
+        graph_train = graph_train and _ranks() == 1 and os.environ.get("BF_BENCH_TRAIN_BUCKETS") is None
+        opt = torch.optim.AdamW(params, lr=2e-5, eps=1e-8, weight_decay=0.0, fused=True, capturable=graph_train)
         # world > 1: flat gradient buffers, all-reduced over the ranks while backward runs
         buckets = GradientBuckets(params) if _ranks() > 1 or os.environ.get("BF_BENCH_TRAIN_BUCKETS") is not None else None
 
@@ -262,6 +287,10 @@ def make_bert(device, S, dtype, train=False, train_mode=False, serial=False):
             # examples/bert_glue.py:227-241: forward, ELBO, backward, clip_grad_norm_(1), optimizer step
             return training_step(bmodel, inputs, S * _world(), nll_fn, opt, n_batches, buckets=buckets,
                                  max_grad_norm=None if os.environ.get("BF_BENCH_TRAIN_NO_CLIP") is not None else 1.0)
+
+        if graph_train:
+            step = _graphed_train_step(bmodel, inputs, S, nll_fn, opt, n_batches,
+                                       None if os.environ.get("BF_BENCH_TRAIN_NO_CLIP") is not None else 1.0, step)
 
     def cpu_baseline():
         from oracle.model_oracle import log_probs, to_oracle
@@ -289,7 +318,7 @@ def make_bert(device, S, dtype, train=False, train_mode=False, serial=False):
     return step, cpu_baseline, cfgd, bmodel
 
 
-def make_bert_large_qa(device, S, dtype, train=False, train_mode=False):
+def make_bert_large_qa(device, S, dtype, train=False, train_mode=False, graph_train=False):
     """BASELINE config 5: to_bayesian(BERT-large QA) SQuAD-shaped forward + ELBO, seq=384, batch=16.  train: the training
     step of the reference's SQuAD loop (examples/bert_squad.py:456-491: forward of S samples, ELBO with the mean of the
     start / end cross-entropies, backward, clip_grad_norm_(1), AdamW) on the same batch."""
@@ -330,7 +359,8 @@ def make_bert_large_qa(device, S, dtype, train=False, train_mode=False):
         if train_mode:
             bmodel.train()
         params = [p for p in bmodel.parameters() if p.requires_grad]
-        opt = torch.optim.AdamW(params, lr=3e-5, eps=1e-8, weight_decay=0.0, fused=True)
+        graph_train = graph_train and _ranks() == 1
+        opt = torch.optim.AdamW(params, lr=3e-5, eps=1e-8, weight_decay=0.0, fused=True, capturable=graph_train)
         buckets = GradientBuckets(params) if _ranks() > 1 else None
 
         def nll_fn(mean):
@@ -339,6 +369,9 @@ def make_bert_large_qa(device, S, dtype, train=False, train_mode=False):
 
         def step():  # noqa: F811
             return training_step(bmodel, inputs, S * _world(), nll_fn, opt, n_batches, buckets=buckets, max_grad_norm=1.0)
+
+        if graph_train:
+            step = _graphed_train_step(bmodel, inputs, S, nll_fn, opt, n_batches, 1.0, step)
 
     def cpu_baseline():
         from oracle.model_oracle import log_probs, to_oracle
@@ -730,6 +763,13 @@ def dry_run(args, world, rank, device, samples):
         sys.exit(3)
 
 
+def _train_graph_note(step):
+    st = getattr(step, "state", None)
+    if st is None:
+        return False
+    return st["note"] or ("GraphedTrainingStep" if st["g"] is not None and st["g"].graph is not None else False)
+
+
 DEFAULTS = {"bert_base": (10, "bf16"), "bert_base_serial": (10, "bf16"), "bert_base_train": (10, "bf16"), "bert_large_qa": (10, "fp16"),
             "bert_large_qa_train": (10, "bf16"), "linear768": (10, "bf16"), "linear768_m32": (10, "bf16"), "mlp": (5, "bf16")}
 
@@ -806,11 +846,13 @@ def main():
         step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype, serial=True)
         delattr(step, "harness") if hasattr(step, "harness") else None
     elif args.workload == "bert_base_train":
-        step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype, train=True, train_mode=not args.no_dropout)
+        step, cpu_baseline, cfgd, bmodel = make_bert(device, S, dtype, train=True, train_mode=not args.no_dropout,
+                                                     graph_train=args.graph != "off")
     elif args.workload == "bert_large_qa":
         step, cpu_baseline, cfgd, bmodel = make_bert_large_qa(device, S, dtype)
     elif args.workload == "bert_large_qa_train":
-        step, cpu_baseline, cfgd, bmodel = make_bert_large_qa(device, S, dtype, train=True, train_mode=not args.no_dropout)
+        step, cpu_baseline, cfgd, bmodel = make_bert_large_qa(device, S, dtype, train=True, train_mode=not args.no_dropout,
+                                                              graph_train=args.graph != "off")
     elif args.workload == "linear768":
         step, cpu_baseline, cfgd, bmodel = make_linear(device, S, dtype, 4096)
     elif args.workload == "linear768_m32":
@@ -825,8 +867,8 @@ def main():
     # Launch-bound workloads (tens of microseconds of GPU work per step) are replayed from a HIP graph: the whole
     # step — sampling, GEMMs, ELBO — is captured once; the Monte-Carlo sample counter lives on the device so every
     # replay draws fresh epsilon (bayeformers_amd.use_device_counter).
-    use_graph = args.graph == "on" or (args.graph == "auto" and world == 1 and
-                                       args.workload in ("linear768", "linear768_m32", "mlp"))
+    use_graph = (args.graph == "on" and not args.workload.endswith("_train")) or (
+        args.graph == "auto" and world == 1 and args.workload in ("linear768", "linear768_m32", "mlp"))
     # The BERT forward workloads go through the library's GraphedSampler instead (the rank's forward + sums in the graph,
     # the S-shard group's collective eagerly after the replay).  A host that takes 4-7 ms to enqueue a forward hides behind
     # the 8.5 ms of kernels of ten samples but not behind the 2-3 ms of a one-to-three-sample shard: auto = on one rank
@@ -886,7 +928,7 @@ def main():
     lib.bf_profile_reset()
     lib.bf_profile_enable(1)
     prof_steps = max(1, min(args.steps, 5))
-    prof_step = eager_step if use_graph else step
+    prof_step = eager_step if use_graph else getattr(step, "eager", step)  # (a graphed training step: its eager form)
     if harness is not None:
         harness.graphed(False)  # the profiling hooks time single launches: eager calls
     auto_replays = None
@@ -1041,7 +1083,8 @@ def main():
         if pre is not None:  # the N-rank run's own preflight: who took part, what the two message kinds cost
             cfgd["preflight"] = {k: pre[k] for k in ("backend", "ranks", "ranks_counted", "bucket_ranks_counted",
                                                      "allreduce_ms", "rccl_version") if k in pre}
-        cfgd.update({"env": honoured_env(), "parallelism": f"mc-sample-shard x{n_ranks}", "last_elbo": last, "hip_graph": graph_note if harness is not None and graph_note else (bool(use_graph) or ("bnn.Model.__call__ replay" if auto_replays else False)),
+        cfgd.update({"env": honoured_env(), "parallelism": f"mc-sample-shard x{n_ranks}", "last_elbo": last, "hip_graph": graph_note if harness is not None and graph_note else (
+                         bool(use_graph) or ("bnn.Model.__call__ replay" if auto_replays else False) or _train_graph_note(step)),
                      "samples_total": total_samples, "samples_per_step": per_step,
                      "allreduce_ms_per_step": round(allreduce_ms, 4) if allreduce_ms is not None else None})
         metric = "MC-samples/sec (fwd+ELBO+backward+AdamW)" if args.workload.endswith("_train") else "MC-samples/sec (fwd+ELBO)"

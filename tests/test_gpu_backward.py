@@ -740,3 +740,92 @@ def test_folded_column_sums_give_the_bias_gradients_of_the_plain_path():
         if "embeddings" in n and "LayerNorm" not in n:
             tol = 5e-2 * scale   # the framework's embedding backward scatters with bf16 atomics: not run-to-run reproducible
         assert (plain[n] - folded[n]).abs().max().item() <= tol, n
+
+
+@pytest.mark.parametrize("train_mode", [False, True])
+def test_graphed_training_step_is_the_eager_step(golden_dir, train_mode):
+    """training.GraphedTrainingStep on the tiny BERT of bert_tiny_train.npz in bench.py's rewritten form: two eager steps, one
+    capture, three replays — step k (loss and EVERY parameter afterwards) is the k-th eager training_step bit for bit, also
+    with the model in train() (HF dropout 0.1 inside the kernels: the device-resident call counter gives every replay the masks
+    of its own step), also when a new batch is copied in."""
+    import copy
+
+    from bayeformers_amd import random as bfr
+    from bayeformers_amd.training import GraphedTrainingStep, training_step
+
+    g, bmodel0, _, inputs, labels = _tiny_train_setup(golden_dir, "bf16", True)
+    S, NB = int(g["S"]), int(g["n_batches"])
+    batches = [inputs, {"input_ids": inputs["input_ids"].flip(0).contiguous(), "attention_mask": inputs["attention_mask"]}]
+    order = [0, 0, 1, 0, 1]
+    nll = lambda mean: torch.nn.functional.cross_entropy(mean[0].float(), labels)
+    bf.set_compute_dtype("bf16")
+
+    def fresh():
+        m = copy.deepcopy(bmodel0)
+        m.train(train_mode)
+        for mod in m.modules():   # only dropout decides training mode here; make sure it is active / inactive everywhere
+            if isinstance(mod, torch.nn.Dropout):
+                mod.train(train_mode)
+        bf.fuse_attention(m)
+        ps = [p for p in m.parameters() if p.requires_grad]
+        # (the learning rate as a device tensor in BOTH runs: GraphedTrainingStep turns a python float into one — a float would
+        # be baked into the capture — and the fused update rounds lr = 1e-3 differently as fp32 tensor and as double)
+        return m, torch.optim.AdamW(ps, lr=torch.tensor(1e-3, device="cuda"), eps=1e-8, weight_decay=0.0, fused=True, capturable=True)
+
+    torch.manual_seed(11)
+    bf.manual_seed(SEED)
+    m_e, opt_e = fresh()
+    losses_e = [float(training_step(m_e, batches[b], S, nll, opt_e, NB, max_grad_norm=1.0)) for b in order]
+    assert bfr.STATE.device_counter is None
+
+    torch.manual_seed(11)
+    bf.manual_seed(SEED)
+    m_g, opt_g = fresh()
+    step = GraphedTrainingStep(m_g, batches[0], S, nll, opt_g, NB, max_grad_norm=1.0, eager_steps=2)
+    try:
+        losses_g = [float(step(batches[b])) for b in order]
+        assert step.captures == 1 and step.steps == len(order) and bfr.STATE.device_counter is not None
+    finally:
+        step.close()
+    assert bfr.STATE.device_counter is None and bfr.get_state()[1] == S * len(order)
+    assert losses_g == losses_e, (losses_g, losses_e)
+    for (n, pe), (_, pg) in zip(m_e.named_parameters(), m_g.named_parameters()):
+        assert torch.equal(pe, pg), n
+    if train_mode:  # the steps really dropped: the same model without dropout ends elsewhere
+        assert losses_e[1] != pytest.approx(losses_e[0], rel=1e-9)
+
+
+def test_device_resident_dropout_call_draws_the_host_counters_masks(golden_dir):
+    """Device-counter mode (what a captured training step runs in): the dropout kernels add a device-resident copy of the call
+    counter to `call` = 0 — forward k must drop exactly what forward k drops with the host-side counter, in the forward and
+    in the masks its backward regenerates."""
+    g, bmodel, params, inputs, labels = _tiny_train_setup(golden_dir, "bf16", True)
+    bmodel.train()
+    bf.set_compute_dtype("bf16")
+
+    def run(device_counter):
+        bf.manual_seed(SEED)
+        torch.manual_seed(5)   # torch's own dropout (the embedding block)
+        if device_counter:
+            bf.use_device_counter(True)
+        try:
+            outs = []
+            for _ in range(3):
+                for p in bmodel.parameters():
+                    p.grad = None
+                with bmodel.monte_carlo(2):
+                    out = bmodel(**{k: v.repeat(2, 1) for k, v in inputs.items()}).logits
+                out.float().square().sum().backward()
+                outs.append((out.detach().clone(), {n: p.grad.clone() for n, p in params.items() if p.grad is not None}))
+        finally:
+            if device_counter:
+                bf.use_device_counter(False)
+        return outs
+
+    host, dev = run(False), run(True)
+    assert not torch.equal(host[0][0], host[1][0])   # the forwards differ from one another (fresh epsilon, fresh masks)
+    for k, ((oh, gh), (od, gd)) in enumerate(zip(host, dev)):
+        assert torch.equal(oh, od), k
+        assert gh.keys() == gd.keys()
+        for n in gh:
+            assert torch.equal(gh[n], gd[n]), (k, n)

@@ -207,3 +207,45 @@ def test_bench_strong_scaling_shards_one_total_unevenly():
     assert two["config"]["samples_per_gpu"] == [3, 2] and two["config"]["samples_per_step"] == 5
     assert two["config"]["samples_total"] == 10
     assert abs(two["config"]["last_elbo"] - one["config"]["last_elbo"]) <= 1e-9 * abs(one["config"]["last_elbo"])
+
+
+def _bench_line(args, env_extra):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args + ["--no-traffic", "--no-cpu-baseline"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+SHARE = {"BF_BENCH_SHARE_GPU": "1", "BF_BENCH_BACKEND": "gloo"}
+
+
+def test_bench_two_ranks_bert_base_forward_through_graphed_sampler():
+    """the BERT-base forward workload through bench.py's own launcher on two ranks (sharing this GPU, gloo on
+    the CUDA tensors) — strong scaling, S = 3 as shards of 2 + 1, each rank replaying ITS shard from a GraphedSampler graph and
+    the packed ELBO all-reduce run eagerly after the replay — must report the one-rank ELBO of the same 3 samples."""
+    one = _bench_line(["--workload", "bert_base", "--samples", "3", "--steps", "2", "--warmup", "1"], {})
+    two = _bench_line(["--workload", "bert_base", "--samples", "3", "--steps", "2", "--warmup", "1", "--gpus", "2", "--strong"], SHARE)
+    assert one["config"]["hip_graph"] == "GraphedSampler" and two["config"]["hip_graph"] == "GraphedSampler"
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["samples_per_gpu"] == [2, 1]
+    assert two["config"]["preflight"]["ranks_counted"] == 2 and len(two["roofline"]["by_rank"]["ms_per_step"]) == 2
+    assert two["config"]["last_elbo"] == pytest.approx(one["config"]["last_elbo"], rel=1e-7)
+
+
+def test_bench_two_ranks_bert_base_training_step_through_gradient_buckets():
+    """... and the training workload: two ranks of 2 samples each (weak scaling: 4 samples per step), every rank backpropagating
+    its samples, the gradients all-reduced in buckets under backward (training.GradientBuckets), against one rank running the
+    same 4 samples: the loss after three optimizer steps agrees (gradient sums in another order: not bit for bit)."""
+    one = _bench_line(["--workload", "bert_base_train", "--samples", "4", "--steps", "2", "--warmup", "1", "--graph", "off"], {})
+    two = _bench_line(["--workload", "bert_base_train", "--samples", "2", "--steps", "2", "--warmup", "1", "--gpus", "2"], SHARE)
+    assert one["config"]["samples_per_step"] == 4 and two["config"]["samples_per_step"] == 4 and two["n_gpus"] == 2
+    assert two["config"]["hip_graph"] is False           # S-sharded ranks run the eager step
+    assert two["metric"].endswith("(fwd+ELBO+backward+AdamW)")
+    assert two["config"]["last_elbo"] == pytest.approx(one["config"]["last_elbo"], rel=1e-6)
