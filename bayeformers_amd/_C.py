@@ -72,7 +72,11 @@ SYMBOLS = {
     "bf_linear_fwd": (_i, [_vp, _i, _i64, _tp, _tp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u32, _vp, _vp, _sz, _vp]),
     "bf_linear_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "bf_linear_bwd": (_i, [_vp, _i64, _vp, _i, _tp, _tp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u64, _u32, _i, _vp,
-                           _vp, _vp, _sz, _vp]),
+                           _vp, _vp, _vp, _sz, _vp]),
+    "bf_linear_bwd_splits": (_i, [_i, _i, _i, _i, _i]),
+    "bf_param_grad_table_bytes": (_sz, [_vp, _i, ctypes.POINTER(ctypes.c_uint32)]),
+    "bf_param_grad_table_build": (_i, [_vp, _i, _vp, _sz]),
+    "bf_param_grad_table": (_i, [_vp, _i, _u32, _i, _u64, _u32, _vp]),
     "bf_kl_grad": (_i, [_tp, _i, _u64, _u32, _vp, _vp, _vp, _vp]),
     "bf_embedding_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, _i64, _i, _u64, _u32, _u32, _vp]),
     "bf_embedding_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i64, _i64, _i64, _i, _u64, _u32, _u32, _vp]),
@@ -106,6 +110,11 @@ SYMBOLS = {
                              ctypes.POINTER(ctypes.c_double)]),
     "bf_profile_read_launches": (_sz, [_i, _vp, _vp, _sz]),
 }
+class bf_pgrad_t(ctypes.Structure):
+    _fields_ = [("d_dw", ctypes.c_void_p), ("d_rho", ctypes.c_void_p), ("d_dmu", ctypes.c_void_p), ("d_drho", ctypes.c_void_p),
+                ("n", ctypes.c_uint64), ("stream_id", ctypes.c_uint32), ("splits", ctypes.c_int32)]
+
+
 BF_PROF_SAMPLE, BF_PROF_GEMM, BF_PROF_FUSED_SMALL, BF_PROF_FUSED_WS = 0, 1, 2, 3
 BF_ACT_NONE, BF_ACT_GELU = 0, 1
 

@@ -656,10 +656,31 @@ size_t bf_linear_bwd_workspace_bytes(int S, int M, int N, int K, int has_bias, i
     return bwd_layout(S, M, N, K, has_bias, dtype, act).total;
 }
 
+int bf_linear_bwd_splits(int S, int M, int N, int K, int dtype) {
+    if (S < 1 || M < 1 || N < 1 || K < 1) return 0;
+    return bwd_splits(S, M, N, K, dtype);
+}
+
+size_t bf_param_grad_table_bytes(const bf_pgrad_t* entries, int n, uint32_t* total_blocks) {
+    if (!entries || n < 1) return 0;
+    return bf_pgrad_table_bytes(entries, n, total_blocks);
+}
+
+int bf_param_grad_table_build(const bf_pgrad_t* entries, int n, void* h_blob, size_t blob_bytes) {
+    if (!entries || n < 1 || !h_blob) BF_FAIL("bf_param_grad_table_build: no entries or no blob");
+    return bf_pgrad_table_build(entries, n, h_blob, blob_bytes);
+}
+
+int bf_param_grad_table(const void* d_blob, int n, uint32_t total_blocks, int S, uint64_t seed, uint32_t sample_base,
+                        void* stream) {
+    return bf_launch_pgrad_table(d_blob, n, total_blocks, S, seed, sample_base, (hipStream_t)stream);
+}
+
 int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, int dtype, const bf_tensor_t* weight,
                   const bf_tensor_t* bias, void* d_dx, float* d_dmu_w, float* d_drho_w, float* d_dmu_b,
                   float* d_drho_b, int S, int M, int N, int K, uint64_t seed, uint32_t sample_base, int act,
-                  const void* d_act_pre, const float* d_dy_colsum, void* d_workspace, size_t workspace_bytes, void* stream_) {
+                  const void* d_act_pre, const float* d_dy_colsum, float* d_dw_keep, void* d_workspace, size_t workspace_bytes,
+                  void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d_x || !d_dy || !weight || !d_drho_w) BF_FAIL("bf_linear_bwd: NULL argument");
     if (act != BF_ACT_NONE && act != BF_ACT_GELU) BF_FAIL("bf_linear_bwd: unknown activation %d", act);
@@ -717,8 +738,11 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
     //    copies and the NT kernel.
     const int sp = x_sample_stride == 0 ? 1 : L.splits;
     const int Mc = M / sp;
-    if (x_sample_stride != 0 && bf_gemm256_tn_supported(dtype, S * sp, Mc, N, K, d_dy, d_x, ws + L.dw)) {
-        if ((rc = bf_launch_gemm256_tn(d_dy, d_x, reinterpret_cast<float*>(ws + L.dw), dtype, S * sp, Mc, N, K, stream)))
+    if (d_dw_keep && (x_sample_stride == 0 || ((uintptr_t)d_dw_keep & 15)))
+        BF_FAIL("bf_linear_bwd: d_dw_keep needs per-sample activations (x_sample_stride = M*K) and a 16-byte aligned buffer");
+    char* dw_dst = d_dw_keep ? reinterpret_cast<char*>(d_dw_keep) : ws + L.dw;  // [S][sp][N][K] fp32
+    if (x_sample_stride != 0 && bf_gemm256_tn_supported(dtype, S * sp, Mc, N, K, d_dy, d_x, dw_dst)) {
+        if ((rc = bf_launch_gemm256_tn(d_dy, d_x, reinterpret_cast<float*>(dw_dst), dtype, S * sp, Mc, N, K, stream)))
             return rc;
     } else {
         const bool with_t = !fused_colsum && bias && bf_transpose_colsum_supported(dtype, S * sp, Mc, N, d_dy, ws + L.dyt);
@@ -736,16 +760,17 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
         if (x_sample_stride == 0) {
             for (int s = 0; s < S; ++s)
                 if ((rc = bf_launch_gemm_nt(ws + L.dyt + (size_t)s * N * M * es, dtype, 0, ws + L.xt, dtype, nullptr,
-                                            ws + L.dw + (size_t)s * N * K * sizeof(float), BF_DT_F32, 1, N, K, M, stream)))
+                                            dw_dst + (size_t)s * N * K * sizeof(float), BF_DT_F32, 1, N, K, M, stream)))
                     return rc;
-        } else if ((rc = bf_launch_gemm_nt(ws + L.dyt, dtype, (int64_t)N * Mc, ws + L.xt, dtype, nullptr, ws + L.dw, BF_DT_F32,
+        } else if ((rc = bf_launch_gemm_nt(ws + L.dyt, dtype, (int64_t)N * Mc, ws + L.xt, dtype, nullptr, dw_dst, BF_DT_F32,
                                            S * sp, N, K, Mc, stream))) {
             return rc;
         }
     }
-    // 4. reduce over samples (and split-K partials) with eps regenerated
-    if ((rc = bf_launch_param_grad(reinterpret_cast<const float*>(ws + L.dw), weight->d_rho, weight->n, S, sp, seed,
-                                   sample_base, weight->stream_id, d_dmu_w, d_drho_w, stream)))
+    // 4. reduce over samples (and split-K partials) with eps regenerated — unless the caller keeps dW_s and reduces the
+    //    weights of all its layers in one launch later (d_dw_keep, bf_param_grad_table)
+    if (!d_dw_keep && (rc = bf_launch_param_grad(reinterpret_cast<const float*>(dw_dst), weight->d_rho, weight->n, S, sp, seed,
+                                                 sample_base, weight->stream_id, d_dmu_w, d_drho_w, stream)))
         return rc;
     if (bias) {
         // the column sums of dy: from the pass that formed dy (fused activation / transpose), from the kernel that produced

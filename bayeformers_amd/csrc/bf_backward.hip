@@ -233,14 +233,12 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
 // load per thread and sample-split otherwise runs at 1.7 TB/s), and the sample-independent half of the Philox rounds
 // is computed once per thread (bf_philox_prepare).
 constexpr int kPgBatch = 5;  // 10 measured: no change (32.44-32.49 vs 32.45-32.50 ms per training step, three interleaved runs)
+// `g` = the thread's group of 4 scalars within the tensor
 template <bool VEC>
-__global__ __launch_bounds__(256) void param_grad_kernel(const float* __restrict__ dw, const float* __restrict__ rho,
-                                                         unsigned long long n, int S, int splits, uint32_t k0, uint32_t k1,
-                                                         uint32_t sample_base, const uint32_t* __restrict__ counter,
-                                                         uint32_t stream, float* __restrict__ dmu,
-                                                         float* __restrict__ drho) {
-    sample_base += counter ? *counter : 0u;
-    const unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void param_grad_body(const float* __restrict__ dw, const float* __restrict__ rho,
+                                                unsigned long long n, int S, int splits, uint32_t k0, uint32_t k1,
+                                                uint32_t sample_base, uint32_t stream, float* __restrict__ dmu,
+                                                float* __restrict__ drho, unsigned long long g) {
     const unsigned long long e0 = g * 4;
     if (e0 >= n) return;
     const int nv = n - e0 >= 4 ? 4 : (int)(n - e0);
@@ -303,6 +301,43 @@ __global__ __launch_bounds__(256) void param_grad_kernel(const float* __restrict
         const float zr = expf(r);
         drho[e0 + i] = se[i] * (r > 20.0f ? 1.0f : zr / (zr + 1.0f));
     }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void param_grad_kernel(const float* __restrict__ dw, const float* __restrict__ rho,
+                                                         unsigned long long n, int S, int splits, uint32_t k0, uint32_t k1,
+                                                         uint32_t sample_base, const uint32_t* __restrict__ counter,
+                                                         uint32_t stream, float* __restrict__ dmu,
+                                                         float* __restrict__ drho) {
+    sample_base += counter ? *counter : 0u;
+    param_grad_body<VEC>(dw, rho, n, S, splits, k0, k1, sample_base, stream, dmu, drho,
+                         (unsigned long long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// The same for MANY tensors in one launch (bf_param_grad_table; the sampling plan's table pattern, bf_sample.hip): block b
+// belongs to entry entry_of_block[b]; its threads are groups (b - block_begin) * 256 + tid of that entry's tensor.  A
+// BERT-base training step has 73 weight tensors whose per-sample gradients (4.6 GB of fp32 with the split-K partials) were
+// read by 73 launches of ~9 waves per CU each; one launch of 83 k blocks keeps the loads of every CU in flight.
+struct PgEntry {
+    const float* dw;
+    const float* rho;
+    float* dmu;
+    float* drho;
+    unsigned long long n;
+    uint32_t stream, block_begin;
+    int32_t splits, vec;
+};
+__global__ __launch_bounds__(256) void param_grad_table_kernel(const PgEntry* __restrict__ table,
+                                                               const uint32_t* __restrict__ entry_of_block, int S, uint32_t k0,
+                                                               uint32_t k1, uint32_t sample_base,
+                                                               const uint32_t* __restrict__ counter) {
+    const PgEntry& e = table[entry_of_block[blockIdx.x]];
+    sample_base += counter ? *counter : 0u;
+    const unsigned long long g = (unsigned long long)(blockIdx.x - e.block_begin) * 256 + threadIdx.x;
+    if (__builtin_amdgcn_readfirstlane(e.vec))
+        param_grad_body<true>(e.dw, e.rho, e.n, S, __builtin_amdgcn_readfirstlane(e.splits), k0, k1, sample_base, e.stream, e.dmu, e.drho, g);
+    else
+        param_grad_body<false>(e.dw, e.rho, e.n, S, __builtin_amdgcn_readfirstlane(e.splits), k0, k1, sample_base, e.stream, e.dmu, e.drho, g);
 }
 
 // Opt-in Bayes-by-Backprop gradient of the KL terms (the reference detaches them, layers/linear.py:99-102):
@@ -643,6 +678,46 @@ int bf_launch_colsum(const void* d_dy, int dtype, float* d_out, int S, int M, in
         hipLaunchKernelGGL(colsum_kernel<_Float16>, grid, dim3(256), 0, stream, (const _Float16*)d_dy, d_out, M, N);
     else
         hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, stream, (const float*)d_dy, d_out, M, N);
+    BF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static uint32_t pg_blocks(uint64_t n) { return (uint32_t)(((n + 3) / 4 + 255) / 256); }
+
+size_t bf_pgrad_table_bytes(const bf_pgrad_t* t, int n, uint32_t* total_blocks) {
+    uint64_t blocks = 0;
+    for (int i = 0; i < n; ++i) blocks += pg_blocks(t[i].n);
+    if (total_blocks) *total_blocks = (uint32_t)blocks;
+    return bf_align_up((size_t)n * sizeof(PgEntry), 256) + (size_t)blocks * sizeof(uint32_t);
+}
+
+int bf_pgrad_table_build(const bf_pgrad_t* t, int n, void* h_blob, size_t blob_bytes) {
+    uint32_t total = 0;
+    if (blob_bytes < bf_pgrad_table_bytes(t, n, &total)) BF_FAIL("bf_param_grad_table_build: blob too small");
+    PgEntry* ent = reinterpret_cast<PgEntry*>(h_blob);
+    uint32_t* map = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(h_blob) + bf_align_up((size_t)n * sizeof(PgEntry), 256));
+    uint32_t blk = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!t[i].d_dw || !t[i].d_rho || !t[i].d_drho || t[i].n == 0 || t[i].splits < 1)
+            BF_FAIL("bf_param_grad_table_build: entry %d: NULL pointer, empty tensor or splits < 1", i);
+        PgEntry& e = ent[i];
+        e.dw = t[i].d_dw; e.rho = t[i].d_rho; e.dmu = t[i].d_dmu; e.drho = t[i].d_drho;
+        e.n = t[i].n; e.stream = t[i].stream_id; e.block_begin = blk; e.splits = t[i].splits;
+        e.vec = (t[i].n % 4 == 0 && ((uintptr_t)t[i].d_dw & 15) == 0) ? 1 : 0;
+        const uint32_t nb = pg_blocks(t[i].n);
+        for (uint32_t b = 0; b < nb; ++b) map[blk + b] = (uint32_t)i;
+        blk += nb;
+    }
+    return 0;
+}
+
+int bf_launch_pgrad_table(const void* d_blob, int n, uint32_t total_blocks, int S, uint64_t seed, uint32_t sample_base,
+                          hipStream_t stream) {
+    if (!d_blob || n < 1 || total_blocks < 1 || S < 1) BF_FAIL("bf_param_grad_table: empty launch");
+    const PgEntry* ent = reinterpret_cast<const PgEntry*>(d_blob);
+    const uint32_t* map = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(d_blob) + bf_align_up((size_t)n * sizeof(PgEntry), 256));
+    hipLaunchKernelGGL(param_grad_table_kernel, dim3(total_blocks), dim3(256), 0, stream, ent, map, S, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), sample_base, bf_sample_counter());
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -174,6 +174,10 @@ int bf_launch_colsum(const void* d_dy, int dtype, float* d_out, int S, int M, in
                      hipStream_t stream);
 int bf_launch_param_grad(const float* d_dw, const float* d_rho, uint64_t n, int S, int splits, uint64_t seed,
                          uint32_t sample_base, uint32_t stream_id, float* d_dmu, float* d_drho, hipStream_t stream);
+size_t bf_pgrad_table_bytes(const bf_pgrad_t* t, int n, uint32_t* total_blocks);
+int bf_pgrad_table_build(const bf_pgrad_t* t, int n, void* h_blob, size_t blob_bytes);
+int bf_launch_pgrad_table(const void* d_blob, int n, uint32_t total_blocks, int S, uint64_t seed, uint32_t sample_base,
+                          hipStream_t stream);
 int bf_launch_reduce_partials(const double* d_partials, uint32_t nrows, int S, double* d_out, hipStream_t stream);
 bool bf_fused_small_supported(int x_dtype, int y_dtype, int compute_dtype, int64_t x_sample_stride, const void* d_x,
                               const bf_tensor_t* weight, const bf_tensor_t* bias, int S, int M, int N, int K);

@@ -24,6 +24,14 @@ from ..parameters.initializations import DEFAULT_UNIFORM, Initialization
 
 
 
+def _note_forward(layer, S, x, cdt, need_grad) -> None:
+    """A forward that records gradients tells the layer's deferred-reduction manager (training.DeferredParamGrads), if it has
+    one, which shape its backward will have: the manager decides BEFORE the backward pass whether this step defers."""
+    d = layer.__dict__.get("_bf_pg_defer")
+    if d is not None and need_grad:
+        d.note_forward(layer, S, x.shape[0] // S, cdt)
+
+
 def _backward(ctx, grad):
     """Shared backward of the per-layer and the planned forward: one bf_linear_bwd call."""
     x, *rest = ctx.saved_tensors
@@ -53,6 +61,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.counter = bfr.counter_snapshot(need_grad)
         ctx.cdt = layer.compute_dtype or bfr.get_compute_dtype()
         ctx.save_for_backward(x)
+        _note_forward(layer, S, x, ctx.cdt, need_grad)
         return ops.linear_forward(layer, x, S, seed, base, lp_out)
 
     @staticmethod
@@ -75,6 +84,7 @@ class _PlannedLinearFn(torch.autograd.Function):
         # the device counter nor the second store below
         ctx.counter = bfr.counter_snapshot(need_grad)
         ctx.cdt = w_s.dtype
+        _note_forward(layer, S, x, ctx.cdt, need_grad)
         # an activation fused into the GEMM while gradients are recorded: the launch also stores the pre-activation,
         # and the backward folds act' (and the bias gradient's column sums) into one pass over the output gradient
         if act and need_grad:
@@ -107,6 +117,8 @@ class _StackedLinearFn(torch.autograd.Function):
         ctx.kept = (fwd.plan, fwd.plan.group_of[id(run[0])], fwd.token, w_stack)
         ctx.counter = bfr.counter_snapshot()
         ctx.save_for_backward(x)
+        for layer in run:
+            _note_forward(layer, S, x, ctx.cdt, True)
         y = ops.gemm_nt_layers(x, w_stack, b_stack, L, S, M, N, K, M * K, x.dtype)
         return tuple(y[l].view(S * M, N) for l in range(L))
 

@@ -502,8 +502,16 @@ def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_
             return slot
         return torch.empty(shape, dtype=torch.float32, device=dev)
 
-    dmu_w = dest(layer.weight.mu, (N, K), need_mu_w)
-    drho_w = dest(layer.weight.rho, (N, K))
+    # A layer whose weight reduction is DEFERRED (training.DeferredParamGrads, armed for this step): bf_linear_bwd leaves the
+    # per-sample gradients dW_s in the manager's buffer and skips the reduction; ONE bf_param_grad_table launch after the
+    # backward pass reduces every such layer into the manager's gradient buffers.  Autograd is handed None for mu / rho.
+    defer = getattr(layer, "_bf_pg_defer", None)
+    dw_keep = defer.keep_buffer(layer, S, M, cdt, seed, sample_base) if defer is not None else None
+    if dw_keep is not None:
+        dmu_w = drho_w = None
+    else:
+        dmu_w = dest(layer.weight.mu, (N, K), need_mu_w)
+        drho_w = dest(layer.weight.rho, (N, K))
     dmu_b = dest(layer.bias.mu, (N,), has_bias and need_mu_b) if has_bias else None
     drho_b = dest(layer.bias.rho, (N,)) if has_bias else None
     lib = _C.lib()
@@ -515,10 +523,13 @@ def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_
     need = lib.bf_linear_bwd_workspace_bytes(S, M, N, K, int(has_bias), _TORCH2BF[cdt], act)
     ws = workspace(dev, need)
     ptr = lambda t: t.data_ptr() if t is not None else None
+    if dw_keep is not None:
+        drho_keep = defer.grad_view(layer.weight.rho)  # (where the table launch will write; nothing is written there now)
     _C.check(lib.bf_linear_bwd(xg.data_ptr(), M * K, dy.data_ptr(), _TORCH2BF[cdt], ctypes.byref(w),
-                               ctypes.byref(b) if has_bias else None, ptr(dx), ptr(dmu_w), ptr(drho_w), ptr(dmu_b),
+                               ctypes.byref(b) if has_bias else None, ptr(dx), ptr(dmu_w),
+                               ptr(drho_w) if dw_keep is None else drho_keep.data_ptr(), ptr(dmu_b),
                                ptr(drho_b), S, M, N, K, seed, sample_base & 0xFFFFFFFF, act, ptr(act_pre) if act else None,
-                               ptr(dy_colsum), ws.data_ptr(), ws.numel(), _stream_ptr()), "bf_linear_bwd")
+                               ptr(dy_colsum), ptr(dw_keep), ws.data_ptr(), ws.numel(), _stream_ptr()), "bf_linear_bwd")
     if dx is not None and dx.dtype != x.dtype:
         dx = dx.to(x.dtype)
     if sunk:

@@ -308,6 +308,8 @@ class counter_override:
         self.prev = None
 
     def __enter__(self):
+        self.outer = getattr(STATE, "override_snapshot", None)
+        STATE.override_snapshot = self.snapshot  # (what a deferred reduction of this backward pass must run under too)
         if self.snapshot is not None:
             from . import _C
             lib = _C.lib()
@@ -316,6 +318,7 @@ class counter_override:
                 _C.check(lib.bf_set_sample_counter(self.snapshot.data_ptr()), "bf_set_sample_counter")
 
     def __exit__(self, *exc):
+        STATE.override_snapshot = self.outer
         if self.snapshot is not None:
             from . import _C
             with torch.cuda.device(self.snapshot.device):

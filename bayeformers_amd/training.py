@@ -27,6 +27,8 @@ from .nn.model import Model
 from .sampling import elbo, sample_bayesian
 
 
+_NO_DEFERRED = __import__("os").environ.get("BF_NO_DEFERRED_PGRAD") is not None  # developer A/B: per-layer weight reductions
+
 _BUCKETS_OF: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()  # optimizer -> the buckets training_step built for it
 
 
@@ -203,6 +205,134 @@ class GradientBuckets:
                 del p._bf_grad_sink
 
 
+class DeferredParamGrads:
+    """One launch for the weight gradients of ALL Bayesian linear layers of a single-process training step.
+
+    Every layer's backward (bf_linear_bwd) ends with a reduction over the Monte-Carlo samples — dmu = sum_s dW_s,
+    drho = (sum_s dW_s o eps_s) o softplus'(rho), eps regenerated — that reads the layer's S (x split-K) fp32 gradients of
+    the sampled weights: 73 launches of ~9 waves per CU in a BERT-base step (1.5 ms, 2.9 TB/s).  Here the layers leave their
+    dW_s in standing buffers instead (`d_dw_keep`: 4.6 GB for BERT-base at S = 10, 0.016 of an MI355X's memory) and ONE
+    table-driven launch over all of them (bf_param_grad_table: 83 k workgroups, every CU's loads in flight) runs after the
+    backward pass; the gradients land in flat buffers of this object and become the parameters' `.grad`, like
+    GradientBuckets' slots.  Same arithmetic per element, in the same order: the gradients are those of the per-layer path
+    bit for bit.
+
+    `training_step` uses it when nothing else has a claim on how the gradients travel: one process, no gradient buckets,
+    no opt-in KL gradient.  The first step of a model (or of a new batch shape) runs the per-layer path and only OBSERVES
+    (layer, samples, rows, dtype) of every layer's forward; the buffers and the table are built from that, and a step
+    defers when its forward showed exactly the shapes the table was built for — decided before the backward pass starts,
+    so a step is never half deferred.  Biases keep their per-layer reduction (their column sums are produced by different
+    kernels from layer to layer; 74 launches of ~3 us)."""
+
+    def __deepcopy__(self, memo):
+        return DeferredParamGrads()
+
+    def __reduce__(self):
+        return (DeferredParamGrads, ())
+
+    def __init__(self):
+        self.table = None      # {id(layer): (layer, S, M, cdt, dw buffer)} + device blob, built from an observed step
+        self.armed = False     # the running step's backward defers
+        self._seen = []        # (layer, S, M, cdt) of the running step's forwards
+        self._open = False     # between begin() and decide(): forwards are being observed
+        self._last = None      # (seed, sample_base, counter snapshot, S) of the backward calls of the running step
+
+    # -- called by training_step ---------------------------------------------------------------------------------
+    def begin(self, model) -> None:
+        from .nn.layers.linear import Linear
+
+        for l in model.fused_children():
+            if isinstance(l, Linear) and l.__dict__.get("_bf_pg_defer") is not self:
+                l._bf_pg_defer = self
+        self._seen, self._open, self.armed, self._last = [], True, False, None
+
+    def decide(self) -> None:
+        """After the step's forward, before its backward."""
+        self._open = False
+        seen = self._seen
+        ids = [id(l) for l, *_ in seen]
+        usable = bool(seen) and len(set(ids)) == len(ids) and not bfr.STATE.kl_gradient
+        if usable and self.table is not None and self._signature(seen) == self.table["sig"]:
+            self.armed = all(l.weight.rho.grad is None and l.weight.mu.grad is None for l, *_ in seen)
+            return
+        self.armed = False
+        self.table = self._build(seen) if usable else None
+
+    def finish(self) -> None:
+        """After the step's backward: the one reduction launch, and the gradients handed to the parameters."""
+        if not self.armed or self._last is None:
+            self.armed = False
+            return
+        from . import _C, ops
+
+        seed, base, counter, S = self._last
+        t = self.table
+        with bfr.counter_override(counter):
+            _C.check(_C.lib().bf_param_grad_table(t["blob"].data_ptr(), t["n"], t["blocks"], S, seed, base & 0xFFFFFFFF,
+                                                  ops._stream_ptr()), "bf_param_grad_table")
+        for p, view in t["grads"]:
+            p.grad = view
+        self.armed, self._last = False, None
+
+    # -- called by the layers ------------------------------------------------------------------------------------
+    def note_forward(self, layer, S, M, cdt) -> None:
+        if self._open:
+            self._seen.append((layer, int(S), int(M), cdt))
+
+    def keep_buffer(self, layer, S, M, cdt, seed, sample_base):
+        if not self.armed:
+            return None
+        e = self.table["layers"].get(id(layer))
+        if e is None or e[1:4] != (S, M, cdt):  # cannot happen after decide(); a deferred step must not be left half done
+            raise RuntimeError("DeferredParamGrads: a layer's backward does not match the forward this step was armed for")
+        self._last = (seed, sample_base, getattr(bfr.STATE, "override_snapshot", None), S)
+        return e[4]
+
+    def grad_view(self, p):
+        return self.table["view"][id(p)]
+
+    # -- internals -----------------------------------------------------------------------------------------------
+    @staticmethod
+    def _signature(seen):
+        return tuple((id(l), S, M, cdt, l.weight.mu.data_ptr(), l.weight.rho.data_ptr(), l.weight.mu.requires_grad)
+                     for l, S, M, cdt in seen)
+
+    def _build(self, seen):
+        import ctypes
+
+        from . import _C, ops
+
+        lib = _C.lib()
+        dev = seen[0][0].weight.rho.device
+        n_el = sum(l.weight.rho.numel() * (2 if l.weight.mu.requires_grad else 1) for l, *_ in seen)
+        flat = torch.zeros(n_el, dtype=torch.float32, device=dev)
+        arr = (_C.bf_pgrad_t * len(seen))()
+        layers, view, grads, off = {}, {}, [], 0
+        for i, (l, S, M, cdt) in enumerate(seen):
+            N, K = l.out_features, l.in_features
+            sp = lib.bf_linear_bwd_splits(S, M, N, K, ops._TORCH2BF[cdt])
+            dw = torch.empty((S, sp, N, K), dtype=torch.float32, device=dev)
+            layers[id(l)] = (l, S, M, cdt, dw)
+            rho, mu = l.weight.rho, l.weight.mu
+            view[id(rho)] = flat[off:off + rho.numel()].view_as(rho)
+            off += rho.numel()
+            grads.append((rho, view[id(rho)]))
+            if mu.requires_grad:
+                view[id(mu)] = flat[off:off + mu.numel()].view_as(mu)
+                off += mu.numel()
+                grads.append((mu, view[id(mu)]))
+            e = arr[i]
+            e.d_dw, e.d_rho, e.d_drho = dw.data_ptr(), rho.data_ptr(), view[id(rho)].data_ptr()
+            e.d_dmu = view[id(mu)].data_ptr() if mu.requires_grad else None
+            e.n, e.stream_id, e.splits = rho.numel(), 2 * l.layer_id, sp
+        blocks = ctypes.c_uint32()
+        nbytes = lib.bf_param_grad_table_bytes(arr, len(seen), ctypes.byref(blocks))
+        blob = torch.empty(nbytes, dtype=torch.uint8)
+        _C.check(lib.bf_param_grad_table_build(arr, len(seen), blob.data_ptr(), nbytes), "bf_param_grad_table_build")
+        return {"sig": self._signature(seen), "layers": layers, "view": view, "grads": grads, "flat": flat,
+                "blob": blob.to(dev), "n": len(seen), "blocks": blocks.value}
+
+
 def grad_norm(tensors: List[Tensor]) -> Tensor:
     """2-norm of all `tensors` together (0-d fp32), as torch.nn.utils.clip_grad_norm_ computes it, in one multi-tensor
     launch per dtype instead of one reduction per tensor."""
@@ -255,9 +385,20 @@ def training_step(model: Model, inputs, samples: int, nll_fn: Callable, optimize
         buckets.zero()
     else:
         optimizer.zero_grad(set_to_none=True)
+    # one process, no buckets: the weight gradients of all Bayesian linears are reduced by ONE launch after the backward pass
+    deferred = None
+    if buckets is None and not _NO_DEFERRED and not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        deferred = model.__dict__.get("_pgrad")
+        if deferred is None:
+            deferred = model.__dict__["_pgrad"] = DeferredParamGrads()
+        deferred.begin(model)
     _, mean, lp, lq = sample_bayesian(model, inputs, samples, select=select, group=group)
     loss = elbo(lp, lq, nll_fn(mean).double(), n_batches)
+    if deferred is not None:
+        deferred.decide()
     loss.backward()
+    if deferred is not None:
+        deferred.finish()
     if buckets is not None:
         buckets.finish()
     if max_grad_norm is not None:

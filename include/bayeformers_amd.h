@@ -243,12 +243,39 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
  * act(y) and d_act_pre the forward's pre-activation y ([S][M][N] of `dtype`, 16-bit, N % 8 == 0): dy = d_dy * act'(y)
  * is formed first, in one pass that also yields the bias gradient's column sums.  act = BF_ACT_NONE: d_act_pre unused.
  * d_dy_colsum (nullable): [S][N] fp32 column sums of d_dy per sample, when the kernel that PRODUCED d_dy left them
- * (bf_attention_bwd_colsum): the bias gradient then needs no pass over d_dy of its own. */
+ * (bf_attention_bwd_colsum): the bias gradient then needs no pass over d_dy of its own.
+ * d_dw_keep (nullable, ABI 6): the per-sample weight gradients dW_s — [S][splits][N][K] fp32 with
+ * splits = bf_linear_bwd_splits(S, M, N, K, dtype) split-K partial products per sample — are left THERE instead of in the
+ * workspace and the weight's reduction over the samples is NOT done (d_dmu_w / d_drho_w untouched): the caller reduces the
+ * weights of many layers with one bf_param_grad_table launch after the backward pass. */
 size_t bf_linear_bwd_workspace_bytes(int S, int M, int N, int K, int has_bias, int dtype, int act);
+int bf_linear_bwd_splits(int S, int M, int N, int K, int dtype);
 int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, int dtype, const bf_tensor_t* weight,
                   const bf_tensor_t* bias, void* d_dx, float* d_dmu_w, float* d_drho_w, float* d_dmu_b,
                   float* d_drho_b, int S, int M, int N, int K, uint64_t seed, uint32_t sample_base, int act,
-                  const void* d_act_pre, const float* d_dy_colsum, void* d_workspace, size_t workspace_bytes, void* stream);
+                  const void* d_act_pre, const float* d_dy_colsum, float* d_dw_keep, void* d_workspace, size_t workspace_bytes,
+                  void* stream);
+
+/* dmu = sum_s dW_s, drho = (sum_s dW_s o eps_s) o softplus'(rho) — step 4 of bf_linear_bwd — for MANY tensors in one launch
+ * (/root/reference/examples/bert_glue.py:239: loss.backward() reaches every layer's mu and rho): the per-sample gradients
+ * that bf_linear_bwd calls left in their d_dw_keep buffers are reduced after the backward pass by one kernel over a device
+ * table of entries (the cross-layer sampling launch's pattern, bf_sample_logprob_table).
+ *   bf_param_grad_table_bytes / _build: size and contents of the HOST blob for n entries (copy it to the device once; it holds
+ *   the entries' pointers); *total_blocks = grid of the launch.  bf_param_grad_table: the launch — S, seed, sample_base as the
+ *   backward calls of the step had them (the device-resident sample counter, when set, is added as everywhere). */
+typedef struct bf_pgrad {
+    const float* d_dw;   /* device, [S][splits][n] fp32 */
+    const float* d_rho;  /* device, n */
+    float* d_dmu;        /* device, n, or NULL (frozen mean) */
+    float* d_drho;       /* device, n */
+    uint64_t n;
+    uint32_t stream_id;  /* Philox stream of the tensor: 2*layer_id + (0 weight | 1 bias) */
+    int32_t splits;
+} bf_pgrad_t;
+size_t bf_param_grad_table_bytes(const bf_pgrad_t* entries, int n, uint32_t* total_blocks);
+int bf_param_grad_table_build(const bf_pgrad_t* entries, int n, void* h_blob, size_t blob_bytes);
+int bf_param_grad_table(const void* d_blob, int n, uint32_t total_blocks, int S, uint64_t seed, uint32_t sample_base,
+                        void* stream);
 
 /* Opt-in Bayes-by-Backprop gradient of the KL terms.  The reference detaches its log-probs (layers/linear.py:99-102
  * store them with `.data =`), so `loss = (lvp - log_prior)/n_batches + nll` (bert_glue.py:235) trains the likelihood

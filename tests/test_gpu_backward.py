@@ -829,3 +829,53 @@ def test_device_resident_dropout_call_draws_the_host_counters_masks(golden_dir):
         assert gh.keys() == gd.keys()
         for n in gh:
             assert torch.equal(gh[n], gd[n]), (k, n)
+
+
+def test_deferred_weight_reduction_gives_the_per_layer_gradients(golden_dir, monkeypatch):
+    """training.DeferredParamGrads: from the second step of a shape on, training_step leaves every layer's per-sample weight
+    gradients in standing buffers and reduces them with ONE bf_param_grad_table launch after the backward pass — the same
+    arithmetic in the same order: parameters after every step equal those of the per-layer path bit for bit; a step with
+    another batch shape falls back (and re-arms for that shape); the gradients are views of the manager's flat buffer."""
+    import copy
+
+    from bayeformers_amd import training
+    from bayeformers_amd.training import training_step
+
+    g, bmodel0, _, inputs, labels = _tiny_train_setup(golden_dir, "bf16", True)
+    S, NB = int(g["S"]), int(g["n_batches"])
+    half = {k: v[: v.shape[0] // 2].contiguous() for k, v in inputs.items()}
+    plan = [(inputs, labels), (inputs, labels), (inputs, labels), (half, labels[: labels.shape[0] // 2]), (inputs, labels)]
+    bf.set_compute_dtype("bf16")
+
+    def run(deferred):
+        monkeypatch.setattr(training, "_NO_DEFERRED", not deferred)
+        m = copy.deepcopy(bmodel0)
+        bf.fuse_attention(m)
+        opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, eps=1e-8, weight_decay=0.0, fused=True)
+        bf.manual_seed(SEED)
+        snaps, armed = [], []
+        for x, y in plan:
+            nll = lambda mean: torch.nn.functional.cross_entropy(mean[0].float(), y)  # noqa: E731
+            orig_finish = training.DeferredParamGrads.finish
+            was = {}
+
+            def finish(self, _o=orig_finish, _w=was):
+                _w["armed"] = self.armed
+                return _o(self)
+
+            monkeypatch.setattr(training.DeferredParamGrads, "finish", finish)
+            loss = float(training_step(m, x, S, nll, opt, NB, max_grad_norm=1.0))
+            monkeypatch.setattr(training.DeferredParamGrads, "finish", orig_finish)
+            armed.append(bool(was.get("armed")))
+            snaps.append((loss, {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}))
+        return snaps, armed, m
+
+    ref, armed_ref, _ = run(False)
+    got, armed, m = run(True)
+    assert armed_ref == [False] * 5 and armed == [False, True, True, False, False]   # observe, defer, defer, new shape, re-observed
+    for k, ((l0, p0), (l1, p1)) in enumerate(zip(ref, got)):
+        assert l0 == l1, k
+        for n in p0:
+            assert torch.equal(p0[n], p1[n]), (k, n)
+    mgr = m._pgrad
+    assert mgr.table is not None and len(mgr.table["layers"]) == len([l for l in m.fused_children()])
