@@ -72,7 +72,7 @@ SYMBOLS = {
     "bf_linear_fwd": (_i, [_vp, _i, _i64, _tp, _tp, _vp, _i, _i, _i, _i, _i, _i, _u64, _u32, _vp, _vp, _sz, _vp]),
     "bf_linear_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "bf_linear_bwd": (_i, [_vp, _i64, _vp, _i, _tp, _tp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u64, _u32, _i, _vp,
-                           _vp, _vp, _vp, _sz, _vp]),
+                           _vp, _vp, _vp, _vp, _sz, _vp]),
     "bf_linear_bwd_splits": (_i, [_i, _i, _i, _i, _i]),
     "bf_param_grad_table_bytes": (_sz, [_vp, _i, ctypes.POINTER(ctypes.c_uint32)]),
     "bf_param_grad_table_build": (_i, [_vp, _i, _vp, _sz]),

@@ -679,8 +679,8 @@ int bf_param_grad_table(const void* d_blob, int n, uint32_t total_blocks, int S,
 int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, int dtype, const bf_tensor_t* weight,
                   const bf_tensor_t* bias, void* d_dx, float* d_dmu_w, float* d_drho_w, float* d_dmu_b,
                   float* d_drho_b, int S, int M, int N, int K, uint64_t seed, uint32_t sample_base, int act,
-                  const void* d_act_pre, const float* d_dy_colsum, float* d_dw_keep, void* d_workspace, size_t workspace_bytes,
-                  void* stream_) {
+                  const void* d_act_pre, const float* d_dy_colsum, float* d_dw_keep, float* d_db_keep, void* d_workspace,
+                  size_t workspace_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d_x || !d_dy || !weight || !d_drho_w) BF_FAIL("bf_linear_bwd: NULL argument");
     if (act != BF_ACT_NONE && act != BF_ACT_GELU) BF_FAIL("bf_linear_bwd: unknown activation %d", act);
@@ -695,6 +695,9 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
         BF_FAIL("bf_linear_bwd: workspace too small (%zu < %zu bytes)", workspace_bytes, L.total);
     char* ws = reinterpret_cast<char*>(d_workspace);
     const int es = (int)bf_dtype_size(dtype);
+    if (d_db_keep && !bias) BF_FAIL("bf_linear_bwd: d_db_keep without a bias");
+    // the bias gradient's per-sample column sums of dy, [S][N] fp32: in the workspace, or where the caller keeps them
+    float* db_dst = d_db_keep ? d_db_keep : reinterpret_cast<float*>(ws + L.db);
 
     int rc = 0;
     // 0. the forward applied act() in its GEMM epilogue: d_dy is the gradient of act(y); dy = d_dy * act'(y_pre), and the
@@ -702,7 +705,7 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
     bool fused_colsum = false;
     if (act != BF_ACT_NONE) {
         if ((rc = bf_launch_gelu_bwd_colsum(d_dy, d_act_pre, ws + L.dpre, dtype, S, M, N, reinterpret_cast<float*>(ws + L.dbp),
-                                            reinterpret_cast<float*>(ws + L.db), stream)))
+                                            db_dst, stream)))
             return rc;
         d_dy = ws + L.dpre;
         fused_colsum = true;
@@ -749,7 +752,7 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
         if (with_t) {  // the bias gradient's column sums ride along with the transpose of dy
             fused_colsum = true;
             if ((rc = bf_launch_transpose_colsum(d_dy, ws + L.dyt, dtype, S * sp, Mc, N, sp, reinterpret_cast<float*>(ws + L.dbp),
-                                                 reinterpret_cast<float*>(ws + L.db), stream)))
+                                                 db_dst, stream)))
                 return rc;
         } else if ((rc = bf_launch_transpose(d_dy, ws + L.dyt, es, S * sp, Mc, N, stream))) {
             return rc;
@@ -775,13 +778,14 @@ int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, in
     if (bias) {
         // the column sums of dy: from the pass that formed dy (fused activation / transpose), from the kernel that produced
         // d_dy (d_dy_colsum), or a pass of their own
-        const float* colsum = reinterpret_cast<const float*>(ws + L.db);
+        // (d_db_keep: the sums stay in the caller's buffer — or in d_dy_colsum, which the caller then copies itself — and the
+        // reduction over the samples is left to its bf_param_grad_table launch)
+        const float* colsum = db_dst;
         if (!fused_colsum && d_dy_colsum && act == BF_ACT_NONE) colsum = d_dy_colsum;
-        else if (!fused_colsum && (rc = bf_launch_colsum(d_dy, dtype, reinterpret_cast<float*>(ws + L.db), S, M, N,
-                                                         reinterpret_cast<float*>(ws + L.dbp), stream)))
+        else if (!fused_colsum && (rc = bf_launch_colsum(d_dy, dtype, db_dst, S, M, N, reinterpret_cast<float*>(ws + L.dbp), stream)))
             return rc;
-        if ((rc = bf_launch_param_grad(colsum, bias->d_rho, bias->n, S, 1, seed,
-                                       sample_base, bias->stream_id, d_dmu_b, d_drho_b, stream)))
+        if (!d_db_keep && (rc = bf_launch_param_grad(colsum, bias->d_rho, bias->n, S, 1, seed,
+                                                     sample_base, bias->stream_id, d_dmu_b, d_drho_b, stream)))
             return rc;
     }
     return 0;

@@ -507,13 +507,18 @@ def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_
     # backward pass reduces every such layer into the manager's gradient buffers.  Autograd is handed None for mu / rho.
     defer = getattr(layer, "_bf_pg_defer", None)
     dw_keep = defer.keep_buffer(layer, S, M, cdt, seed, sample_base) if defer is not None else None
+    db_keep = None
     if dw_keep is not None:
         dmu_w = drho_w = None
+        db_keep = defer.keep_bias_buffer(layer, dy_colsum if not act else None) if has_bias else None
     else:
         dmu_w = dest(layer.weight.mu, (N, K), need_mu_w)
         drho_w = dest(layer.weight.rho, (N, K))
-    dmu_b = dest(layer.bias.mu, (N,), has_bias and need_mu_b) if has_bias else None
-    drho_b = dest(layer.bias.rho, (N,)) if has_bias else None
+    if db_keep is not None:
+        dmu_b = drho_b = None
+    else:
+        dmu_b = dest(layer.bias.mu, (N,), has_bias and need_mu_b) if has_bias else None
+        drho_b = dest(layer.bias.rho, (N,)) if has_bias else None
     lib = _C.lib()
     if act:
         if act_pre is None or act_pre.dtype != cdt or act_pre.numel() != S * M * N:
@@ -528,8 +533,9 @@ def linear_backward(layer, x: Tensor, grad_y: Tensor, S: int, seed: int, sample_
     _C.check(lib.bf_linear_bwd(xg.data_ptr(), M * K, dy.data_ptr(), _TORCH2BF[cdt], ctypes.byref(w),
                                ctypes.byref(b) if has_bias else None, ptr(dx), ptr(dmu_w),
                                ptr(drho_w) if dw_keep is None else drho_keep.data_ptr(), ptr(dmu_b),
-                               ptr(drho_b), S, M, N, K, seed, sample_base & 0xFFFFFFFF, act, ptr(act_pre) if act else None,
-                               ptr(dy_colsum), ptr(dw_keep), ws.data_ptr(), ws.numel(), _stream_ptr()), "bf_linear_bwd")
+                               ptr(drho_b) if db_keep is None else defer.grad_view(layer.bias.rho).data_ptr(), S, M, N, K, seed,
+                               sample_base & 0xFFFFFFFF, act, ptr(act_pre) if act else None,
+                               ptr(dy_colsum), ptr(dw_keep), ptr(db_keep), ws.data_ptr(), ws.numel(), _stream_ptr()), "bf_linear_bwd")
     if dx is not None and dx.dtype != x.dtype:
         dx = dx.to(x.dtype)
     if sunk:

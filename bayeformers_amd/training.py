@@ -221,8 +221,9 @@ class DeferredParamGrads:
     no opt-in KL gradient.  The first step of a model (or of a new batch shape) runs the per-layer path and only OBSERVES
     (layer, samples, rows, dtype) of every layer's forward; the buffers and the table are built from that, and a step
     defers when its forward showed exactly the shapes the table was built for — decided before the backward pass starts,
-    so a step is never half deferred.  Biases keep their per-layer reduction (their column sums are produced by different
-    kernels from layer to layer; 74 launches of ~3 us)."""
+    so a step is never half deferred.  The biases ride in the same launch (73 more launches of 6 us gone): their per-sample
+    gradients — the column sums of dy, [S][N] — are written into standing buffers by whichever kernel forms them; the sums a
+    producer of dy left with it (attention backward: query / key / value) are copied there by one multi-tensor copy."""
 
     def __deepcopy__(self, memo):
         return DeferredParamGrads()
@@ -236,6 +237,7 @@ class DeferredParamGrads:
         self._seen = []        # (layer, S, M, cdt) of the running step's forwards
         self._open = False     # between begin() and decide(): forwards are being observed
         self._last = None      # (seed, sample_base, counter snapshot, S) of the backward calls of the running step
+        self._copies = ([], [])  # (sources, destinations): column sums their producer left elsewhere, gathered before the launch
 
     # -- called by training_step ---------------------------------------------------------------------------------
     def begin(self, model) -> None:
@@ -244,7 +246,7 @@ class DeferredParamGrads:
         for l in model.fused_children():
             if isinstance(l, Linear) and l.__dict__.get("_bf_pg_defer") is not self:
                 l._bf_pg_defer = self
-        self._seen, self._open, self.armed, self._last = [], True, False, None
+        self._seen, self._open, self.armed, self._last, self._copies = [], True, False, None, ([], [])
 
     def decide(self) -> None:
         """After the step's forward, before its backward."""
@@ -253,7 +255,7 @@ class DeferredParamGrads:
         ids = [id(l) for l, *_ in seen]
         usable = bool(seen) and len(set(ids)) == len(ids) and not bfr.STATE.kl_gradient
         if usable and self.table is not None and self._signature(seen) == self.table["sig"]:
-            self.armed = all(l.weight.rho.grad is None and l.weight.mu.grad is None for l, *_ in seen)
+            self.armed = all(p.grad is None for p, _ in self.table["grads"])
             return
         self.armed = False
         self.table = self._build(seen) if usable else None
@@ -267,6 +269,9 @@ class DeferredParamGrads:
 
         seed, base, counter, S = self._last
         t = self.table
+        if self._copies[0]:
+            torch._foreach_copy_(self._copies[1], self._copies[0])
+        self._copies = ([], [])
         with bfr.counter_override(counter):
             _C.check(_C.lib().bf_param_grad_table(t["blob"].data_ptr(), t["n"], t["blocks"], S, seed, base & 0xFFFFFFFF,
                                                   ops._stream_ptr()), "bf_param_grad_table")
@@ -288,13 +293,25 @@ class DeferredParamGrads:
         self._last = (seed, sample_base, getattr(bfr.STATE, "override_snapshot", None), S)
         return e[4]
 
+    def keep_bias_buffer(self, layer, given_colsum):
+        """The standing [S][N] buffer the layer's bias column sums go to; `given_colsum`: they exist already (left by the kernel
+        that produced dy) — gathered into the buffer before the launch."""
+        db = self.table["layers"][id(layer)][5]
+        if db is not None and given_colsum is not None:
+            self._copies[0].append(given_colsum)
+            self._copies[1].append(db)
+        return db
+
     def grad_view(self, p):
         return self.table["view"][id(p)]
 
     # -- internals -----------------------------------------------------------------------------------------------
     @staticmethod
     def _signature(seen):
-        return tuple((id(l), S, M, cdt, l.weight.mu.data_ptr(), l.weight.rho.data_ptr(), l.weight.mu.requires_grad)
+        from .nn.parameters.gaussian import Gaussian
+
+        return tuple((id(l), S, M, cdt) + tuple(v for g in (l.weight, l.bias) if isinstance(g, Gaussian)
+                                                for v in (g.mu.data_ptr(), g.rho.data_ptr(), g.mu.requires_grad))
                      for l, S, M, cdt in seen)
 
     def _build(self, seen):
@@ -304,33 +321,45 @@ class DeferredParamGrads:
 
         lib = _C.lib()
         dev = seen[0][0].weight.rho.device
-        n_el = sum(l.weight.rho.numel() * (2 if l.weight.mu.requires_grad else 1) for l, *_ in seen)
+        from .nn.parameters.gaussian import Gaussian
+
+        def tensors_of(l):
+            return [l.weight] + ([l.bias] if isinstance(l.bias, Gaussian) else [])
+
+        def aligned(n):  # every tensor's slots start on a 16-byte boundary of the flat buffer
+            return (n + 3) // 4 * 4
+
+        n_el = sum(aligned(g.rho.numel()) * (2 if g.mu.requires_grad else 1) for l, *_ in seen for g in tensors_of(l))
         flat = torch.zeros(n_el, dtype=torch.float32, device=dev)
-        arr = (_C.bf_pgrad_t * len(seen))()
-        layers, view, grads, off = {}, {}, [], 0
-        for i, (l, S, M, cdt) in enumerate(seen):
+        n_entries = sum(len(tensors_of(l)) for l, *_ in seen)
+        arr = (_C.bf_pgrad_t * n_entries)()
+        layers, view, grads, off, i = {}, {}, [], 0, 0
+        for l, S, M, cdt in seen:
             N, K = l.out_features, l.in_features
             sp = lib.bf_linear_bwd_splits(S, M, N, K, ops._TORCH2BF[cdt])
             dw = torch.empty((S, sp, N, K), dtype=torch.float32, device=dev)
-            layers[id(l)] = (l, S, M, cdt, dw)
-            rho, mu = l.weight.rho, l.weight.mu
-            view[id(rho)] = flat[off:off + rho.numel()].view_as(rho)
-            off += rho.numel()
-            grads.append((rho, view[id(rho)]))
-            if mu.requires_grad:
-                view[id(mu)] = flat[off:off + mu.numel()].view_as(mu)
-                off += mu.numel()
-                grads.append((mu, view[id(mu)]))
-            e = arr[i]
-            e.d_dw, e.d_rho, e.d_drho = dw.data_ptr(), rho.data_ptr(), view[id(rho)].data_ptr()
-            e.d_dmu = view[id(mu)].data_ptr() if mu.requires_grad else None
-            e.n, e.stream_id, e.splits = rho.numel(), 2 * l.layer_id, sp
+            db = torch.empty((S, N), dtype=torch.float32, device=dev) if isinstance(l.bias, Gaussian) else None
+            layers[id(l)] = (l, S, M, cdt, dw, db)
+            for k, (g, buf, splits) in enumerate(zip(tensors_of(l), (dw, db), (sp, 1))):
+                rho, mu = g.rho, g.mu
+                view[id(rho)] = flat[off:off + rho.numel()].view_as(rho)
+                off += aligned(rho.numel())
+                grads.append((rho, view[id(rho)]))
+                if mu.requires_grad:
+                    view[id(mu)] = flat[off:off + mu.numel()].view_as(mu)
+                    off += aligned(mu.numel())
+                    grads.append((mu, view[id(mu)]))
+                e = arr[i]
+                e.d_dw, e.d_rho, e.d_drho = buf.data_ptr(), rho.data_ptr(), view[id(rho)].data_ptr()
+                e.d_dmu = view[id(mu)].data_ptr() if mu.requires_grad else None
+                e.n, e.stream_id, e.splits = rho.numel(), 2 * l.layer_id + k, splits
+                i += 1
         blocks = ctypes.c_uint32()
-        nbytes = lib.bf_param_grad_table_bytes(arr, len(seen), ctypes.byref(blocks))
+        nbytes = lib.bf_param_grad_table_bytes(arr, n_entries, ctypes.byref(blocks))
         blob = torch.empty(nbytes, dtype=torch.uint8)
-        _C.check(lib.bf_param_grad_table_build(arr, len(seen), blob.data_ptr(), nbytes), "bf_param_grad_table_build")
+        _C.check(lib.bf_param_grad_table_build(arr, n_entries, blob.data_ptr(), nbytes), "bf_param_grad_table_build")
         return {"sig": self._signature(seen), "layers": layers, "view": view, "grads": grads, "flat": flat,
-                "blob": blob.to(dev), "n": len(seen), "blocks": blocks.value}
+                "blob": blob.to(dev), "n": n_entries, "blocks": blocks.value}
 
 
 def grad_norm(tensors: List[Tensor]) -> Tensor:

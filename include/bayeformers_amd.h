@@ -247,14 +247,17 @@ int bf_linear_fwd(const void* d_x, int x_dtype, int64_t x_sample_stride, const b
  * d_dw_keep (nullable, ABI 6): the per-sample weight gradients dW_s — [S][splits][N][K] fp32 with
  * splits = bf_linear_bwd_splits(S, M, N, K, dtype) split-K partial products per sample — are left THERE instead of in the
  * workspace and the weight's reduction over the samples is NOT done (d_dmu_w / d_drho_w untouched): the caller reduces the
- * weights of many layers with one bf_param_grad_table launch after the backward pass. */
+ * weights of many layers with one bf_param_grad_table launch after the backward pass.
+ * d_db_keep (nullable; needs a bias): likewise for the bias — its per-sample gradients, the column sums of dy ([S][N] fp32),
+ * are written THERE by whichever kernel forms them and not reduced (d_dmu_b / d_drho_b untouched); when d_dy_colsum is
+ * given they are already in that buffer and nothing is written (the caller copies them where its table reads). */
 size_t bf_linear_bwd_workspace_bytes(int S, int M, int N, int K, int has_bias, int dtype, int act);
 int bf_linear_bwd_splits(int S, int M, int N, int K, int dtype);
 int bf_linear_bwd(const void* d_x, int64_t x_sample_stride, const void* d_dy, int dtype, const bf_tensor_t* weight,
                   const bf_tensor_t* bias, void* d_dx, float* d_dmu_w, float* d_drho_w, float* d_dmu_b,
                   float* d_drho_b, int S, int M, int N, int K, uint64_t seed, uint32_t sample_base, int act,
-                  const void* d_act_pre, const float* d_dy_colsum, float* d_dw_keep, void* d_workspace, size_t workspace_bytes,
-                  void* stream);
+                  const void* d_act_pre, const float* d_dy_colsum, float* d_dw_keep, float* d_db_keep, void* d_workspace,
+                  size_t workspace_bytes, void* stream);
 
 /* dmu = sum_s dW_s, drho = (sum_s dW_s o eps_s) o softplus'(rho) — step 4 of bf_linear_bwd — for MANY tensors in one launch
  * (/root/reference/examples/bert_glue.py:239: loss.backward() reaches every layer's mu and rho): the per-sample gradients
