@@ -213,6 +213,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_sched_kernel(const GemmParams 
     // RING: this wave's pieces (the first `cnt` of four) of its group's unit `half` (0 / 1) of k-step kt of tile t, into
     // buffer buf
     auto issue_unit = [&](const Src& t, int kt, int buf, int half, int cnt) {
+#ifdef BF_DEV
+        if (p.flags & 1) return;     // ablation: no DMA in the k-loop (tools/r6g_tn_probe.sh)
+        if (p.flags & 64) kt = 0;    // ablation: every k-step re-reads k-step 0 (operands L2-hot)
+#endif
         char* dst = smem + buf * STAGE_BYTES + (wm == 0 ? 0 : X_BYTES) + half * 16384 + wn * 1024;
         const T* b = t.ob;
         if constexpr (SEG) {
@@ -953,12 +957,22 @@ int bf_launch_gemm256_tn(const void* d_a, const void* d_b, float* d_out, int dty
     p.act = BF_ACT_NONE;
     p.layers = 1;
     p.flags = 0;
+#ifdef BF_DEV
+    if (const char* ab = getenv("BF_GEMM_ABLATE")) p.flags = atoi(ab);
+#endif
     p.tiles_m = (p.M + TM - 1) / TM;
     p.tiles_n = (p.N + TN - 1) / TN;
     Sched sc;
     if (get_schedule(p.S, 1, p.tiles_n, p.M, BF_SCHED_POLICY, stream, sc)) return 1;
     p.sched = sc.d_table;
     p.sched_rounds = sc.rounds;
+#ifdef BF_DEV
+    // developer builds, BF_GEMM_TN_FORM=1: the TN form on the five-slot ring (bf_gemm256_r5.hip, TRX) — built and measured in
+    // round 6 (profiles/r6h_tn_ring5_ab.txt): bit-identical, 0-1.4 % per launch, nothing in the training step; the product
+    // keeps the two-buffer unit ring of this file
+    if (const char* fe = getenv("BF_GEMM_TN_FORM"))
+        if (atoi(fe) && bf_gemm256_r5_tn_supported(p)) return bf_launch_gemm256_r5_tn(p, dtype, stream, sc.grid);
+#endif
     if (dtype == BF_DT_BF16) return launch256_tn<__bf16>(p, stream, sc.grid);
     return launch256_tn<_Float16>(p, stream, sc.grid);
 }

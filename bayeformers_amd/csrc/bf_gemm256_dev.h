@@ -28,6 +28,8 @@ int bf_gemm256_get_schedule(int S, int layers, int tiles_n, int M, int policy, h
 bool bf_gemm256_r5_supported(const GemmParams& p, int w_dtype, int y_dtype);
 int bf_launch_gemm256_r5(const GemmParams& p, int w_dtype, hipStream_t stream, int grid);
 int bf_launch_gemm256_r5_nn(const GemmParams& p, int dtype, hipStream_t stream, int grid);
+bool bf_gemm256_r5_tn_supported(const GemmParams& p);
+int bf_launch_gemm256_r5_tn(const GemmParams& p, int dtype, hipStream_t stream, int grid);
 
 namespace {
 

@@ -54,9 +54,13 @@ struct FragOf { using type = typename Mfma16<T>::frag; };
 template <>
 struct FragOf<float> { using type = f32x4_t; };
 
-template <typename T, typename YT, bool TRW = false, bool SEG = false>
+// TRX (round 6): the x unit contraction-major too ([64 contraction rows][256] tile of 512-byte rows, swizzled and read through
+// ds_read_b64_tr_b16 like a TRW unit) with fp32 outputs — the TN form dW[s] = dy[s]^T x[s] of the backward pass, which ran on
+// the two-buffer unit ring of bf_gemm256.hip (1 k-step ahead, 32 KiB of LDS reserved for its epilogue) until round 6.
+template <typename T, typename YT, bool TRW = false, bool SEG = false, bool TRX = false>
 __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams p) {
-    static_assert(sizeof(T) == 2 || (!TRW && !SEG && sizeof(YT) == 4), "fp32 operands: forward form, fp32 outputs");
+    static_assert(sizeof(T) == 2 || (!TRW && !SEG && !TRX && sizeof(YT) == 4), "fp32 operands: forward form, fp32 outputs");
+    static_assert(!TRX || (TRW && !SEG), "contraction-major x: the TN form (both operands contraction-major, no segments)");
     using frag = typename FragOf<T>::type;
     constexpr unsigned ES = sizeof(T);            // bytes per operand element
     constexpr int TKE = ROW_BYTES / (int)ES;      // k-values per k-step: 64 (16-bit) or 32 (fp32)
@@ -112,10 +116,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     auto setup_x = [&](const int4 d) {
         const int m0 = __builtin_amdgcn_readfirstlane(d.w);
         xb = reinterpret_cast<const T*>(p.x) + (long long)__builtin_amdgcn_readfirstlane(d.y) * p.x_sstride;
-        int prow, kc8;
-        piece_lane(prow, kc8);
-        xo = ((unsigned)(m0 + wid * 8 + prow) * (unsigned)K + kc8) * ES;
-        x_bytes = (unsigned)M * (unsigned)K * ES;
+        if constexpr (TRX) {  // as the W unit of the TRW form, over the M (= 512-byte row) direction of x
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int tr_r = wid * 2 + (ln >> 5);
+            const int tr_c = (ln & 31) ^ (((tr_r & 3) | ((tr_r >> 1) & 4)) << 1);
+            xo = ((unsigned)tr_r * (unsigned)M + (unsigned)min(m0 + tr_c * 8, M - 8)) * 2u;
+            x_bytes = 0x7FFFFFFF;
+        } else {
+            int prow, kc8;
+            piece_lane(prow, kc8);
+            xo = ((unsigned)(m0 + wid * 8 + prow) * (unsigned)K + kc8) * ES;
+            x_bytes = (unsigned)M * (unsigned)K * ES;
+        }
     };
     // one 1 KiB piece: `base` (a buffer of `bytes`) + per-lane byte offset `off` + wave-uniform byte offset `soff` -> LDS `dst`
     auto piece = [&](const T* base, unsigned bytes, unsigned off, int soff, char* dst) {
@@ -145,8 +158,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
         const int seg = segment(kt);
         const T* xs = SEG ? xb + (long long)seg * p.x_seg_stride : xb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i * 8 + 7 < h4 || i * 8 + wid < h4) piece(xs, x_bytes, xo + i * rowblk, kt * (TK * 2), base + i * 8192);
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (TRX) piece(xs, x_bytes, xo, (kt * TK + i * 16) * M * 2, base + i * 8192);
+            else if (i * 8 + 7 < h4 || i * 8 + wid < h4) piece(xs, x_bytes, xo + i * rowblk, kt * (TK * 2), base + i * 8192);
+        }
     };
     auto issue_w = [&](int kt, int slot) {
 #ifdef BF_DEV
@@ -180,6 +195,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     // the block's 32-byte granule; granule' = granule ^ key(row).  Fragment block i of the wave: one XOR away.
     const int tr_rl = ((lane & 15) >> 2) | (((lane >> 4) & 1) << 2);
     const unsigned tr_w0 = lds0 + ((lane >> 4) * 8 + ((lane & 15) >> 2)) * 512 + (lane & 3) * 8 + (((wn * 4) ^ tr_rl) << 5);
+    // contraction-major x unit: wave group wm owns the 16-row blocks wm, wm + 2, ... of the tile = granules wm + 2 j
+    const unsigned tr_x0 = lds0 + ((lane >> 4) * 8 + ((lane & 15) >> 2)) * 512 + (lane & 3) * 8 + ((wm ^ tr_rl) << 5);
     auto tr_read = [&](unsigned a0, int blk, auto half) -> frag {
         const unsigned a = a0 ^ (unsigned)(blk << 5);
         constexpr int off = decltype(half)::value * 32 * 512;
@@ -239,9 +256,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
                         wf[decltype(ic)::value] = lds_read(aw, std::integral_constant<int, decltype(ic)::value * 16 * ROW_BYTES>{});
                     });
                 }
-                static_for<0, H>([&](auto jc) {
-                    xf[decltype(jc)::value] = lds_read(ax, std::integral_constant<int, decltype(jc)::value * 32 * ROW_BYTES>{});
-                });
+                if constexpr (TRX) {
+                    const unsigned atx = tr_x0 + slot_x * SLOT_BYTES;
+#pragma unroll
+                    for (int j = 0; j < H; ++j) xf[j] = tr_read(atx, 2 * j, half);
+                } else {
+                    static_for<0, H>([&](auto jc) {
+                        xf[decltype(jc)::value] = lds_read(ax, std::integral_constant<int, decltype(jc)::value * 32 * ROW_BYTES>{});
+                    });
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
             auto mfmas = [&] {
@@ -325,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
             // group 1's last LDS slot, group 1 comes from its last MFMA slot.  The next unit that lands there is W(2) of
             // the next tile, issued behind that tile's second barrier, which every wave reaches after its epilogue; the
             // slot of W of the last k-step takes the next tile's X(1) at once (no wave reads it any more).
-            static_assert(sizeof(YT) == 2 || sizeof(T) == 4, "the one-slot epilogue scratch: 16-bit outputs, or fp32 through one slice");
+            // (the one-slot epilogue scratch: 16-bit outputs through two 2 KiB slices per wave, fp32 outputs through one of 4 KiB)
             int sc = a + 4;
             if (sc >= NSLOT) sc -= NSLOT;
             YT* y = reinterpret_cast<YT*>(p.y) + (long long)s * M * N;
@@ -356,9 +379,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     }
 }
 
-template <typename T, typename YT, bool TRW, bool SEG>
+template <typename T, typename YT, bool TRW, bool SEG, bool TRX = false>
 int launch_r5(const GemmParams& p, hipStream_t stream, int grid) {
-    hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, TRW, SEG>), dim3(grid), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, TRW, SEG, TRX>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -407,6 +430,21 @@ int bf_launch_gemm256_f32(const GemmParams& p0, hipStream_t stream) {
     p.sched_rounds = sc.rounds;
     return launch_r5<float, float, false, false>(p, stream, sc.grid);
 }
+
+#ifdef BF_DEV
+// TN form (both operands contraction-major, fp32 out): out[b][n][k] = sum_m a[b][m][n] * bmat[b][m][k] — the weight gradient.
+// Developer builds only: measured against the unit ring of bf_gemm256.hip (profiles/r6h_tn_ring5_ab.txt), not faster.
+bool bf_gemm256_r5_tn_supported(const GemmParams& p) {
+    if (p.K < 2 * TK || p.M % 8 || p.N % 8) return false;
+    // (a sample's operand is addressed by 32-bit byte offsets through a buffer descriptor)
+    return (long long)(p.K + 64) * p.M < (1ll << 30) && (long long)(p.K + 64) * p.N < (1ll << 30);
+}
+
+int bf_launch_gemm256_r5_tn(const GemmParams& p, int dtype, hipStream_t stream, int grid) {
+    if (dtype == BF_DT_BF16) return launch_r5<__bf16, float, true, false, true>(p, stream, grid);
+    return launch_r5<_Float16, float, true, false, true>(p, stream, grid);
+}
+#endif
 
 // NN form (x K-contiguous, W contraction-major as sampled, 16-bit out): y[s][m][k] = sum_n x[s][m][n] w[s][n][k]
 int bf_launch_gemm256_r5_nn(const GemmParams& p, int dtype, hipStream_t stream, int grid) {
