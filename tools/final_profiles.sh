@@ -9,7 +9,7 @@ HASH=${2:-unknown}
 OUT=gpurun_out/${TAG}_final
 mkdir -p $OUT
 python bench.py > $OUT/bench_bert_base_default.json 2> $OUT/bench_bert_base_default.err
-for w in bert_large_qa bert_base_train bert_large_qa_train linear768 linear768_m32 mlp; do
+for w in bert_large_qa bert_base_serial bert_base_train bert_large_qa_train linear768 linear768_m32 mlp; do
     python bench.py --workload $w --no-traffic > $OUT/bench_$w.json 2> /dev/null
 done
 python bench.py --workload bert_base_train --no-dropout --no-traffic > $OUT/bench_bert_base_train_no_dropout.json 2> /dev/null
