@@ -74,6 +74,8 @@ SYMBOLS = {
     "bf_linear_bwd": (_i, [_vp, _i64, _vp, _i, _tp, _tp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _u64, _u32, _i, _vp,
                            _vp, _vp, _vp, _vp, _sz, _vp]),
     "bf_linear_bwd_splits": (_i, [_i, _i, _i, _i, _i]),
+    "bf_gemm_nn_actgrad_supported": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "bf_gemm_nn_actgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "bf_param_grad_table_bytes": (_sz, [_vp, _i, ctypes.POINTER(ctypes.c_uint32)]),
     "bf_param_grad_table_build": (_i, [_vp, _i, _vp, _sz]),
     "bf_param_grad_table": (_i, [_vp, _i, _u32, _i, _u64, _u32, _vp]),

@@ -23,7 +23,7 @@ from .ops import invalidate_caches  # noqa: F401
 from .random import (get_compute_dtype, manual_seed, set_compute_dtype, set_kl_gradient,  # noqa: F401
                      use_device_counter)
 
-__all__ = ["to_bayesian", "invalidate_caches", "fuse_activations", "fuse_residual_layernorm", "fuse_shared_inputs", "fuse_attention", "fuse_embeddings", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
+__all__ = ["to_bayesian", "invalidate_caches", "fuse_activations", "fuse_residual_layernorm", "fuse_shared_inputs", "fuse_ffn_pairs", "fuse_attention", "fuse_embeddings", "enable_embedding", "nn", "manual_seed", "set_compute_dtype", "get_compute_dtype",
            "use_device_counter", "set_kl_gradient"]
 
 
@@ -134,6 +134,66 @@ def _layernorm_forward(self, input):
     if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad):
         return ops.AddLayerNormFn.apply(input, None, self.weight, self.bias, self.eps)
     return ops.add_layernorm(input, None, self.weight, self.bias, self.eps)
+
+
+def _ffn_pair_chunk(self, attention_output):
+    """`feed_forward_chunk` of an HF transformer layer — output(intermediate(a), a) — with the two Bayesian dense layers and
+    the GELU between them as ONE autograd node (nn.layers.linear._FFNPairFn) when a gradient is recorded and both layers were
+    sampled by the model's cross-layer plan; anything else (inference, layers outside the plan, another activation) runs
+    the module's own method."""
+    from . import ops
+    from .nn.layers.linear import _FFNPairFn
+    from .nn.parameters.gaussian import Gaussian
+
+    up, down = self.intermediate.dense, self.output.dense
+    ctx = bfr.STATE.ctx
+    a = attention_output
+    plan = ctx.plan if ctx is not None else None
+    usable = (plan is not None and torch.is_grad_enabled() and id(up) in plan.group_of and id(down) in plan.group_of
+              and not up._small_m and not down._small_m and up.activation == "gelu" and down.activation is None
+              and isinstance(self.intermediate.intermediate_act_fn, _FusedIntoDense)
+              and up._shared_input is None and down._shared_input is None
+              and isinstance(up.bias, Gaussian) and isinstance(down.bias, Gaussian)
+              and a.is_cuda and a.dtype in (torch.bfloat16, torch.float16) and a.shape[-1] == up.in_features
+              and up.out_features % 8 == 0 and (a.numel() // up.in_features) % ctx.S == 0
+              and (a.numel() // up.in_features) // ctx.S > 128
+              and (a.requires_grad or any(p.requires_grad for l in (up, down) for p in l.parameters())))
+    if not usable:
+        return self._bf_plain_ffn_chunk(attention_output)
+    S, seed, base = ctx.S, bfr.STATE.seed, ctx.sample_base
+    w1, b1 = plan.ensure(up, ctx.token, seed, base, ctx.lp_buf)
+    w2, b2 = plan.ensure(down, ctx.token, seed, base, ctx.lp_buf)
+    if w1.dtype != a.dtype or w2.dtype != a.dtype:
+        return self._bf_plain_ffn_chunk(attention_output)
+    x2 = a.reshape(-1, up.in_features)
+    params = [t for l in (up, down) for t in (l.weight.mu, l.weight.rho, l.bias.mu, l.bias.rho)]
+    y = _FFNPairFn.apply(x2 if x2.is_contiguous() else x2.contiguous(), up, down, S, seed, base, w1, b1, w2, b2, *params)
+    for l in (up, down):  # what Linear.forward leaves behind: the log-probs of this forward are the plan's
+        l._lp_view, l._lp_dirty = ctx.slot(l), True
+    y = y.view(*a.shape[:-1], down.out_features)
+    out = self.output
+    if getattr(out.LayerNorm, "_bf_fused", False) and isinstance(out.forward, types.MethodType) and out.forward.__func__ is _dense_residual_norm_forward:
+        return _residual_norm(out, y, a)
+    return out.LayerNorm(out.dropout(y) + a)
+
+
+def fuse_ffn_pairs(model: torch.nn.Module) -> int:
+    """Make the feed-forward pair of every HuggingFace-style transformer layer (modules with `intermediate.dense` and
+    `output.dense` as bnn.Linear children and a `feed_forward_chunk` method) ONE autograd node in training: the GELU's
+    backward then rides in the epilogue of the down-projection's input-gradient GEMM (bf_gemm_nn_actgrad) instead of a pass
+    of its own over the intermediate-sized gradient.  Call after `fuse_activations`.  Training-time rewrite; inference is
+    untouched.  Returns the number of layers rewritten."""
+    fused = 0
+    for m in model.modules():
+        inter, out = getattr(m, "intermediate", None), getattr(m, "output", None)
+        if (inter is not None and out is not None and isinstance(getattr(inter, "dense", None), nn.Linear)
+                and isinstance(getattr(out, "dense", None), nn.Linear) and hasattr(m, "feed_forward_chunk")
+                and isinstance(getattr(out, "LayerNorm", None), torch.nn.LayerNorm) and hasattr(out, "dropout")
+                and inter.dense.out_features == out.dense.in_features and not hasattr(m, "_bf_plain_ffn_chunk")):
+            m._bf_plain_ffn_chunk = m.feed_forward_chunk
+            m.feed_forward_chunk = types.MethodType(_ffn_pair_chunk, m)
+            fused += 1
+    return fused
 
 
 def fuse_residual_layernorm(model: torch.nn.Module) -> int:

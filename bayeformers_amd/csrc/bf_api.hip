@@ -587,6 +587,18 @@ int bf_gemm_nn(const void* d_x, const void* d_w, void* d_y, int dtype, int S, in
     return bf_launch_gemm256_nn(d_x, d_w, d_y, dtype, S, M, N, K, (hipStream_t)stream);
 }
 
+int bf_gemm_nn_actgrad_supported(const void* d_x, const void* d_w, const void* d_y, const void* d_pre, int dtype, int S, int M,
+                                 int N, int K) {
+    return bf_gemm256_nn_actgrad_supported(dtype, S, M, N, K, d_x, d_w, d_y, d_pre) ? 1 : 0;
+}
+
+int bf_gemm_nn_actgrad(const void* d_x, const void* d_w, void* d_y, const void* d_pre, int dtype, int S, int M, int N, int K,
+                       int act, void* stream) {
+    if (!d_x || !d_w || !d_y || !d_pre) BF_FAIL("bf_gemm_nn_actgrad: null pointer");
+    if (act != BF_ACT_GELU) BF_FAIL("bf_gemm_nn_actgrad: unknown activation %d", act);
+    return bf_launch_gemm256_nn(d_x, d_w, d_y, dtype, S, M, N, K, (hipStream_t)stream, 1, d_pre, act);
+}
+
 int bf_gemm_nn_layers(const void* d_x, const void* d_w, void* d_y, int dtype, int L, int S, int M, int N, int K,
                       void* stream) {
     if (!d_x || !d_w || !d_y) BF_FAIL("bf_gemm_nn_layers: null pointer");

@@ -988,15 +988,26 @@ bool bf_gemm256_nn_supported(int dtype, int S, int M, int Nl, int Kl, const void
     return (long long)M * Kl >= 128 * 128;
 }
 
+bool bf_gemm256_nn_actgrad_supported(int dtype, int S, int M, int Nl, int Kl, const void* d_x, const void* d_w, const void* d_y,
+                                     const void* d_gpre) {
+    if (!bf_gemm256_nn_supported(dtype, S, M, Nl, Kl, d_x, d_w, d_y) || !d_gpre || ((uintptr_t)d_gpre & 15)) return false;
+    GemmParams p{};
+    p.M = M, p.N = Kl, p.K = Nl;
+    return bf_gemm256_r5_supported(p, dtype, dtype);  // the fused derivative lives in the ring kernel's epilogue only
+}
+
 int bf_launch_gemm256_nn(const void* d_x, const void* d_w, void* d_y, int dtype, int S, int M, int Nl, int Kl,
-                         hipStream_t stream, int segs) {
+                         hipStream_t stream, int segs, const void* d_gpre, int act) {
     if (segs < 1 || segs > 4) BF_FAIL("bf_gemm_nn: 1 to 4 layers (got %d)", segs);
+    if (d_gpre && (segs != 1 || act != BF_ACT_GELU || !bf_gemm256_nn_actgrad_supported(dtype, S, M, Nl, Kl, d_x, d_w, d_y, d_gpre)))
+        BF_FAIL("bf_gemm_nn_actgrad: needs the ring form of the NN GEMM (16-bit, K %% 8 == 0, contraction >= 128), the GELU and one layer");
     GemmParams p{};
     p.x = d_x;
     p.w = d_w;
     p.bias = nullptr;
     p.y = d_y;
     p.y2 = nullptr;
+    p.gpre = d_gpre;
     p.x_sstride = (long long)M * Nl;
     p.S = S;
     p.M = M;

@@ -140,7 +140,8 @@ __device__ __forceinline__ f32x4_t act_chunk(f32x4_t c, int act) {
 // when a wave gets here, see the kernel).
 template <typename YT, int H, int SLICES = 2>
 __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc)[4][H], YT* y, YT* y2, int m0,
-                                              int m_end, int n0, int N, int wm, int wn, int lane, int act) {
+                                              int m_end, int n0, int N, int wm, int wn, int lane, int act,
+                                              const YT* gpre = nullptr) {  // gpre: the stored rows are multiplied by act'(gpre)
     constexpr int ROWB = 64 * (int)sizeof(YT);   // 128 or 256
     constexpr int BLK = 16 * ROWB;               // 2 or 4 KiB
     constexpr int CH = ROWB / 16;                // 16-byte chunks per row: 8 or 16
@@ -166,7 +167,7 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
         char* R = scratch + (SLICES == 2 ? (mb & 1) * BLK : 0);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            const f32x4_t v = y2 ? acc[nb][mb] : bf_apply_act<sizeof(YT) == 2>(acc[nb][mb], act);
+            const f32x4_t v = (y2 || gpre) ? acc[nb][mb] : bf_apply_act<sizeof(YT) == 2>(acc[nb][mb], act);
             char* dst = R + wr_off[nb];
             if constexpr (sizeof(YT) == 4)
                 *reinterpret_cast<f32x4_t*>(dst) = v;
@@ -213,6 +214,17 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
                     v = act_chunk<YT>(v, act);
                 }
                 YT* o = y + (unsigned)(m * N + n);
+                if constexpr (sizeof(YT) == 2) {
+                    if (gpre && n_full) {  // (whole 16-byte chunks only: the host requires N % 8 == 0 for this form)
+                        typedef __attribute__((ext_vector_type(8))) YT yt8;
+                        const yt8 g = __builtin_bit_cast(yt8, v);
+                        const yt8 x = *reinterpret_cast<const yt8*>(gpre + (unsigned)(m * N + n));
+                        yt8 r;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) r[j] = (YT)((float)g[j] * bf_gelu_grad((float)x[j]));
+                        v = __builtin_bit_cast(f32x4_t, r);
+                    }
+                }
                 if (n_full) {
                     gemm_st16(reinterpret_cast<f32x4_t*>(o), v);
                 } else {

@@ -359,7 +359,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
             if (p.flags & 16) m_end = 0;  // ablation: no global stores
             if (p.flags & 8) return;      // ablation: no epilogue
 #endif
-            epilogue_wave<YT, H, sizeof(YT) == 2 ? 2 : 1>(scratch, acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act);
+            const YT* gpre = (TRW && !TRX && sizeof(YT) == 2 && p.gpre) ? reinterpret_cast<const YT*>(p.gpre) + (long long)s * M * N : nullptr;
+            epilogue_wave<YT, H, sizeof(YT) == 2 ? 2 : 1>(scratch, acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act, gpre);
         };
         switch (h) {
             case 8: body(std::integral_constant<int, 8>{}); break;

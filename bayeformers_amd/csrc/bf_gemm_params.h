@@ -9,6 +9,10 @@ struct GemmParams {
     const float* bias;
     void* y;
     void* y2;  // 256-wide kernel only: when set, act(y) goes to y and the pre-activation y (same dtype) to y2
+    // five-slot ring kernel, 16-bit outputs: when set ([S][M][N] of the output type), y is multiplied by act'(gpre) on its way
+    // out (act = the activation whose derivative is meant) — the input-gradient GEMM of a layer whose input was act(pre):
+    // d pre = (dy W) o act'(pre) without a pass of its own over the activation-sized gradient (bf_gemm_nn_actgrad)
+    const void* gpre;
     long long x_sstride;  // elements between samples of x (0 = one x shared by all samples)
     int S, M, N, K;
     int tiles_m, tiles_n;
@@ -45,7 +49,9 @@ int bf_launch_gemm256_tn(const void* d_a, const void* d_b, float* d_out, int dty
 // NN form (x K-contiguous, w contraction-major, 16-bit out): y[s][m][k] = sum_n x[s][m][n] * w[s][n][k]
 bool bf_gemm256_nn_supported(int dtype, int S, int M, int Nl, int Kl, const void* d_x, const void* d_w, const void* d_y);
 int bf_launch_gemm256_nn(const void* d_x, const void* d_w, void* d_y, int dtype, int S, int M, int Nl, int Kl,
-                         hipStream_t stream, int segs = 1);
+                         hipStream_t stream, int segs = 1, const void* d_gpre = nullptr, int act = 0);
+bool bf_gemm256_nn_actgrad_supported(int dtype, int S, int M, int Nl, int Kl, const void* d_x, const void* d_w, const void* d_y,
+                                     const void* d_gpre);
 #ifdef BF_DEV
 // round-1 kernel (fixed 256x256 tiles, arithmetic tile order), kept in developer builds as the A/B baseline
 int bf_launch_gemm256_r1(const GemmParams& p, int w_dtype, int y_dtype, hipStream_t stream);

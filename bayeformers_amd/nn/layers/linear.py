@@ -158,6 +158,51 @@ class _StackedLinearFn(torch.autograd.Function):
         return tuple(out)
 
 
+class _FFNPairFn(torch.autograd.Function):
+    """dense -> exact GELU -> dense of a transformer feed-forward pair (HF BertIntermediate + BertOutput.dense) as ONE autograd
+    node.  Forward: the two planned GEMMs as they run anyway (GELU in the first one's epilogue, pre-activation kept).  Backward:
+    the gradient that reaches the pre-activation, (dy W_down) o gelu'(pre), comes out of the down layer's input-gradient GEMM
+    itself (bf_gemm_nn_actgrad) — autograd's two nodes need a pass of their own over the [S*M, 3072] gradient for it
+    (gelu_bwd_colsum: 130 us per layer of a BERT-base step).  The intermediate never leaves this node, so it has exactly one
+    consumer by construction.  Everything else is the two layers' ordinary backward (ops.linear_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, up, down, S, seed, base, w1, b1, w2, b2, *params):
+        ctx.up, ctx.down, ctx.S, ctx.seed, ctx.base, ctx.cdt = up, down, S, seed, base, w1.dtype
+        fwd = bfr.STATE.ctx
+        ctx.kept = tuple((fwd.plan, fwd.plan.group_of[id(l)], fwd.token, w) for l, w in ((up, w1), (down, w2)))
+        ctx.counter = bfr.counter_snapshot(True)
+        _note_forward(up, S, x, ctx.cdt, True)
+        _note_forward(down, S, x, ctx.cdt, True)   # (same rows per sample: the intermediate is [S*M, N1])
+        h, pre = ops.planned_linear_forward(x, w1, b1, S, up.out_features, up.in_features, 1, True)
+        y = ops.planned_linear_forward(h, w2, b2, S, down.out_features, down.in_features, 0)
+        ctx.save_for_backward(x, pre, h)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pre, h = ctx.saved_tensors
+        up, down, S, seed, base, cdt = ctx.up, ctx.down, ctx.S, ctx.seed, ctx.base, ctx.cdt
+        M = x.shape[0] // S
+        alive = [plan.arena_owner[gi % len(plan.arenas)] == (gi, token) for plan, gi, token, _ in ctx.kept]
+        w1 = ctx.kept[0][3] if alive[0] else None
+        w2 = ctx.kept[1][3] if alive[1] else None
+        need = ctx.needs_input_grad   # x, then (after the 9 non-tensor arguments) mu_w, rho_w, mu_b, rho_b of up and of down
+        dy = (dy if dy.dtype == cdt else dy.to(cdt)).contiguous()
+        with bfr.counter_override(ctx.counter):
+            dyv = dy.view(S, M, down.out_features)
+            fused = w2 is not None and ops.gemm_nn_actgrad_supported(dyv, w2, pre)
+            # the down layer: its parameter gradients (and, without the fused form, its input gradient)
+            r2 = ops.linear_backward(down, h, dy, S, seed, base, cdt, not fused, need[14], need[16], w2)
+            if fused:
+                dpre = ops.gemm_nn_actgrad(dyv, w2, pre).view(S * M, -1)
+                r1 = ops.linear_backward(up, x, dpre, S, seed, base, cdt, need[0], need[10], need[12], w1)
+            else:
+                r1 = ops.linear_backward(up, x, r2[0], S, seed, base, cdt, need[0], need[10], need[12], w1, 1, pre)
+        dx = r1[0]
+        return (dx, None, None, None, None, None, None, None, None, None) + tuple(r1[1:]) + tuple(r2[1:])
+
+
 class Linear(KernelLayer):
     """Bayesian Linear layer with Gaussian weight/bias posteriors and a prior per parameter.
 

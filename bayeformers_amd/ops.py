@@ -281,6 +281,27 @@ def gemm_nn(x: Tensor, w: Tensor) -> Tensor:
     return y
 
 
+def gemm_nn_actgrad_supported(x: Tensor, w: Tensor, pre: Tensor) -> bool:
+    S, M, N = x.shape
+    K = w.shape[2]
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype and pre.dtype == x.dtype
+            and x.is_contiguous() and w.is_contiguous() and pre.is_contiguous() and pre.numel() == S * M * K):
+        return False
+    return bool(_C.lib().bf_gemm_nn_actgrad_supported(x.data_ptr(), w.data_ptr(), x.data_ptr(), pre.data_ptr(), _TORCH2BF[x.dtype],
+                                                      S, M, N, K))
+
+
+def gemm_nn_actgrad(x: Tensor, w: Tensor, pre: Tensor, act: int = 1) -> Tensor:
+    """y[s] = (x[s] w[s]) o act'(pre[s]) (bf_gemm_nn_actgrad): the input-gradient GEMM of a layer whose input was act(pre), with
+    the activation's derivative in its epilogue.  x: [S, M, N], w: [S, N, K], pre: [S, M, K] (or [S*M, K]); returns [S, M, K]."""
+    S, M, N = x.shape
+    K = w.shape[2]
+    y = torch.empty((S, M, K), dtype=x.dtype, device=x.device)
+    _C.check(_C.lib().bf_gemm_nn_actgrad(x.data_ptr(), w.data_ptr(), y.data_ptr(), pre.data_ptr(), _TORCH2BF[x.dtype], S, M, N, K,
+                                         int(act), _stream_ptr()), "bf_gemm_nn_actgrad")
+    return y
+
+
 def gemm_nn_layers(x: Tensor, w: Tensor) -> Tensor:
     """y[s] = sum_l x[l][s] w[l][s] (bf_gemm_nn_layers): the one input gradient of L layers that read the same
     activations.  x: [L, S, M, N], w: [L, S, N, K], 16-bit; returns [S, M, K]."""

@@ -199,6 +199,7 @@ def build_bert(device, dtype):
     n_qkv = bf.fuse_shared_inputs(bmodel) if os.environ.get("BF_BENCH_NO_QKV_FUSION") is None else 0
     attn = bf.fuse_attention(bmodel) if os.environ.get("BF_BENCH_NO_ATTENTION") is None else False
     n_emb = bf.fuse_embeddings(bmodel) if os.environ.get("BF_BENCH_NO_EMBED_FUSION") is None else 0
+    n_ffn = bf.fuse_ffn_pairs(bmodel) if os.environ.get("BF_BENCH_NO_FFN_PAIR") is None else 0  # (acts when gradients are recorded)
     if dtype != "fp32":
         bmodel = bmodel.to(torch.bfloat16 if dtype == "bf16" else torch.float16)
     g = torch.Generator().manual_seed(321)
@@ -206,7 +207,7 @@ def build_bert(device, dtype):
     labels = torch.randint(0, 2, (B,), generator=g)
     inputs = {"input_ids": ids.to(device), "attention_mask": torch.ones(B, L, dtype=torch.long, device=device)}
     info = {"gelu_fused_into_gemm": n_fused, "residual_layernorm_fused": n_ln, "qkv_in_one_launch": n_qkv,
-            "attention_kernel": bool(attn), "embeddings_in_one_launch": n_emb}
+            "attention_kernel": bool(attn), "embeddings_in_one_launch": n_emb, "ffn_pair_one_autograd_node": n_ffn}
     return bmodel, model, inputs, ids, labels, info
 
 
@@ -336,6 +337,7 @@ def make_bert_large_qa(device, S, dtype, train=False, train_mode=False, graph_tr
     n_qkv = bf.fuse_shared_inputs(bmodel) if os.environ.get("BF_BENCH_NO_QKV_FUSION") is None else 0
     attn = bf.fuse_attention(bmodel) if os.environ.get("BF_BENCH_NO_ATTENTION") is None else False
     n_emb = bf.fuse_embeddings(bmodel) if os.environ.get("BF_BENCH_NO_EMBED_FUSION") is None else 0
+    n_ffn = bf.fuse_ffn_pairs(bmodel) if os.environ.get("BF_BENCH_NO_FFN_PAIR") is None else 0
     if dtype != "fp32":
         bmodel = bmodel.to(torch.bfloat16 if dtype == "bf16" else torch.float16)
     g = torch.Generator().manual_seed(654)

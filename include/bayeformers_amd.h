@@ -191,6 +191,15 @@ int bf_gemm_nn(const void* d_x, const void* d_w, void* d_y, int dtype, int S, in
  * as ONE contraction of length L*N: one launch and one output instead of L launches and L - 1 additions. */
 int bf_gemm_nn_layers(const void* d_x, const void* d_w, void* d_y, int dtype, int L, int S, int M, int N, int K,
                       void* stream);
+/* bf_gemm_nn with the derivative of an activation in its epilogue (ABI 6): y[s][m][k] = (sum_n x[s][m][n] w[s][n][k]) * act'(pre[s][m][k])
+ * — the gradient that reaches the PRE-activation of the layer whose act(pre) was this layer's input (HF BertIntermediate ->
+ * BertOutput: dpre = (dy W_down) o gelu'(pre); /root/reference/examples/bert_glue.py:239 runs it as two autograd nodes), without a
+ * pass of its own over the [S][M][K] gradient.  act = BF_ACT_GELU; d_pre: [S][M][K] of `dtype`, 16-byte aligned; needs the ring
+ * form of the NN kernel (bf_gemm_nn_actgrad_supported = 1: 16-bit dtype, K % 8 == 0, N >= 128 ...). */
+int bf_gemm_nn_actgrad_supported(const void* d_x, const void* d_w, const void* d_y, const void* d_pre, int dtype, int S, int M,
+                                 int N, int K);
+int bf_gemm_nn_actgrad(const void* d_x, const void* d_w, void* d_y, const void* d_pre, int dtype, int S, int M, int N, int K,
+                       int act, void* stream);
 
 /* Build (once per device and shape) the tile schedule the 256-wide GEMM kernels run a [S][M][N] problem of L stacked
  * layers on — a small device table, allocated here.  The first bf_gemm_nt* / bf_linear_* call of a shape does the same

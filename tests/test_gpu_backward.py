@@ -879,3 +879,57 @@ def test_deferred_weight_reduction_gives_the_per_layer_gradients(golden_dir, mon
             assert torch.equal(p0[n], p1[n]), (k, n)
     mgr = m._pgrad
     assert mgr.table is not None and len(mgr.table["layers"]) == len([l for l in m.fused_children()])
+
+
+def test_ffn_pair_node_matches_the_two_layer_path():
+    """fuse_ffn_pairs: dense -> GELU -> dense of a transformer layer as one autograd node whose backward takes the GELU's
+    derivative in the epilogue of the down-projection's input-gradient GEMM (bf_gemm_nn_actgrad).  Same forward bit for bit;
+    every gradient agrees with the two-node path to bf16 rounding (the fused form rounds the intermediate gradient once
+    instead of twice), and the kernel alone agrees with its definition in fp32."""
+    import copy
+
+    from transformers import BertConfig, BertForSequenceClassification
+
+    from bayeformers_amd import ops
+
+    # the kernel against its definition
+    g = torch.Generator(device="cuda").manual_seed(3)
+    S, M, N, K = 3, 512, 256, 1024
+    dy = torch.randn(S, M, N, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(S, N, K, device="cuda", generator=g) * 0.05).bfloat16()
+    pre = torch.randn(S, M, K, device="cuda", generator=g).bfloat16()
+    assert ops.gemm_nn_actgrad_supported(dy, w, pre)
+    got = ops.gemm_nn_actgrad(dy, w, pre).float()
+    x = pre.float()
+    dgelu = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+    want = torch.einsum("smn,snk->smk", dy.float(), w.float()) * dgelu
+    assert (got - want).abs().max().item() <= 2 ** -7 * want.abs().max().item()
+    assert torch.equal(ops.gemm_nn(dy, w), ops.gemm_nn(dy, w))  # (the plain form is untouched)
+
+    cfg = BertConfig(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024, vocab_size=500,
+                     max_position_embeddings=128)
+    torch.manual_seed(0)
+    base = bf.to_bayesian(BertForSequenceClassification(cfg).eval(), delta=0.05).cuda().to(torch.bfloat16)
+    ids = torch.randint(0, 500, (4, 128), device="cuda")
+    labels = torch.randint(0, 2, (4,), device="cuda")
+    bf.set_compute_dtype("bf16")
+
+    def run(pair):
+        m = copy.deepcopy(base)
+        bf.fuse_activations(m), bf.fuse_residual_layernorm(m), bf.fuse_shared_inputs(m), bf.fuse_attention(m)
+        if pair:
+            assert bf.fuse_ffn_pairs(m) == 2
+        bf.manual_seed(SEED)
+        S = 3
+        with m.monte_carlo(S):
+            out = m(input_ids=ids.repeat(S, 1)).logits
+        torch.nn.functional.cross_entropy(out.float().view(S, 4, 2).mean(0), labels).backward()
+        return out.detach(), {n: p.grad.float() for n, p in m.named_parameters() if p.grad is not None}
+
+    o0, g0 = run(False)
+    o1, g1 = run(True)
+    assert torch.equal(o0, o1)
+    assert g0.keys() == g1.keys() and len(g0) > 40
+    for n in g0:
+        scale = g0[n].abs().max().item() + 1e-20
+        assert (g0[n] - g1[n]).abs().max().item() <= 3e-2 * scale, (n, (g0[n] - g1[n]).abs().max().item() / scale)
