@@ -122,6 +122,7 @@ def call_signature(args, kwargs):
             return None, None
     if device is None:
         return None, None
+    sig.append(("device", device.index))
     return tuple(sig), device
 
 

@@ -316,3 +316,17 @@ def test_bayesian_children_walk_is_kept_and_notices_a_swapped_layer():
     b.model[2] = bnn.Linear(8, 4)
     b.refresh()
     assert len(b._children()[0]) == 2
+
+
+def test_fuse_ffn_pairs_rewires_only_transformer_feed_forward_pairs():
+    import bayeformers_amd as bf
+    from transformers import BertConfig, BertForSequenceClassification
+
+    cfg = BertConfig(hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128, vocab_size=100,
+                     max_position_embeddings=32)
+    b = bf.to_bayesian(BertForSequenceClassification(cfg).eval(), delta=0.05)
+    assert bf.fuse_activations(b) == 2
+    assert bf.fuse_ffn_pairs(b) == 2 and bf.fuse_ffn_pairs(b) == 0          # idempotent
+    layer = b.model.bert.encoder.layer[0]
+    assert layer.feed_forward_chunk.__func__ is bf._ffn_pair_chunk and hasattr(layer, "_bf_plain_ffn_chunk")
+    assert bf.fuse_ffn_pairs(bf.to_bayesian(torch.nn.Sequential(torch.nn.Linear(4, 4)))) == 0
