@@ -179,12 +179,31 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
     };
     // software pipeline over the blocks: block mb + 1 is converted and written (other slice) behind the row reads of
     // block mb — one LDS round trip per block instead of two
+    // gpre: the 16-byte chunks of the pre-activation that belong to the rows of block mb are fetched TWO blocks ahead (they come
+    // from HBM: written by the forward pass long ago) into registers the accumulators of the blocks already written out gave up
+    constexpr int PF = 2;
+    f32x4_t gp[PF + 1][NI];
+    auto fetch_gpre = [&](int mb) {
+        if constexpr (sizeof(YT) == 2) {
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const int m = m0 + (2 * mb + wm) * 16 + it * RPI + rr;
+                gp[mb % (PF + 1)][it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (m < m_end && n_full) gp[mb % (PF + 1)][it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(gpre + (unsigned)(m * N + n)));
+            }
+        }
+    };
     write_block(0);
+    if (gpre) {
+#pragma unroll
+        for (int b = 0; b < PF && b < H; ++b) fetch_gpre(b);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int mb = 0; mb < H; ++mb) {
         const char* R = scratch + (SLICES == 2 ? (mb & 1) * BLK : 0);
         f32x4_t rows[NI];
+        if (gpre && mb + PF < H) fetch_gpre(mb + PF);
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             const int r = it * RPI + rr;
@@ -218,7 +237,7 @@ __device__ __forceinline__ void epilogue_wave(char* scratch, const f32x4_t (&acc
                     if (gpre && n_full) {  // (whole 16-byte chunks only: the host requires N % 8 == 0 for this form)
                         typedef __attribute__((ext_vector_type(8))) YT yt8;
                         const yt8 g = __builtin_bit_cast(yt8, v);
-                        const yt8 x = *reinterpret_cast<const yt8*>(gpre + (unsigned)(m * N + n));
+                        const yt8 x = __builtin_bit_cast(yt8, gp[mb % (PF + 1)][it]);
                         yt8 r;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) r[j] = (YT)((float)g[j] * bf_gelu_grad((float)x[j]));
