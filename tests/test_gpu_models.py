@@ -146,7 +146,7 @@ def test_benchmarked_configuration_matches_reference_c3(golden_dir):
     bf.set_compute_dtype("bf16")
     bmodel, _, inputs, ids, labels, info = bench.build_bert(torch.device("cuda"), "bf16")
     assert info == {"gelu_fused_into_gemm": 12, "residual_layernorm_fused": 24, "qkv_in_one_launch": 12,
-                    "attention_kernel": True, "embeddings_in_one_launch": 1}
+                    "attention_kernel": True, "embeddings_in_one_launch": 1, "ffn_pair_one_autograd_node": 12}
     assert tuple(ids.shape) == (B, L) and int(ids.sum()) == int(g["ids_sum"]) and np.array_equal(labels.numpy(), g["labels"])
     assert len(bmodel.fused_children()) == int(g["n_layers"])
     bf.manual_seed(SEED)
