@@ -239,6 +239,7 @@ def auto_forward(model, args, kwargs) -> Optional[Any]:
         cache.seen[sig] = n + 1
         return None
     if any(m.training for m in model.modules()):  # a child switched to train() on its own: dropout masks are per call
+        cache.refused.add(sig)  # (not asked again — the walk costs 0.5 ms — until the model's mode is set anew: Model.train)
         return None
     while len(cache.forwards) >= KEEP:
         cache.forwards.pop(0)[1].close()

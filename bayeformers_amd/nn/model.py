@@ -147,6 +147,12 @@ class Model(Module):
             return out
         return self._eager_call(*args, **kwargs)
 
+    def train(self, mode: bool = True):
+        cache = self.__dict__.get("_graphs")
+        if cache is not None:
+            cache.refused.clear()  # signatures that were kept eager because of a child in training mode get another look
+        return super(Model, self).train(mode)
+
     def _eager_call(self, *args, **kwargs):
         S = self._mc_samples
         layers = self.fused_children()

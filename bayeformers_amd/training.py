@@ -231,6 +231,11 @@ class DeferredParamGrads:
     def __reduce__(self):
         return (DeferredParamGrads, ())
 
+    def release(self) -> None:
+        """Give the standing buffers back (4.6 GB for BERT-base at S = 10): the next training step observes and builds again.
+        `release_training_buffers(model)` calls it."""
+        self.table, self.armed, self._last, self._copies = None, False, None, ([], [])
+
     def __init__(self):
         self.table = None      # {id(layer): (layer, S, M, cdt, dw buffer)} + device blob, built from an observed step
         self.armed = False     # the running step's backward defers
@@ -360,6 +365,14 @@ class DeferredParamGrads:
         _C.check(lib.bf_param_grad_table_build(arr, n_entries, blob.data_ptr(), nbytes), "bf_param_grad_table_build")
         return {"sig": self._signature(seen), "layers": layers, "view": view, "grads": grads, "flat": flat,
                 "blob": blob.to(dev), "n": n_entries, "blocks": blocks.value}
+
+
+def release_training_buffers(model: Model) -> None:
+    """Free what `training_step` keeps on a model between steps (the per-sample weight-gradient buffers of DeferredParamGrads) —
+    for a long evaluation phase after training on the same GPU."""
+    mgr = model.__dict__.get("_pgrad")
+    if mgr is not None:
+        mgr.release()
 
 
 def grad_norm(tensors: List[Tensor]) -> Tensor:

@@ -324,3 +324,17 @@ def test_dropout_group_numbering_refuses_an_unsplittable_shard():
     assert d.first_group(2 * 160, 96) == 4 * 160 * 96
     with pytest.raises(_C.BayeFormersAMDError, match="cannot be split"):
         d.first_group(2 * 160 + 1, 96)
+
+
+def test_release_training_buffers_forgets_the_deferred_table():
+    from bayeformers_amd import training
+
+    class M:   # what release_training_buffers needs of a model
+        pass
+
+    m = M()
+    mgr = m.__dict__["_pgrad"] = training.DeferredParamGrads()
+    mgr.table, mgr.armed = {"sig": ()}, True
+    training.release_training_buffers(m)
+    assert mgr.table is None and not mgr.armed
+    training.release_training_buffers(M())   # nothing to release: no error
