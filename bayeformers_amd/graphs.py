@@ -84,6 +84,7 @@ class GraphCache:
         self.forwards = []   # [(signature, GraphedForward)], most recent last
         self.seen = {}       # signature -> eager calls seen so far (a forward is captured at its third call)
         self.refused = set()  # signatures whose capture failed or whose outputs cannot be copied: always eager
+        self.evictions = 0    # captured forwards closed to make room: a loop over more than KEEP signatures would capture for ever
 
     def __deepcopy__(self, memo):
         return GraphCache()
@@ -209,6 +210,7 @@ class GraphedForward:
 
 AUTO_AFTER = 2   # eager calls of one signature before it is captured (a one-off call never pays for a capture)
 KEEP = 2         # captured signatures kept per model
+MAX_EVICTIONS = 4  # ... and how often one of them may be closed for another before new signatures stay eager
 DISABLED = os.environ.get("BF_NO_AUTO_GRAPH") is not None
 
 
@@ -241,8 +243,16 @@ def auto_forward(model, args, kwargs) -> Optional[Any]:
     if any(m.training for m in model.modules()):  # a child switched to train() on its own: dropout masks are per call
         cache.refused.add(sig)  # (not asked again — the walk costs 0.5 ms — until the model's mode is set anew: Model.train)
         return None
+    if cache.evictions >= MAX_EVICTIONS:  # a loop that cycles through more signatures than are kept: capturing does not pay
+        return None
     while len(cache.forwards) >= KEEP:
         cache.forwards.pop(0)[1].close()
+        cache.evictions += 1
+        if cache.evictions == MAX_EVICTIONS:
+            import warnings
+
+            warnings.warn(f"bayeformers_amd: this model's evaluation forwards come in more than {KEEP} batch signatures; they keep "
+                          "running eagerly from now on (bucket the batch shapes, or use sampling.GraphedSampler per shape)")
     try:
         fw = GraphedForward(model, args, kwargs, device)
     except Exception as e:  # noqa: BLE001 - whatever the capture raised, the eager forward is still the product path
