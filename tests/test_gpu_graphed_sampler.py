@@ -266,3 +266,35 @@ def test_dropped_model_releases_its_graphs():
     gc.collect()
     assert ref() is None
     assert bfr.STATE.device_counter is None and bfr.get_state()[1] == 2 + 3
+
+
+def test_model_call_stops_capturing_when_signatures_cycle():
+    """A loop over more batch shapes than a model keeps captured forwards for must not capture for ever: after a few evictions new
+    signatures stay eager (with a warning) — and every call still returns what the eager call returns."""
+    import warnings
+
+    import bayeformers_amd as bf
+    from bayeformers_amd import graphs
+
+    bmodel, batches = _build()
+    bf.set_compute_dtype("bf16")
+    shapes = [{k: v[:n].clone() for k, v in batches[0].items()} for n in (1, 2, 3, 4)]
+    try:
+        with torch.no_grad(), warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            for _ in range(6):
+                for x in shapes:
+                    bmodel(**x)
+        cache = bmodel._graphs
+        assert cache.evictions == graphs.MAX_EVICTIONS and len(cache.forwards) <= graphs.KEEP
+        assert any("batch signatures" in str(w.message) for w in caught)
+        bmodel.graph_replay = False
+        bf.manual_seed(SEED)
+        with torch.no_grad():
+            want = bmodel(**shapes[3]).logits
+        bmodel.graph_replay = True
+        bf.manual_seed(SEED)
+        with torch.no_grad():
+            assert torch.equal(bmodel(**shapes[3]).logits, want)
+    finally:
+        bmodel._graphs.close()
