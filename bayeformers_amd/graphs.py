@@ -171,8 +171,9 @@ class GraphedForward:
         with torch.no_grad(), torch.cuda.device(self.device):
             for _ in range(self._warmup):  # plans, workspaces and tile schedules are built outside the capture
                 model._eager_call(*self._args, **self._kwargs)
-            # the warm-up forwards consumed sample indices the caller never saw: hand them back
+            # the warm-up forwards consumed sample indices (and dropout call numbers) the caller never saw: hand them back
             bfr.STATE.device_counter.sub_(self._warmup * total)
+            bfr.STATE.device_drop_counter.sub_(self._warmup)
             bfr.STATE.counter_moves += 1
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()

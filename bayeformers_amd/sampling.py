@@ -374,6 +374,7 @@ class GraphedSampler:
             # the warm-up steps consumed sample indices the caller never saw: hand them back, so that the first replay
             # draws what the eager step from the caller's state would have drawn
             bfr.STATE.device_counter.sub_(self._warmup * self.samples)
+            bfr.STATE.device_drop_counter.sub_(self._warmup)  # (one dropout call number per forward, used or not)
             bfr.STATE.counter_moves += 1
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()

@@ -210,6 +210,9 @@ def test_model_call_replays_the_reference_loop_and_equals_eager():
         assert not bmodel._graphs.forwards and bfr.STATE.device_counter is None
         got = loop(True)
         assert len(bmodel._graphs.forwards) == 1 and bfr.STATE.device_counter is not None
+        # every forward took one dropout call number, replayed or not, and the capture's warm-up forward gave its own back: the
+        # counter stands where the all-eager history left it (a training step that follows draws the same masks either way)
+        assert int(bfr.STATE.device_drop_counter.item()) == len(order)
         for k, (e, r) in enumerate(zip(eager, got)):
             assert torch.equal(e[0], r[0]), k
             assert e[1:] == r[1:], k
