@@ -57,8 +57,11 @@ struct FragOf<float> { using type = f32x4_t; };
 // TRX (round 6): the x unit contraction-major too ([64 contraction rows][256] tile of 512-byte rows, swizzled and read through
 // ds_read_b64_tr_b16 like a TRW unit) with fp32 outputs — the TN form dW[s] = dy[s]^T x[s] of the backward pass, which ran on
 // the two-buffer unit ring of bf_gemm256.hip (1 k-step ahead, 32 KiB of LDS reserved for its epilogue) until round 6.
-template <typename T, typename YT, bool TRW = false, bool SEG = false, bool TRX = false>
+// AG (round 6, NN form): the epilogue multiplies the stored rows by act'(p.gpre) (bf_gemm_nn_actgrad) — an instantiation of its
+// own, so that the plain input-gradient launches are the kernel they were.
+template <typename T, typename YT, bool TRW = false, bool SEG = false, bool TRX = false, bool AG = false>
 __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams p) {
+    static_assert(!AG || (TRW && !TRX && !SEG && sizeof(YT) == 2), "the activation-gradient epilogue: NN form, 16-bit outputs");
     static_assert(sizeof(T) == 2 || (!TRW && !SEG && !TRX && sizeof(YT) == 4), "fp32 operands: forward form, fp32 outputs");
     static_assert(!TRX || (TRW && !SEG), "contraction-major x: the TN form (both operands contraction-major, no segments)");
     using frag = typename FragOf<T>::type;
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
             if (p.flags & 16) m_end = 0;  // ablation: no global stores
             if (p.flags & 8) return;      // ablation: no epilogue
 #endif
-            const YT* gpre = (TRW && !TRX && sizeof(YT) == 2 && p.gpre) ? reinterpret_cast<const YT*>(p.gpre) + (long long)s * M * N : nullptr;
+            const YT* gpre = AG ? reinterpret_cast<const YT*>(p.gpre) + (long long)s * M * N : nullptr;
             epilogue_wave<YT, H, sizeof(YT) == 2 ? 2 : 1>(scratch, acc, y, y2, m0, m_end, n0, N, wm, wn, lane, p.act, gpre);
         };
         switch (h) {
@@ -380,9 +383,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_ring5_kernel(const GemmParams 
     }
 }
 
-template <typename T, typename YT, bool TRW, bool SEG, bool TRX = false>
+template <typename T, typename YT, bool TRW, bool SEG, bool TRX = false, bool AG = false>
 int launch_r5(const GemmParams& p, hipStream_t stream, int grid) {
-    hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, TRW, SEG, TRX>), dim3(grid), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL((gemm256_ring5_kernel<T, YT, TRW, SEG, TRX, AG>), dim3(grid), dim3(512), 0, stream, p);
     BF_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -450,6 +453,10 @@ int bf_launch_gemm256_r5_tn(const GemmParams& p, int dtype, hipStream_t stream, 
 // NN form (x K-contiguous, W contraction-major as sampled, 16-bit out): y[s][m][k] = sum_n x[s][m][n] w[s][n][k]
 int bf_launch_gemm256_r5_nn(const GemmParams& p, int dtype, hipStream_t stream, int grid) {
     const bool seg = p.segs > 1;
+    if (p.gpre) {  // the activation-gradient epilogue (one layer, no segments: checked by the caller)
+        if (dtype == BF_DT_BF16) return launch_r5<__bf16, __bf16, true, false, false, true>(p, stream, grid);
+        return launch_r5<_Float16, _Float16, true, false, false, true>(p, stream, grid);
+    }
     if (dtype == BF_DT_BF16)
         return seg ? launch_r5<__bf16, __bf16, true, true>(p, stream, grid) : launch_r5<__bf16, __bf16, true, false>(p, stream, grid);
     return seg ? launch_r5<_Float16, _Float16, true, true>(p, stream, grid) : launch_r5<_Float16, _Float16, true, false>(p, stream, grid);
