@@ -151,8 +151,11 @@ class GraphedForward:
 
     def __init__(self, model, args, kwargs, device, warmup: int = 1) -> None:
         self.model, self.device = model, device
-        self._args = tuple(a.clone() if isinstance(a, Tensor) else a for a in args)
-        self._kwargs = {k: (v.clone() if isinstance(v, Tensor) else v) for k, v in kwargs.items()}
+        # (the captured input buffers are written on every later call, possibly outside the torch.inference_mode() this call may
+        # be running under: they must be ordinary tensors, not inference tensors)
+        with torch.inference_mode(False):
+            self._args = tuple(a.clone() if isinstance(a, Tensor) else a for a in args)
+            self._kwargs = {k: (v.clone() if isinstance(v, Tensor) else v) for k, v in kwargs.items()}
         self.graph = self._static = None
         self.captures = 0
         self._warmup = max(1, int(warmup))
@@ -168,7 +171,7 @@ class GraphedForward:
         self.graph = self._static = None
         model = self.model
         total = model._mc_span[1]
-        with torch.no_grad(), torch.cuda.device(self.device):
+        with torch.inference_mode(False), torch.no_grad(), torch.cuda.device(self.device):
             for _ in range(self._warmup):  # plans, workspaces and tile schedules are built outside the capture
                 model._eager_call(*self._args, **self._kwargs)
             # the warm-up forwards consumed sample indices (and dropout call numbers) the caller never saw: hand them back

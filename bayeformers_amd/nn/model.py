@@ -167,7 +167,8 @@ class Model(Module):
             dev = layers[0].weight.mu.device
             buf = self._lp_buf
             if buf is None or buf.shape[0] != len(layers) or buf.shape[1] != S or buf.device != dev:
-                buf = self._lp_buf = torch.zeros((len(layers), S, 2), dtype=torch.float64, device=dev)
+                with torch.inference_mode(False):  # (kept across forwards, written in place by forwards of any mode)
+                    buf = self._lp_buf = torch.zeros((len(layers), S, 2), dtype=torch.float64, device=dev)
             slots = {id(l): buf[i] for i, l in enumerate(layers)}
         plan = None
         linears = [l for l in layers if isinstance(l, Linear)]

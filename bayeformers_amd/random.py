@@ -90,11 +90,14 @@ def use_device_counter(enable: bool = True, device="cuda") -> None:
     if enable:
         if STATE.device_counter is None:
             v = STATE.next_sample if STATE.next_sample < 2 ** 31 else STATE.next_sample - 2 ** 32
-            STATE.device_counter = torch.full((1,), v, dtype=torch.int32, device=device)
-            # the dropout `call` numbers move with it: the device counter takes over where the host's stands, the host part
-            # every later forward hands the kernels is 0
             c = STATE.next_dropout_call if STATE.next_dropout_call < 2 ** 31 else STATE.next_dropout_call - 2 ** 32
-            STATE.device_drop_counter = torch.full((1,), c, dtype=torch.int32, device=device)
+            # (ordinary tensors even when the caller runs under torch.inference_mode(): they are updated in place for the rest of
+            # the process, in whatever mode later forwards run)
+            with torch.inference_mode(False):
+                STATE.device_counter = torch.full((1,), v, dtype=torch.int32, device=device)
+                # the dropout `call` numbers move with it: the device counter takes over where the host's stands, the host part
+                # every later forward hands the kernels is 0
+                STATE.device_drop_counter = torch.full((1,), c, dtype=torch.int32, device=device)
         # the library keeps one pointer per HIP device, selected by the CURRENT device: make it the counter's
         with torch.cuda.device(STATE.device_counter.device):
             _C.check(_C.lib().bf_set_sample_counter(STATE.device_counter.data_ptr()), "bf_set_sample_counter")

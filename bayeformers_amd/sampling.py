@@ -345,7 +345,8 @@ class GraphedSampler:
         # the S_local-fold repeat of the batch is made ONCE, here: a new batch is copied into it (broadcast over the
         # sample axis) and the captured step starts at the model's forward
         self._signature = self._sig(inputs)
-        self._rep = self._map(inputs, lambda v: v.repeat(self._s_local, *([1] * (v.dim() - 1))) if v.dim() > 0 else v.clone())
+        with torch.inference_mode(False):  # (buffers that later calls write, in whatever mode they run: never inference tensors)
+            self._rep = self._map(inputs, lambda v: v.repeat(self._s_local, *([1] * (v.dim() - 1))) if v.dim() > 0 else v.clone())
         # the captured kernels hold the counter's ADDRESS: it must stay on the device until the last sampler is closed
         graphs.acquire_counter(self.device)
         self._open = True
@@ -368,7 +369,7 @@ class GraphedSampler:
         from . import random as bfr
 
         self.graph = self._static = None
-        with torch.no_grad(), torch.cuda.device(self.device):
+        with torch.inference_mode(False), torch.no_grad(), torch.cuda.device(self.device):
             for _ in range(self._warmup):  # plans, workspaces and tile schedules are built outside the capture
                 self._step()
             # the warm-up steps consumed sample indices the caller never saw: hand them back, so that the first replay

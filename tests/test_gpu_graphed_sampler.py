@@ -301,3 +301,53 @@ def test_model_call_stops_capturing_when_signatures_cycle():
             assert torch.equal(bmodel(**shapes[3]).logits, want)
     finally:
         bmodel._graphs.close()
+
+
+def test_replay_captured_under_inference_mode_takes_later_batches_under_no_grad():
+    """A forward captured while the caller runs under torch.inference_mode() keeps ordinary input buffers: a later call under
+    no_grad (or inference mode again) can still copy its batch in, and both equal the eager results."""
+    import bayeformers_amd as bf
+    from bayeformers_amd.sampling import GraphedSampler
+
+    bmodel, batches = _build()
+    bf.set_compute_dtype("bf16")
+    try:
+        bmodel.graph_replay = False
+        bf.manual_seed(SEED)
+        with torch.no_grad():
+            want = [bmodel(**batches[b]).logits.clone() for b in (0, 0, 0, 1, 1)]
+        bmodel.graph_replay = True
+        bf.manual_seed(SEED)
+        got = []
+        with torch.inference_mode():
+            for b in (0, 0, 0):          # the third call captures, inside inference mode
+                got.append(bmodel(**batches[b]).logits.clone())
+        with torch.no_grad():
+            got.append(bmodel(**batches[1]).logits.clone())
+        with torch.inference_mode():
+            got.append(bmodel(**batches[1]).logits.clone())
+        assert len(bmodel._graphs.forwards) == 1
+        for k, (g, w) in enumerate(zip(got, want)):
+            assert torch.equal(g, w), k
+        with torch.inference_mode():
+            sampler = GraphedSampler(bmodel, batches[0], 2)
+        with torch.no_grad():
+            sampler(batches[1])
+        sampler.close()
+    finally:
+        bmodel._graphs.close()
+
+
+def test_bench_serial_workload_reports_the_replayed_reference_loop():
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "bert_base_serial", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["hip_graph"] == "bnn.Model.__call__ replay" and "SERIAL" in d["config"]["workload"]
+    assert d["config"]["samples_per_step"] == 10 and d["value"] > 0 and d["roofline"]["launches_per_step"] == 480
