@@ -351,3 +351,30 @@ def test_bench_serial_workload_reports_the_replayed_reference_loop():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["config"]["hip_graph"] == "bnn.Model.__call__ replay" and "SERIAL" in d["config"]["workload"]
     assert d["config"]["samples_per_step"] == 10 and d["value"] > 0 and d["roofline"]["launches_per_step"] == 480
+
+
+def test_replay_of_the_reference_call_with_labels():
+    """The reference's loop passes the labels with the inputs and reads `model(**inputs)[1]` (examples/bert_glue.py:63): loss and
+    logits of a replayed forward equal the eager ones."""
+    import bayeformers_amd as bf
+
+    bmodel, batches = _build()
+    bf.set_compute_dtype("bf16")
+    labels = torch.tensor([0, 1, 1, 0], device="cuda")
+    inputs = dict(batches[0], labels=labels)
+
+    def loop(replay):
+        bmodel.graph_replay = replay
+        bf.manual_seed(SEED)
+        with torch.no_grad():
+            outs = [bmodel(**inputs) for _ in range(5)]
+        return [(o[0].clone(), o[1].clone()) for o in outs]
+
+    try:
+        eager, got = loop(False), loop(True)
+        assert len(bmodel._graphs.forwards) == 1
+        for k, (e, g) in enumerate(zip(eager, got)):
+            assert torch.equal(e[0], g[0]) and torch.equal(e[1], g[1]), k
+    finally:
+        bmodel.graph_replay = True
+        bmodel._graphs.close()
