@@ -338,3 +338,54 @@ def test_release_training_buffers_forgets_the_deferred_table():
     training.release_training_buffers(m)
     assert mgr.table is None and not mgr.armed
     training.release_training_buffers(M())   # nothing to release: no error
+
+
+def test_deferred_param_grads_decides_before_the_backward_pass():
+    """training.DeferredParamGrads without a GPU: the observe / arm / fall-back logic and the table it builds (host side only —
+    nothing is launched).  A step defers only when its forward showed exactly the layers, shapes and parameter addresses the table
+    was built for, each layer once, with no gradient standing on its parameters."""
+    import bayeformers_amd as bf
+    from bayeformers_amd import training
+
+    net = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 8, bias=False))
+    model = bf.to_bayesian(net)
+    l0, l1 = model.fused_children()
+    mgr = training.DeferredParamGrads()
+    S, M, cdt = 3, 256, torch.bfloat16
+
+    def forward(layers, m=M):
+        mgr.begin(model)
+        assert l0._bf_pg_defer is mgr and l1._bf_pg_defer is mgr
+        for l in layers:
+            mgr.note_forward(l, S, m, cdt)
+        mgr.decide()
+
+    forward([l0, l1])
+    assert not mgr.armed and mgr.table is not None            # first step: observed, table built for the next one
+    t = mgr.table
+    assert t["n"] == 3 and len(t["layers"]) == 2               # two weights and one bias
+    assert t["layers"][id(l1)][5] is None                      # no bias buffer for the bias-less layer
+    assert t["layers"][id(l0)][4].shape[0] == S and tuple(t["layers"][id(l0)][4].shape[2:]) == (32, 16)
+    assert {id(p) for p, _ in t["grads"]} == {id(l0.weight.rho), id(l0.weight.mu), id(l0.bias.rho), id(l0.bias.mu),
+                                               id(l1.weight.rho), id(l1.weight.mu)}
+    assert all(v.data_ptr() % 16 == 0 for _, v in t["grads"])  # every slot of the flat buffer on a 16-byte boundary
+    forward([l0, l1])
+    assert mgr.armed and mgr.table is t                         # same shapes: this step defers, on the same table
+    assert mgr.keep_buffer(l0, S, M, cdt, 1, 0) is t["layers"][id(l0)][4] and mgr.grad_view(l0.weight.rho).shape == (32, 16)
+    with pytest.raises(RuntimeError, match="does not match"):
+        mgr.keep_buffer(l0, S, M + 1, cdt, 1, 0)                # a backward that contradicts the armed forward: never half deferred
+    mgr.note_forward(l0, S, M, cdt)                             # (a block recomputed during backward: not observed any more)
+    forward([l0, l1], m=512)
+    assert not mgr.armed and mgr.table is not t                 # another batch shape: per-layer path now, re-armed for next time
+    forward([l0, l0, l1], m=512)
+    assert not mgr.armed and mgr.table is None                  # a layer used twice in one forward is never deferred
+    forward([l0, l1], m=512)
+    forward([l0, l1], m=512)
+    assert mgr.armed
+    l0.weight.rho.grad = torch.zeros_like(l0.weight.rho)        # a gradient already standing (accumulation): not this step
+    forward([l0, l1], m=512)
+    assert not mgr.armed
+    l0.weight.rho.grad = None
+    training.release_training_buffers(model)                     # (no manager on the model itself: nothing to do)
+    mgr.release()
+    assert mgr.table is None
