@@ -933,3 +933,39 @@ def test_ffn_pair_node_matches_the_two_layer_path():
     for n in g0:
         scale = g0[n].abs().max().item() + 1e-20
         assert (g0[n] - g1[n]).abs().max().item() <= 3e-2 * scale, (n, (g0[n] - g1[n]).abs().max().item() / scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("S,M,N,K", [(2, 200, 128, 1000),      # fewer rows than one tile, output width not a multiple of 256
+                                     (1, 4100, 256, 264),      # a ragged last row unit; one whole and one 8-wide column tile
+                                     (3, 33, 512, 520),        # two row units, the second with one row
+                                     (5, 1024, 768, 3072)])    # the BERT-base shape, scaled down in rows
+def test_gemm_nn_actgrad_ragged_shapes(dtype, S, M, N, K):
+    """bf_gemm_nn_actgrad at the edges of its tiling: the pre-activation chunks are fetched two row blocks ahead of their use,
+    so rows past M and columns past the last whole tile must neither be read nor written.  The output is allocated inside a
+    guard band that has to come back untouched."""
+    from bayeformers_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    dy = torch.randn(S, M, N, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(S, N, K, device="cuda", generator=g) * 0.05).to(dtype)
+    pre = (torch.randn(S, M, K, device="cuda", generator=g) * 1.5).to(dtype)
+    assert ops.gemm_nn_actgrad_supported(dy, w, pre)
+    from bayeformers_amd import _C
+
+    band, mark = 8192, 12345.0
+    buf = torch.full((S * M * K + 2 * band,), mark, device="cuda", dtype=dtype)
+    got = buf[band:band + S * M * K].view(S, M, K)
+    _C.check(_C.lib().bf_gemm_nn_actgrad(dy.data_ptr(), w.data_ptr(), got.data_ptr(), pre.data_ptr(), ops._TORCH2BF[dtype], S, M, N, K,
+                                         1, ops._stream_ptr()), "bf_gemm_nn_actgrad")
+    assert (buf[:band] == mark).all() and (buf[band + S * M * K:] == mark).all()
+    x = pre.float()
+    dgelu = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+    want = torch.einsum("smn,snk->smk", dy.float(), w.float()) * dgelu
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10  # one rounding of the product to the output type
+    assert (got.float() - want).abs().max().item() <= tol * want.abs().max().item()
+    # the same launch is the plain NN product followed by the derivative, to one more rounding of the intermediate
+    two_step = (ops.gemm_nn(dy, w).float() * dgelu)
+    assert (got.float() - two_step).abs().max().item() <= 2 * tol * want.abs().max().item()
+    assert torch.equal(got, ops.gemm_nn_actgrad(dy, w, pre))  # deterministic
